@@ -1,0 +1,69 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement (the "oracle") of the hot path of liron88/HM-16.2:
+ * TEncSlice::compressSlice and everything below it for I slices.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this code.
+ * The product library (hm-16.2_amd/csrc) never includes, links or calls anything in oracle/.
+ *
+ * Parity status: PINNED. The restatement is checked bit-for-bit against the real reference
+ * (oracle/_ref, built from /root/reference by oracle/Makefile.ref) through the fixtures in
+ * tests/golden/ that tests/gen_golden.py produced with oracle/_ref/hm_dump.
+ */
+#ifndef HM_ORACLE_H
+#define HM_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Sequence/slice parameters the reference's compressSlice reads through its members
+ * (SURVEY.md 8b "Inputs"): all-intra configuration of cfg/encoder_intra_main*.cfg. */
+typedef struct {
+  int width, height;        /* luma samples, multiples of 8 */
+  int bit_depth;            /* 8 or 10, luma == chroma */
+  int qp;                   /* slice QP (TEncSlice::initEncSlice, TEncSlice.cpp:293) */
+  int wpp;                  /* WaveFrontSynchro: CABAC sync per CTU row (TEncSlice.cpp:740-755,855-858) */
+  double lambda;            /* TComRdCost::m_dLambda (TEncSlice.cpp:323-352 -> setUpLambda :132) */
+  double chroma_weight;     /* TComRdCost::m_distortionWeight[Cb/Cr] (TEncSlice.cpp:146) */
+} hmo_cfg;
+
+/* Fills lambda and chroma_weight from qp exactly as TEncSlice::initEncSlice does for an I slice of an
+ * all-intra GOP (GOPSize 1, depth 0): lambda = 0.57 * 2^((qp-12)/3). */
+void hmo_cfg_set_qp(hmo_cfg *c, int qp);
+
+/* Per-CTU output, same fields and order as TComDataCU's per-partition arrays (256 4x4 partitions in
+ * z-scan order, TComDataCU.h:86-157) and the coefficient packing of m_pcTrCoeff (TU at zorder*16). */
+typedef struct {
+  double total_cost;
+  uint32_t total_bits, total_dist;
+  uint8_t depth[256], part_size[256], pred_mode[256], intra_dir_luma[256], intra_dir_chroma[256],
+          tr_idx[256], cbf[3][256], tskip[3][256];
+  int32_t coeff_y[4096], coeff_cb[1024], coeff_cr[1024];
+} hmo_ctu;
+
+/* The restated TEncSlice::compressSlice for one I picture.
+ *   org[3]  : original planes, uint16 samples, tightly packed (w x h, w/2 x h/2 x 2)
+ *   rec[3]  : reconstructed (pre-deblocking) planes out, same layout
+ *   ctus    : ceil(w/64)*ceil(h/64) records, raster order
+ * Returns 0, or a negative value on bad arguments. */
+int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus);
+
+/* Same, restricted to CTU rows [row0, row1) -- usable only when wpp==0 is false?  No: rows depend on
+ * each other, so this variant needs rec/ctus of rows < row0 already filled (used for bounded timing). */
+int hmo_compress_rows(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus,
+                      int max_ctus);
+
+/* ---- primitives, exported for the known-answer tests (TComRdCost.cpp / TComTrQuant.cpp) ---- */
+uint32_t hmo_sad(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int sub_shift, int bit_depth);
+uint32_t hmo_sse(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int bit_depth);
+uint32_t hmo_hads(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int bit_depth);
+void hmo_fwd_transform(int bit_depth, const int32_t *block, int32_t *coeff, int n, int use_dst);
+void hmo_inv_transform(int bit_depth, const int32_t *coeff, int32_t *block, int n, int use_dst);
+
+/* optional trace of every RD cost evaluation ("RD bits dist cost"), same text as oracle/_ref/hm_dump's HM_TRACE */
+void hmo_set_trace(const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,302 @@
+// TEST INFRASTRUCTURE ONLY (never linked into the product library).
+//
+// Harness that drives the REAL reference encoder (liron88/HM-16.2, compiled from
+// /root/reference by oracle/Makefile.ref) and dumps what the hot path leaves behind,
+// so that the CPU restatement in oracle/ and the HIP path can be pinned against it.
+//
+//   hm_dump enc  <HM options ...> --  <dump.bin>      per-CTU decision dump of every picture
+//   hm_dump kat  <kat.bin> <seed>                     known-answer vectors for the primitives
+//
+// Reference interfaces used (nothing is copied; we only call them):
+//   TAppEncTop::xInitLibCfg/xCreateLib/xInitLib   source/App/TAppEncoder/TAppEncTop.cpp:69,365,386
+//   TEncTop::encode                               source/Lib/TLibEncoder/TEncTop.cpp:259
+//   TComDataCU getters                            source/Lib/TLibCommon/TComDataCU.h
+//   xTrMxN / xITrMxN                              source/Lib/TLibCommon/TComTrQuant.cpp:836,894
+//   TComRdCost::getDistPart / setDistParam        source/Lib/TLibCommon/TComRdCost.cpp:433,356
+//
+// With HM_TRACE=<file> in the environment, every TComRdCost::calcRdCost call made by the
+// encoder is logged (bits, distortion, cost) through a link-time --wrap, which gives an
+// ordered trace of all RD decisions without touching the reference sources.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <list>
+#include <vector>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <algorithm>
+#include <limits>
+#include <map>
+#include <assert.h>
+#include <stdint.h>
+
+#define private public
+#define protected public
+#include "TAppEncTop.h"
+#include "TLibCommon/TComRdCost.h"
+#include "TLibCommon/TComTrQuant.h"
+#include "TLibCommon/TComPic.h"
+#undef private
+#undef protected
+
+// external-linkage functions of TComTrQuant.cpp (not declared in a header)
+Void xTrMxN(Int bitDepth, TCoeff *block, TCoeff *coeff, Int iWidth, Int iHeight, Bool useDST, const Int maxTrDynamicRange);
+Void xITrMxN(Int bitDepth, TCoeff *coeff, TCoeff *block, Int iWidth, Int iHeight, Bool useDST, const Int maxTrDynamicRange);
+
+// ---------------------------------------------------------------------------------------------
+// link-time trace of calcRdCost
+// ---------------------------------------------------------------------------------------------
+static FILE *g_trace = NULL;
+extern "C" Double __real__ZN10TComRdCost10calcRdCostEjjb5DFunc(TComRdCost *self, UInt bits, UInt dist, Bool flag, DFunc f);
+extern "C" Double __wrap__ZN10TComRdCost10calcRdCostEjjb5DFunc(TComRdCost *self, UInt bits, UInt dist, Bool flag, DFunc f)
+{
+  Double c = __real__ZN10TComRdCost10calcRdCostEjjb5DFunc(self, bits, dist, flag, f);
+  if (g_trace) fprintf(g_trace, "RD %u %u %.1f\n", bits, dist, c);
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dump format (little endian):
+//   header : "HMD1", u32 width, height, bitDepth, ctuSize, numFrames
+//   frame  : u32 poc, u32 numCtus, then per CTU (raster order):
+//              f64 totalCost, u32 totalBits, u32 totalDist,
+//              u8[256] depth, partSize, predMode, intraDirLuma, intraDirChroma, trIdx,
+//              cbfY, cbfCb, cbfCr, tskipY, tskipCb, tskipCr     (z-scan order, 4x4 units)
+//              i32[4096] coeffY, i32[1024] coeffCb, i32[1024] coeffCr  (HM's own TU packing)
+//            then the reconstructed planes of the picture (u16, w*h, w/2*h/2 *2), no margins
+// ---------------------------------------------------------------------------------------------
+static void put32(FILE *f, uint32_t v) { fwrite(&v, 4, 1, f); }
+
+static void dumpPic(FILE *f, TComPic *pic)
+{
+  TComPicSym *sym = pic->getPicSym();
+  const UInt numCtus = sym->getNumberOfCtusInFrame();
+  put32(f, (uint32_t)pic->getPOC());
+  put32(f, numCtus);
+  for (UInt a = 0; a < numCtus; a++)
+  {
+    TComDataCU *ctu = pic->getCtu(a);
+    double cost = ctu->getTotalCost();
+    fwrite(&cost, 8, 1, f);
+    put32(f, ctu->getTotalBits());
+    put32(f, (uint32_t)ctu->getTotalDistortion());
+    const UInt np = pic->getNumPartitionsInCtu();
+    assert(np == 256);
+    uint8_t buf[12][256];
+    for (UInt i = 0; i < np; i++)
+    {
+      buf[0][i] = ctu->getDepth(i);
+      buf[1][i] = (uint8_t)ctu->getPartitionSize(i);
+      buf[2][i] = (uint8_t)ctu->getPredictionMode(i);
+      buf[3][i] = ctu->getIntraDir(CHANNEL_TYPE_LUMA, i);
+      buf[4][i] = ctu->getIntraDir(CHANNEL_TYPE_CHROMA, i);
+      buf[5][i] = ctu->getTransformIdx(i);
+      buf[6][i] = ctu->getCbf(COMPONENT_Y)[i];
+      buf[7][i] = ctu->getCbf(COMPONENT_Cb)[i];
+      buf[8][i] = ctu->getCbf(COMPONENT_Cr)[i];
+      buf[9][i] = ctu->getTransformSkip(COMPONENT_Y)[i];
+      buf[10][i] = ctu->getTransformSkip(COMPONENT_Cb)[i];
+      buf[11][i] = ctu->getTransformSkip(COMPONENT_Cr)[i];
+    }
+    fwrite(buf, 1, sizeof(buf), f);
+    fwrite(ctu->getCoeff(COMPONENT_Y), 4, 4096, f);
+    fwrite(ctu->getCoeff(COMPONENT_Cb), 4, 1024, f);
+    fwrite(ctu->getCoeff(COMPONENT_Cr), 4, 1024, f);
+  }
+  TComPicYuv *rec = pic->getPicYuvRec();
+  for (int c = 0; c < 3; c++)
+  {
+    ComponentID id = ComponentID(c);
+    const Int w = rec->getWidth(id), h = rec->getHeight(id), s = rec->getStride(id);
+    const Pel *p = rec->getAddr(id);
+    std::vector<uint16_t> row(w);
+    for (Int y = 0; y < h; y++)
+    {
+      for (Int x = 0; x < w; x++) row[x] = (uint16_t)p[y * s + x];
+      fwrite(&row[0], 2, w, f);
+    }
+  }
+}
+
+static int runEnc(int argc, char **argv, const char *dumpName)
+{
+  TAppEncTop app;
+  app.create();
+  if (!app.parseCfg(argc, argv)) { app.destroy(); return 1; }
+
+  FILE *df = fopen(dumpName, "wb");
+  if (!df) { perror(dumpName); return 1; }
+  fwrite("HMD1", 1, 4, df);
+  put32(df, app.m_iSourceWidth); put32(df, app.m_iSourceHeight);
+  put32(df, app.m_internalBitDepth[0]); put32(df, app.m_uiMaxCUWidth); put32(df, app.m_framesToBeEncoded);
+
+  std::fstream bitstreamFile(app.m_pchBitstreamFile, std::fstream::binary | std::fstream::out);
+  TComPicYuv *pcPicYuvOrg = new TComPicYuv;
+  TComPicYuv *pcPicYuvRec = NULL;
+  app.xInitLibCfg();
+  app.xCreateLib();
+  app.xInitLib(app.m_isField);
+
+  Int iNumEncoded = 0;
+  Bool bEos = false;
+  const InputColourSpaceConversion ipCSC = app.m_inputColourSpaceConvert;
+  const InputColourSpaceConversion snrCSC = (!app.m_snrInternalColourSpace) ? app.m_inputColourSpaceConvert : IPCOLOURSPACE_UNCHANGED;
+  std::list<AccessUnit> outputAccessUnits;
+  TComPicYuv cPicYuvTrueOrg;
+  pcPicYuvOrg->create(app.m_iSourceWidth, app.m_iSourceHeight, app.m_chromaFormatIDC, app.m_uiMaxCUWidth, app.m_uiMaxCUHeight, app.m_uiMaxCUDepth);
+  cPicYuvTrueOrg.create(app.m_iSourceWidth, app.m_iSourceHeight, app.m_chromaFormatIDC, app.m_uiMaxCUWidth, app.m_uiMaxCUHeight, app.m_uiMaxCUDepth);
+
+  int nextPocToDump = 0;
+  while (!bEos)
+  {
+    app.xGetBuffer(pcPicYuvRec);
+    app.m_cTVideoIOYuvInputFile.read(pcPicYuvOrg, &cPicYuvTrueOrg, ipCSC, app.m_aiPad, app.m_InputChromaFormatIDC);
+    app.m_iFrameRcvd++;
+    bEos = (app.m_iFrameRcvd == app.m_framesToBeEncoded);
+    Bool flush = 0;
+    if (app.m_cTVideoIOYuvInputFile.isEof())
+    {
+      flush = true; bEos = true; app.m_iFrameRcvd--;
+      app.m_cTEncTop.setFramesToBeEncoded(app.m_iFrameRcvd);
+    }
+    app.m_cTEncTop.encode(bEos, flush ? 0 : pcPicYuvOrg, flush ? 0 : &cPicYuvTrueOrg, snrCSC, app.m_cListPicYuvRec, outputAccessUnits, iNumEncoded);
+    if (iNumEncoded > 0)
+    {
+      // every picture just encoded is still in the encoder's picture list, with its per-CTU data
+      TComList<TComPic*> *lst = app.m_cTEncTop.getListPic();
+      for (int k = 0; k < iNumEncoded; k++)
+      {
+        for (TComList<TComPic*>::iterator it = lst->begin(); it != lst->end(); ++it)
+        {
+          if ((*it)->getPOC() == nextPocToDump && (*it)->getReconMark()) { dumpPic(df, *it); break; }
+        }
+        nextPocToDump++;
+      }
+      app.xWriteOutput(bitstreamFile, iNumEncoded, outputAccessUnits);
+      outputAccessUnits.clear();
+    }
+  }
+  app.m_cTEncTop.printSummary(app.m_isField);
+  fclose(df);
+  // leak the rest on purpose: process exits
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// primitive known-answer vectors
+//   "KAT1", then records: u32 tag, u32 n_in, i32[n_in] params+inputs, u32 n_out, i32[n_out]
+//   tags: 1 SAD, 2 SSE, 3 HAD, 4 fwd transform, 5 inv transform
+// ---------------------------------------------------------------------------------------------
+static uint32_t g_rng = 1;
+static uint32_t rnd() { g_rng ^= g_rng << 13; g_rng ^= g_rng >> 17; g_rng ^= g_rng << 5; return g_rng; }
+
+static void putRec(FILE *f, uint32_t tag, const std::vector<int32_t> &in, const std::vector<int32_t> &out)
+{
+  put32(f, tag); put32(f, (uint32_t)in.size()); fwrite(in.data(), 4, in.size(), f);
+  put32(f, (uint32_t)out.size()); fwrite(out.data(), 4, out.size(), f);
+}
+
+static int runKat(const char *name, uint32_t seed)
+{
+  g_rng = seed ? seed : 1;
+  FILE *f = fopen(name, "wb");
+  if (!f) { perror(name); return 1; }
+  fwrite("KAT1", 1, 4, f);
+  initROM();
+  TComRdCost rd; rd.init();
+  const int sizes[5] = {4, 8, 16, 32, 64};
+  for (int bd = 8; bd <= 10; bd += 2)
+  {
+    g_bitDepth[0] = g_bitDepth[1] = bd;
+    g_maxTrDynamicRange[0] = g_maxTrDynamicRange[1] = 15;
+    const int maxv = (1 << bd) - 1;
+    for (int si = 0; si < 5; si++)
+    {
+      const int n = sizes[si];
+      for (int rep = 0; rep < 6; rep++)
+      {
+        std::vector<Pel> a(n * n), b(n * n);
+        const int spread = (rep < 2) ? maxv : (rep < 4 ? 40 : 6);
+        for (int i = 0; i < n * n; i++)
+        {
+          int base = rnd() % (maxv + 1);
+          a[i] = (Pel)base;
+          int d = (int)(rnd() % (2 * spread + 1)) - spread;
+          b[i] = (Pel)std::min(maxv, std::max(0, base + d));
+        }
+        std::vector<int32_t> in;
+        in.push_back(bd); in.push_back(n);
+        for (int i = 0; i < n * n; i++) in.push_back(a[i]);
+        for (int i = 0; i < n * n; i++) in.push_back(b[i]);
+        // SAD with sub-shift 0 and 1 (the FEN row subsampling of integer ME)
+        for (int sub = 0; sub < 2; sub++)
+        {
+          DistParam dp;
+          dp.pOrg = &a[0]; dp.pCur = &b[0]; dp.iStrideOrg = n; dp.iStrideCur = n; dp.iCols = n; dp.iRows = n;
+          dp.iStep = 1; dp.bApplyWeight = false; dp.bitDepth = bd; dp.iSubShift = sub;
+          rd.setDistParam(n, n, DF_SAD, dp);
+          dp.iSubShift = sub;
+          std::vector<int32_t> in2(in); in2.insert(in2.begin() + 2, sub);
+          std::vector<int32_t> out(1, (int32_t)dp.DistFunc(&dp));
+          putRec(f, 1, in2, out);
+        }
+        {
+          std::vector<int32_t> out(1, (int32_t)rd.getDistPart(bd, &b[0], n, &a[0], n, n, n, COMPONENT_Y, DF_SSE));
+          putRec(f, 2, in, out);
+        }
+        {
+          std::vector<int32_t> out(1, (int32_t)rd.getDistPart(bd, &b[0], n, &a[0], n, n, n, COMPONENT_Y, DF_HADS));
+          putRec(f, 3, in, out);
+        }
+        if (n <= 32)
+        {
+          for (int dst = 0; dst < (n == 4 ? 2 : 1); dst++)
+          {
+            std::vector<TCoeff> blk(n * n), coef(n * n), back(n * n);
+            for (int i = 0; i < n * n; i++) blk[i] = (TCoeff)a[i] - (TCoeff)b[i];
+            xTrMxN(bd, &blk[0], &coef[0], n, n, dst != 0, 15);
+            std::vector<int32_t> tin; tin.push_back(bd); tin.push_back(n); tin.push_back(dst);
+            for (int i = 0; i < n * n; i++) tin.push_back(blk[i]);
+            // xTrMxN clobbers nothing in blk; record output
+            std::vector<int32_t> tout(coef.begin(), coef.end());
+            putRec(f, 4, tin, tout);
+            // inverse of a sparsified / quantised-looking version
+            std::vector<TCoeff> q(n * n);
+            for (int i = 0; i < n * n; i++) q[i] = (rnd() % 4 == 0) ? (coef[i] / 8) * 8 : 0;
+            std::vector<TCoeff> qc(q);
+            xITrMxN(bd, &qc[0], &back[0], n, n, dst != 0, 15);
+            std::vector<int32_t> iin; iin.push_back(bd); iin.push_back(n); iin.push_back(dst);
+            for (int i = 0; i < n * n; i++) iin.push_back(q[i]);
+            std::vector<int32_t> iout(back.begin(), back.end());
+            putRec(f, 5, iin, iout);
+          }
+        }
+      }
+    }
+  }
+  fclose(f);
+  return 0;
+}
+
+int main(int argc, char **argv)
+{
+  if (getenv("HM_TRACE")) g_trace = fopen(getenv("HM_TRACE"), "w");
+  if (argc >= 4 && !strcmp(argv[1], "kat")) return runKat(argv[2], (uint32_t)atoi(argv[3]));
+  if (argc >= 4 && !strcmp(argv[1], "enc"))
+  {
+    // argv: hm_dump enc <HM options...> -- dump.bin
+    int sep = -1;
+    for (int i = 2; i < argc; i++) if (!strcmp(argv[i], "--")) sep = i;
+    if (sep < 0 || sep + 1 >= argc) { fprintf(stderr, "usage: hm_dump enc <HM options> -- <dump.bin>\n"); return 2; }
+    std::vector<char*> av; av.push_back(argv[0]);
+    for (int i = 2; i < sep; i++) av.push_back(argv[i]);
+    int rc = runEnc((int)av.size(), &av[0], argv[sep + 1]);
+    if (g_trace) fclose(g_trace);
+    return rc;
+  }
+  fprintf(stderr, "usage: hm_dump enc <HM options> -- <dump.bin> | hm_dump kat <kat.bin> <seed>\n");
+  return 2;
+}
