@@ -1,0 +1,310 @@
+// hm355 -- gfx950 kernels and the C ABI of include/hm355.h.
+//
+// One workgroup (one 64-lane wavefront) searches one CTU; a launch carries every CTU of every picture
+// in the batch whose dependencies are complete (see hm355_build_schedule).  Launches of consecutive
+// steps are ordered by the stream, which is also what makes the neighbours' reconstruction, decision
+// arrays and CABAC hand-off visible (kernel boundary == device-scope release/acquire).
+//
+// There is no CPU path in this library: every entry point needs a working HIP device.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "hm355_core.h"
+#include "hm355_host_common.h"
+#include "../../include/hm355.h"
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64) hm355_ctu_kernel(const Params *P, const WorkItem *items, int count)
+{
+  __shared__ Shared sh;
+  const int b = (int)blockIdx.x;
+  if (b >= count) return;
+  process_ctu(&sh, P, items + b, b);
+}
+
+// batched distortion primitives: one wavefront per n x n block pair
+extern "C" __global__ void __launch_bounds__(64) hm355_dist_kernel(int kind, int n, int bitDepth, int count, const Pel *org, const Pel *cur, uint32_t *out)
+{
+  for (int b = (int)blockIdx.x; b < count; b += (int)gridDim.x) {
+    const Pel *o = org + (size_t)b * n * n, *c = cur + (size_t)b * n * n;
+    uint32_t v;
+    if (kind == 0) v = dist_sad(o, n, c, n, n, 0, bitDepth);
+    else if (kind == 3) v = dist_sad(o, n, c, n, n, 1, bitDepth);
+    else if (kind == 1) v = dist_sse(o, n, c, n, n, bitDepth);
+    else v = dist_hads(o, n, c, n, n, bitDepth);
+    if (hm_lane() == 0) out[b] = v;
+  }
+}
+// batched transforms: LDS-staged, one wavefront per block
+extern "C" __global__ void __launch_bounds__(64) hm355_transform_kernel(int inverse, int n, int bitDepth, int useDst, int count, const int32_t *in, int32_t *out)
+{
+  __shared__ Shared sh;
+  load_tmat(&sh);
+  const int l2 = hm_log2(n);
+  for (int b = (int)blockIdx.x; b < count; b += (int)gridDim.x) {
+    const int32_t *src = in + (size_t)b * n * n; int32_t *dst = out + (size_t)b * n * n;
+    HM_PAR_FOR(i, n * n) sh.bufA[(i >> l2) * HM_TSTRIDE + (i & (n - 1))] = src[i];
+    HM_SYNC();
+    if (inverse) inv_transform(&sh, n, useDst, bitDepth); else fwd_transform(&sh, n, useDst, bitDepth);
+    HM_PAR_FOR(i, n * n) dst[i] = sh.bufA[(i >> l2) * HM_TSTRIDE + (i & (n - 1))];
+    HM_SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct Slot {           // one picture resident in HBM
+  FrameBuf fb;          // device pointers + slice parameters (host copy)
+};
+struct hm355_ctx {
+  hm355_seq_cfg cfg;
+  Params hp;            // host copy of the kernel parameters
+  Params *dP;
+  Tables *dTab;
+  FrameBuf *dFrames;
+  WorkSpace *dWs; size_t wsCount;
+  WorkItem *dItems; size_t itemsCap;
+  std::vector<Slot> slots;
+  std::vector<WorkItem> items; std::vector<int> stepStart; int schedFrames;
+  hipStream_t stream; hipEvent_t ev0, ev1;
+  double lastKernelMs; int lastLaunches;
+  std::string err;
+  int numCtus;
+  void *staging; size_t stagingBytes;
+};
+
+#define HM_CHECK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HM355_ERR_DEVICE; } } while (0)
+
+static int fail(hm355_ctx *c, int code, const char *msg) { if (c) c->err = msg; return code; }
+
+extern "C" const char *hm355_last_error(const hm355_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+static int maxItemsPerStep(int wCtu, int hCtu, int wpp, int frames)
+{
+  if (!wpp) return frames;
+  int best = 0;
+  for (int s = 0; s < wCtu + 2 * (hCtu - 1); s++) { int c = 0; for (int y = 0; y < hCtu; y++) { int x = s - 2 * y; if (x >= 0 && x < wCtu) c++; } if (c > best) best = c; }
+  return best * frames;
+}
+
+extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
+{
+  if (!cfg || !out) return HM355_ERR_ARG;
+  *out = NULL;
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || (cfg->bit_depth != 8 && cfg->bit_depth != 10) ||
+      cfg->ctu_size != 64 || cfg->max_cu_depth != 4 || cfg->tu_log2_max != 5 || cfg->tu_log2_min != 2 || cfg->tu_max_depth_intra != 3 ||
+      cfg->max_batch < 1 || (cfg->wavefront_synchro != 0 && cfg->wavefront_synchro != 1))
+    return HM355_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
+  hm355_ctx *c = new hm355_ctx();
+  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0;
+  c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0;
+  Params &P = c->hp; memset(&P, 0, sizeof(P));
+  P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
+  P.wCtu = (cfg->width + 63) / 64; P.hCtu = (cfg->height + 63) / 64;
+  P.stride[0] = P.wCtu * 64; P.stride[1] = P.stride[2] = P.wCtu * 32;
+  c->numCtus = P.wCtu * P.hCtu;
+  *out = c;   // from here on the caller destroys on failure
+  HM_CHECK(c, hipStreamCreate(&c->stream));
+  HM_CHECK(c, hipEventCreate(&c->ev0)); HM_CHECK(c, hipEventCreate(&c->ev1));
+  Tables *ht = new Tables; hm355_build_tables(ht);
+  hipError_t e = hipMalloc((void **)&c->dTab, sizeof(Tables));
+  if (e == hipSuccess) e = hipMemcpy(c->dTab, ht, sizeof(Tables), hipMemcpyHostToDevice);
+  delete ht;
+  HM_CHECK(c, e);
+  c->wsCount = (size_t)maxItemsPerStep(P.wCtu, P.hCtu, P.wpp, cfg->max_batch);
+  HM_CHECK(c, hipMalloc((void **)&c->dWs, c->wsCount * sizeof(WorkSpace)));
+  HM_CHECK(c, hipMalloc((void **)&c->dFrames, sizeof(FrameBuf) * cfg->max_batch));
+  HM_CHECK(c, hipMalloc((void **)&c->dP, sizeof(Params)));
+  c->slots.resize(cfg->max_batch);
+  for (int s = 0; s < cfg->max_batch; s++) {
+    FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
+    for (int k = 0; k < 3; k++) {
+      const size_t bytes = (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel);
+      HM_CHECK(c, hipMalloc((void **)&fb.org[k], bytes)); HM_CHECK(c, hipMemset(fb.org[k], 0, bytes));
+      HM_CHECK(c, hipMalloc((void **)&fb.rec[k], bytes)); HM_CHECK(c, hipMemset(fb.rec[k], 0, bytes));
+    }
+    HM_CHECK(c, hipMalloc((void **)&fb.meta, sizeof(CtuMeta) * c->numCtus));
+    HM_CHECK(c, hipMalloc((void **)&fb.coef, sizeof(TCoeff) * (size_t)c->numCtus * HM_COEF_CTU));
+    HM_CHECK(c, hipMalloc((void **)&fb.stat, sizeof(CtuStat) * c->numCtus));
+    HM_CHECK(c, hipMalloc((void **)&fb.endState, sizeof(Cabac) * c->numCtus));
+  }
+  P.tab = c->dTab; P.ws = c->dWs; P.frames = c->dFrames;
+  HM_CHECK(c, hipMemcpy(c->dP, &P, sizeof(Params), hipMemcpyHostToDevice));
+  return HM355_OK;
+}
+
+extern "C" void hm355_destroy(hm355_ctx *c)
+{
+  if (!c) return;
+  for (size_t s = 0; s < c->slots.size(); s++) {
+    FrameBuf &fb = c->slots[s].fb;
+    for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
+    if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState);
+  }
+  if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems);
+  if (c->staging) hipHostFree(c->staging);
+  if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int hm355_upload(hm355_ctx *c, int slot, const hm355_planes *org)
+{
+  if (!c || !org || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp; FrameBuf &fb = c->slots[slot].fb;
+  for (int k = 0; k < 3; k++) {
+    if (!org->plane[k]) return fail(c, HM355_ERR_ARG, "null plane");
+    const int w = P.width >> (k ? 1 : 0), h = P.height >> (k ? 1 : 0);
+    HM_CHECK(c, hipMemcpy2DAsync(fb.org[k], (size_t)P.stride[k] * sizeof(Pel), org->plane[k], (size_t)w * 2, (size_t)w * 2, h, hipMemcpyHostToDevice, c->stream));
+  }
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  return HM355_OK;
+}
+
+extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
+{
+  if (!c || !slices || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp;
+  std::vector<FrameBuf> fbs(n);
+  for (int f = 0; f < n; f++) {
+    if (slices[f].slice_type != 2) return fail(c, HM355_ERR_ARG, "only I slices are supported");
+    if (slices[f].qp < 0 || slices[f].qp > 51 || !(slices[f].lambda > 0) || !(slices[f].chroma_weight > 0)) return fail(c, HM355_ERR_ARG, "bad slice parameters");
+    hm355_fill_slice_params(&c->slots[f].fb, P.bitDepth, slices[f].qp, slices[f].lambda, slices[f].chroma_weight);
+    fbs[f] = c->slots[f].fb;
+  }
+  HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
+  if (c->schedFrames != n) {
+    hm355_build_schedule(P.wCtu, P.hCtu, P.wpp, n, c->items, c->stepStart);
+    if (c->items.size() > c->itemsCap) {
+      if (c->dItems) hipFree(c->dItems);
+      c->dItems = NULL; c->itemsCap = 0;
+      HM_CHECK(c, hipMalloc((void **)&c->dItems, sizeof(WorkItem) * c->items.size()));
+      c->itemsCap = c->items.size();
+    }
+    HM_CHECK(c, hipMemcpyAsync(c->dItems, c->items.data(), sizeof(WorkItem) * c->items.size(), hipMemcpyHostToDevice, c->stream));
+    c->schedFrames = n;
+  }
+  HM_CHECK(c, hipStreamSynchronize(c->stream));   // fbs / items must stay valid until copied
+  HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
+  const int steps = (int)c->stepStart.size() - 1;
+  int launches = 0;
+  for (int s = 0; s < steps; s++) {
+    const int start = c->stepStart[s], count = c->stepStart[s + 1] - start;
+    if (count <= 0) continue;
+    if ((size_t)count > c->wsCount) return fail(c, HM355_ERR_DEVICE, "internal: step larger than workspace");
+    hipLaunchKernelGGL(hm355_ctu_kernel, dim3(count), dim3(64), 0, c->stream, (const Params *)c->dP, (const WorkItem *)(c->dItems + start), count);
+    launches++;
+  }
+  HM_CHECK(c, hipGetLastError());
+  HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->lastKernelMs = ms; c->lastLaunches = launches;
+  return HM355_OK;
+}
+
+extern "C" int hm355_last_run_info(const hm355_ctx *c, double *kernel_ms, int *launches)
+{
+  if (!c) return HM355_ERR_ARG;
+  if (kernel_ms) *kernel_ms = c->lastKernelMs;
+  if (launches) *launches = c->lastLaunches;
+  return HM355_OK;
+}
+
+extern "C" int hm355_download(hm355_ctx *c, int slot, hm355_planes *rec, hm355_ctu_out *ctus, hm355_slice_stats *stats)
+{
+  if (!c || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp; FrameBuf &fb = c->slots[slot].fb;
+  if (rec)
+    for (int k = 0; k < 3; k++) {
+      if (!rec->plane[k]) return fail(c, HM355_ERR_ARG, "null plane");
+      const int w = P.width >> (k ? 1 : 0), h = P.height >> (k ? 1 : 0);
+      HM_CHECK(c, hipMemcpy2D(rec->plane[k], (size_t)w * 2, fb.rec[k], (size_t)P.stride[k] * sizeof(Pel), (size_t)w * 2, h, hipMemcpyDeviceToHost));
+    }
+  if (ctus || stats) {
+    std::vector<CtuStat> st(c->numCtus);
+    HM_CHECK(c, hipMemcpy(st.data(), fb.stat, sizeof(CtuStat) * c->numCtus, hipMemcpyDeviceToHost));
+    if (stats) {
+      stats->pic_total_bits = 0; stats->pic_rd_cost = 0; stats->pic_dist = 0;
+      for (int a = 0; a < c->numCtus; a++) { stats->pic_total_bits += st[a].bits; stats->pic_rd_cost += st[a].cost; stats->pic_dist += st[a].dist; }
+    }
+    if (ctus) {
+      std::vector<CtuMeta> meta(c->numCtus);
+      std::vector<TCoeff> coef((size_t)c->numCtus * HM_COEF_CTU);
+      HM_CHECK(c, hipMemcpy(meta.data(), fb.meta, sizeof(CtuMeta) * c->numCtus, hipMemcpyDeviceToHost));
+      HM_CHECK(c, hipMemcpy(coef.data(), fb.coef, sizeof(TCoeff) * coef.size(), hipMemcpyDeviceToHost));
+      for (int a = 0; a < c->numCtus; a++) {
+        hm355_ctu_out *o = ctus + a; const CtuMeta *m = &meta[a];
+        o->total_cost = st[a].cost; o->total_bits = st[a].bits; o->total_dist = st[a].dist;
+        memcpy(o->depth, m->depth, 256); memcpy(o->part_size, m->part, 256); memcpy(o->pred_mode, m->pred, 256);
+        memcpy(o->intra_dir_luma, m->dirL, 256); memcpy(o->intra_dir_chroma, m->dirC, 256); memcpy(o->tr_idx, m->tr, 256);
+        memcpy(o->cbf, m->cbf, 768); memcpy(o->tskip, m->ts, 768);
+        const TCoeff *cf = coef.data() + (size_t)a * HM_COEF_CTU;
+        memcpy(o->coeff_y, cf, 4096 * 4); memcpy(o->coeff_cb, cf + 4096, 1024 * 4); memcpy(o->coeff_cr, cf + 5120, 1024 * 4);
+      }
+    }
+  }
+  return HM355_OK;
+}
+
+extern "C" int hm355_compress_slices(hm355_ctx *c, int n, const hm355_slice_desc *slices, const hm355_planes *org,
+                                     hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_slice_stats *stats)
+{
+  if (!c || !slices || !org || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  int rc;
+  for (int f = 0; f < n; f++) if ((rc = hm355_upload(c, f, org + f)) != HM355_OK) return rc;
+  if ((rc = hm355_run(c, n, slices)) != HM355_OK) return rc;
+  for (int f = 0; f < n; f++)
+    if ((rc = hm355_download(c, f, rec ? rec + f : NULL, ctus ? ctus[f] : NULL, stats ? stats + f : NULL)) != HM355_OK) return rc;
+  return HM355_OK;
+}
+
+extern "C" int hm355_compress_slice(hm355_ctx *c, const hm355_slice_desc *slice, const hm355_planes *org,
+                                    hm355_planes *rec, hm355_ctu_out *ctus, hm355_slice_stats *stats)
+{
+  hm355_ctu_out *cl[1] = { ctus };
+  return hm355_compress_slices(c, 1, slice, org, rec, ctus ? cl : NULL, stats);
+}
+
+// ------------------------------------------------------------------------------------------------
+// primitive batches
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm355_dist_batch(hm355_ctx *c, int kind, int n, int bit_depth, int count, const int16_t *org, const int16_t *cur, uint32_t *out)
+{
+  if (!c || !org || !cur || !out || count < 1 || kind < 0 || kind > 3 || (n != 4 && n != 8 && n != 16 && n != 32 && n != 64) || (bit_depth != 8 && bit_depth != 10)) return HM355_ERR_ARG;
+  const size_t bytes = (size_t)count * n * n * sizeof(Pel);
+  Pel *dO = NULL, *dC = NULL; uint32_t *dOut = NULL;
+  int rc = HM355_OK;
+  if (hipMalloc((void **)&dO, bytes) != hipSuccess || hipMalloc((void **)&dC, bytes) != hipSuccess || hipMalloc((void **)&dOut, (size_t)count * 4) != hipSuccess) rc = HM355_ERR_NOMEM;
+  if (rc == HM355_OK && (hipMemcpy(dO, org, bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dC, cur, bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = HM355_ERR_DEVICE;
+  if (rc == HM355_OK) {
+    const int grid = count < 65536 ? count : 65536;
+    hipLaunchKernelGGL(hm355_dist_kernel, dim3(grid), dim3(64), 0, c->stream, kind, n, bit_depth, count, (const Pel *)dO, (const Pel *)dC, dOut);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, dOut, (size_t)count * 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = HM355_ERR_DEVICE; c->err = "dist kernel failed"; }
+  }
+  if (dO) hipFree(dO); if (dC) hipFree(dC); if (dOut) hipFree(dOut);
+  return rc;
+}
+
+extern "C" int hm355_transform_batch(hm355_ctx *c, int inverse, int n, int bit_depth, int use_dst, int count, const int32_t *in, int32_t *out)
+{
+  if (!c || !in || !out || count < 1 || (n != 4 && n != 8 && n != 16 && n != 32) || (bit_depth != 8 && bit_depth != 10) || (use_dst && n != 4)) return HM355_ERR_ARG;
+  const size_t bytes = (size_t)count * n * n * 4;
+  int32_t *dI = NULL, *dOut = NULL; int rc = HM355_OK;
+  if (hipMalloc((void **)&dI, bytes) != hipSuccess || hipMalloc((void **)&dOut, bytes) != hipSuccess) rc = HM355_ERR_NOMEM;
+  if (rc == HM355_OK && hipMemcpy(dI, in, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = HM355_ERR_DEVICE;
+  if (rc == HM355_OK) {
+    const int grid = count < 65536 ? count : 65536;
+    hipLaunchKernelGGL(hm355_transform_kernel, dim3(grid), dim3(64), 0, c->stream, inverse, n, bit_depth, use_dst, count, (const int32_t *)dI, dOut);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, dOut, bytes, hipMemcpyDeviceToHost) != hipSuccess) { rc = HM355_ERR_DEVICE; c->err = "transform kernel failed"; }
+  }
+  if (dI) hipFree(dI); if (dOut) hipFree(dOut);
+  return rc;
+}

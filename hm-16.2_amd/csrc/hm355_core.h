@@ -1,0 +1,1749 @@
+// hm355 -- CTU rate-distortion search of an HM-16.2-shaped intra encoder, written for one 64-lane
+// CDNA4 wavefront per CTU.
+//
+// Execution model of this file
+//   * One workgroup == one wavefront (64 lanes) == one CTU in flight.  Control flow is wave-uniform:
+//     every lane runs the decision logic on identical values (kept in LDS / HBM scratch), so there is
+//     no divergence and no lane-0 bottleneck on branches.
+//   * Sample / coefficient work (reference-sample fetch, the 35 predictors, residual, 4..32-point
+//     separable transforms, de-quantisation, reconstruction, SAD/SSE/SATD) is spread over the lanes
+//     with HM_PAR_FOR and finished by a DPP/shuffle butterfly reduction (hm_wave_sum).
+//   * Transform blocks are staged through LDS with a padded stride (33 words) so that the row pass
+//     and the column pass are both bank-conflict free; the transform matrix sits in LDS too.
+//   * The CABAC estimator state (163 context bytes + Q15 accumulator) and its 5x6 snapshots stay in
+//     LDS; snapshot copies are 22 eight-byte LDS moves.
+// The file is plain C++: hm355_kernels.hip compiles it for gfx950; tests/hostsim compiles the very
+// same source for the host with HM_NT == 1 (a debugging aid only -- it is not part of the product
+// library and nothing in the product can reach it).
+//
+// What it restates (file:line under /root/reference/source/Lib): see each function.
+#pragma once
+#include "hm355_types.h"
+
+#ifdef HM355_HOSTSIM
+#include <string.h>
+#include <math.h>
+#include <stdlib.h>
+#define HM_DEV static
+#define HM_NOINLINE __attribute__((noinline))
+#define HM_CONST static const
+#define HM_NT 1
+static inline int hm_lane() { return 0; }
+#define HM_SYNC() ((void)0)
+static inline uint32_t hm_wave_sum(uint32_t v) { return v; }
+static inline int hm_wave_sum_i(int v) { return v; }
+#ifdef HM355_HOSTSIM_REVERSE   /* run every lane-parallel loop backwards: catches order dependence */
+#define HM_PAR_FOR(i, n) for (int i = (n) - 1; i >= 0; i--)
+#else
+#define HM_PAR_FOR(i, n) for (int i = 0; i < (n); i++)
+#endif
+#else
+#define HM_DEV __device__
+#define HM_NOINLINE __attribute__((noinline))
+#define HM_CONST __device__ const
+#define HM_NT 64
+__device__ __forceinline__ int hm_lane() { return (int)threadIdx.x; }
+#define HM_SYNC() __syncthreads()
+__device__ __forceinline__ uint32_t hm_wave_sum(uint32_t v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int hm_wave_sum_i(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+#define HM_PAR_FOR(i, n) for (int i = hm_lane(); i < (n); i += HM_NT)
+#endif
+
+#define HM_MAX_DOUBLE 1.7e+308
+#define PLANAR_IDX 0
+#define DC_IDX 1
+#define HOR_IDX 10
+#define VER_IDX 26
+#define DM_CHROMA_IDX 36
+#define SIZE_2Nx2N 0
+#define SIZE_NxN 3
+#define SIZE_NONE 8
+#define MODE_INTRA 1
+#define MODE_NONE 2
+#define SCAN_DIAG 0
+#define SCAN_HOR 1
+#define SCAN_VER 2
+
+// ------------------------------------------------------------------------------------------------
+// constant tables
+// ------------------------------------------------------------------------------------------------
+// ContextModel.cpp:66-128 (FAST_BIT_EST)
+HM_CONST uint8_t HM_NEXT_MPS[128] = {
+  2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
+  34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65,
+  66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97,
+  98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 124, 125, 126, 127 };
+HM_CONST uint8_t HM_NEXT_LPS[128] = {
+  1, 0, 0, 1, 2, 3, 4, 5, 4, 5, 8, 9, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 18, 19, 22, 23, 22, 23, 24, 25,
+  26, 27, 26, 27, 30, 31, 30, 31, 32, 33, 32, 33, 36, 37, 36, 37, 38, 39, 38, 39, 42, 43, 42, 43, 44, 45, 44, 45, 46, 47, 48, 49,
+  48, 49, 50, 51, 52, 53, 52, 53, 54, 55, 54, 55, 56, 57, 58, 59, 58, 59, 60, 61, 60, 61, 60, 61, 62, 63, 64, 65, 64, 65, 66, 67,
+  66, 67, 66, 67, 68, 69, 68, 69, 70, 71, 70, 71, 70, 71, 72, 73, 72, 73, 72, 73, 74, 75, 74, 75, 74, 75, 76, 77, 76, 77, 126, 127 };
+HM_CONST int32_t HM_ENTROPY_BITS[128] = {
+  0x07b23, 0x085f9, 0x074a0, 0x08cbc, 0x06ee4, 0x09354, 0x067f4, 0x09c1b, 0x060b0, 0x0a62a, 0x05a9c, 0x0af5b, 0x0548d, 0x0b955, 0x04f56, 0x0c2a9,
+  0x04a87, 0x0cbf7, 0x045d6, 0x0d5c3, 0x04144, 0x0e01b, 0x03d88, 0x0e937, 0x039e0, 0x0f2cd, 0x03663, 0x0fc9e, 0x03347, 0x10600, 0x03050, 0x10f95,
+  0x02d4d, 0x11a02, 0x02ad3, 0x12333, 0x0286e, 0x12cad, 0x02604, 0x136df, 0x02425, 0x13f48, 0x021f4, 0x149c4, 0x0203e, 0x1527b, 0x01e4d, 0x15d00,
+  0x01c99, 0x166de, 0x01b18, 0x17017, 0x019a5, 0x17988, 0x01841, 0x18327, 0x016df, 0x18d50, 0x015d9, 0x19547, 0x0147c, 0x1a083, 0x0138e, 0x1a8a3,
+  0x01251, 0x1b418, 0x01166, 0x1bd27, 0x01068, 0x1c77b, 0x00f7f, 0x1d18e, 0x00eda, 0x1d91a, 0x00e19, 0x1e254, 0x00d4f, 0x1ec9a, 0x00c90, 0x1f6e0,
+  0x00c01, 0x1fef8, 0x00b5f, 0x208b1, 0x00ab6, 0x21362, 0x00a15, 0x21e46, 0x00988, 0x2285d, 0x00934, 0x22ea8, 0x008a8, 0x239b2, 0x0081d, 0x24577,
+  0x007c9, 0x24ce6, 0x00763, 0x25663, 0x00710, 0x25e8f, 0x006a0, 0x26a26, 0x00672, 0x26f23, 0x005e8, 0x27ef8, 0x005ba, 0x284b5, 0x0055e, 0x29057,
+  0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f, 0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb };
+// I-slice context initialisation values, ContextTables.h:170-502 (our context order, see hm355_types.h)
+HM_CONST uint8_t HM_CTX_INIT_I[HM_NUM_CTX] = {
+  139, 141, 157,   184, 154, 154, 154,   184,   63, 139,   153, 138, 138,
+  111, 141, 154, 154, 154, 94, 138, 182, 154, 154,   91, 171, 134, 141,
+  111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 141,
+  140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 111,
+  110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
+  138, 153, 136, 167, 152, 152,   139, 139 };
+// first column of the 32-point core transform (TComRom.cpp:456-484); the matrix follows the cosine index law
+HM_CONST int8_t HM_DCT_C[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
+HM_CONST int8_t HM_DST4[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
+HM_CONST int32_t HM_QUANT_SCALES[6] = {26214, 23302, 20560, 18396, 16384, 14564};
+HM_CONST int32_t HM_INV_QUANT_SCALES[6] = {40, 45, 51, 57, 64, 72};
+HM_CONST uint8_t HM_GROUP_IDX[32] = {0,1,2,3,4,4,5,5,6,6,6,6,7,7,7,7,8,8,8,8,8,8,8,8,9,9,9,9,9,9,9,9};
+HM_CONST uint8_t HM_CTX_IND_MAP_4x4[16] = {0,1,4,5, 2,3,4,5, 6,6,8,8, 7,7,8,8};
+HM_CONST uint8_t HM_INTRA_MODE_NUM_FAST[6] = {3, 8, 8, 3, 3, 3};
+HM_CONST uint8_t HM_INTRA_FILTER[5] = {10, 7, 1, 0, 10};
+HM_CONST int8_t HM_ANG_TABLE[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+HM_CONST int16_t HM_INV_ANG_TABLE[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256};
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident state of one CTU search
+// ------------------------------------------------------------------------------------------------
+#define HM_TSTRIDE 33
+struct Shared {
+  Cabac cur;                         // m_pcRDGoOnSbacCoder
+  Cabac slot[5][CI_NUM];             // m_pppcRDSbacCoder[depth][CI_*]
+  int32_t tmat[32 * HM_TSTRIDE];     // 32-point transform matrix, padded rows
+  int32_t bufA[32 * HM_TSTRIDE], bufB[32 * HM_TSTRIDE];
+  Pel refTop[2][132], refLeft[2][132];        // [filtered][0 = corner, 1..2N]
+  Pel refMain[200], refSide[200];             // angular: extended main / side reference, origin at +64
+  Pel tsPred[3][16], tsRec[3][16];            // transform-skip trial of a 4x4 block
+  TCoeff tsCoef[3][16];
+  uint8_t flags[72];
+  Pel line[272];
+  // uniform per-CTU context
+  const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
+  CtuMeta *cm; TCoeff *cc;
+  int32_t ctuX, ctuY, ctuAddr;
+};
+
+HM_DEV inline int hm_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+HM_DEV inline int hm_abs(int v) { return v < 0 ? -v : v; }
+HM_DEV inline int hm_log2(int n) { return n >= 64 ? 6 : (n >= 32 ? 5 : (n >= 16 ? 4 : (n >= 8 ? 3 : 2))); }
+
+// lane-parallel byte fill / copies (uniform arguments)
+HM_DEV inline void par_set8(uint8_t *p, int v, int n) { HM_PAR_FOR(i, n) p[i] = (uint8_t)v; HM_SYNC(); }
+HM_DEV inline void par_copy8(uint8_t *d, const uint8_t *s, int n) { HM_PAR_FOR(i, n) d[i] = s[i]; HM_SYNC(); }
+HM_DEV inline void par_copy32(TCoeff *d, const TCoeff *s, int n) { HM_PAR_FOR(i, n) d[i] = s[i]; HM_SYNC(); }
+HM_DEV inline void par_zero32(TCoeff *d, int n) { HM_PAR_FOR(i, n) d[i] = 0; HM_SYNC(); }
+// n x n block copy between two strided planes
+HM_DEV inline void par_copy_blk(Pel *d, int ds, const Pel *s, int ss, int n)
+{
+  const int l2 = hm_log2(n);
+  HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); d[y * ds + x] = s[y * ss + x]; }
+  HM_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------
+// CABAC bit estimator (TEncBinCABACCounter, TEncBinCoderCABACCounter.cpp:56-131)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline void cabac_copy(Cabac *d, const Cabac *s)
+{ // TEncSbac::load/store, TEncSbac.cpp:396-421: the whole context array + m_fracBits
+  const uint64_t *sp = (const uint64_t *)s; uint64_t *dp = (uint64_t *)d;
+  HM_PAR_FOR(i, (int)(sizeof(Cabac) / 8)) dp[i] = sp[i];
+  HM_SYNC();
+}
+HM_DEV inline void cabac_init(Cabac *c, int qp)
+{ // ContextModel::init, ContextModel.cpp:55-64; TEncSbac::resetEntropy, TEncSbac.cpp:106-161
+  qp = hm_clip3(0, 51, qp);
+  HM_PAR_FOR(i, HM_NUM_CTX) {
+    const int iv = HM_CTX_INIT_I[i];
+    const int slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
+    int st = ((slope * qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
+    const int mps = st >= 64;
+    c->s[i] = (uint8_t)(((mps ? (st - 64) : (63 - st)) << 1) + mps);
+  }
+  c->frac = 0;
+  HM_SYNC();
+}
+HM_DEV inline void enc_bin(Cabac *c, int ctx, int bin)
+{
+  const uint8_t st = c->s[ctx];
+  c->frac += (uint64_t)HM_ENTROPY_BITS[st ^ bin];
+  c->s[ctx] = ((st & 1) == bin) ? HM_NEXT_MPS[st] : HM_NEXT_LPS[st];
+}
+HM_DEV inline void enc_ep(Cabac *c, int n) { c->frac += (uint64_t)32768 * (uint64_t)n; }
+HM_DEV inline void enc_trm(Cabac *c, int bin) { c->frac += (uint64_t)HM_ENTROPY_BITS[126 ^ bin]; }
+HM_DEV inline void reset_bits(Cabac *c) { c->frac &= 32767; }           // TEncBinCoderCABAC.cpp:161
+HM_DEV inline uint32_t num_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
+HM_DEV inline int ebits(const Cabac *c, int ctx, int bin) { return HM_ENTROPY_BITS[c->s[ctx] ^ bin]; }
+
+HM_DEV inline double calc_rd_cost(const Shared *e, uint32_t bits, uint32_t dist)
+{ // TComRdCost::calcRdCost, TComRdCost.cpp:56-123 (DF_DEFAULT, lossy)
+  const double t = (double)bits * e->fb.lambda;
+  const double u = (double)dist + t;
+  return floor(u + 0.5);
+}
+
+// ------------------------------------------------------------------------------------------------
+// distortion (TComRdCost.cpp): lanes split the samples / the Hadamard blocks, butterfly-reduce
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline uint32_t dist_sse(const Pel *org, int so, const Pel *cur, int sc, int n, int bitDepth)
+{ // xGetSSE*, TComRdCost.cpp:970-1318
+  const int shift = (bitDepth - 8) << 1, l2 = hm_log2(n);
+  uint32_t sum = 0;
+  HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int d = org[y * so + x] - cur[y * sc + x]; sum += (uint32_t)((d * d) >> shift); }
+  return hm_wave_sum(sum);
+}
+HM_DEV inline uint32_t had8(const Pel *org, int so, const Pel *cur, int sc)
+{ // xCalcHADs8x8, TComRdCost.cpp:1439-1530: sum |H8 D H8|, (s+2)>>2
+  int d[64];
+#pragma unroll
+  for (int y = 0; y < 8; y++)
+#pragma unroll
+    for (int x = 0; x < 8; x++) d[y * 8 + x] = org[y * so + x] - cur[y * sc + x];
+#pragma unroll
+  for (int y = 0; y < 8; y++) {
+#pragma unroll
+    for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+      for (int b = 0; b < 8; b += len << 1)
+#pragma unroll
+        for (int k = 0; k < len; k++) { const int a0 = d[y * 8 + b + k], a1 = d[y * 8 + b + k + len]; d[y * 8 + b + k] = a0 + a1; d[y * 8 + b + k + len] = a0 - a1; }
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int x = 0; x < 8; x++) {
+#pragma unroll
+    for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+      for (int b = 0; b < 8; b += len << 1)
+#pragma unroll
+        for (int k = 0; k < len; k++) { const int a0 = d[(b + k) * 8 + x], a1 = d[(b + k + len) * 8 + x]; d[(b + k) * 8 + x] = a0 + a1; d[(b + k + len) * 8 + x] = a0 - a1; }
+#pragma unroll
+    for (int y = 0; y < 8; y++) s += (uint32_t)hm_abs(d[y * 8 + x]);
+  }
+  return (s + 2) >> 2;
+}
+HM_DEV inline uint32_t had4(const Pel *org, int so, const Pel *cur, int sc)
+{ // xCalcHADs4x4, TComRdCost.cpp:1343-1437: sum |H4 D H4|, (s+1)>>1
+  int d[16];
+#pragma unroll
+  for (int y = 0; y < 4; y++)
+#pragma unroll
+    for (int x = 0; x < 4; x++) d[y * 4 + x] = org[y * so + x] - cur[y * sc + x];
+#pragma unroll
+  for (int y = 0; y < 4; y++) {
+    const int a = d[y * 4] + d[y * 4 + 1], b = d[y * 4] - d[y * 4 + 1], c = d[y * 4 + 2] + d[y * 4 + 3], e = d[y * 4 + 2] - d[y * 4 + 3];
+    d[y * 4] = a + c; d[y * 4 + 1] = b + e; d[y * 4 + 2] = a - c; d[y * 4 + 3] = b - e;
+  }
+  uint32_t s = 0;
+#pragma unroll
+  for (int x = 0; x < 4; x++) {
+    const int a = d[x] + d[4 + x], b = d[x] - d[4 + x], c = d[8 + x] + d[12 + x], e = d[8 + x] - d[12 + x];
+    s += (uint32_t)(hm_abs(a + c) + hm_abs(b + e) + hm_abs(a - c) + hm_abs(b - e));
+  }
+  return (s + 1) >> 1;
+}
+HM_DEV inline uint32_t dist_hads(const Pel *org, int so, const Pel *cur, int sc, int n, int bitDepth)
+{ // xGetHADs, TComRdCost.cpp:1537-1606
+  uint32_t sum = 0;
+  if (n >= 8) { const int nb = n >> 3; HM_PAR_FOR(b, nb * nb) { const int by = b / nb, bx = b - by * nb; sum += had8(org + by * 8 * so + bx * 8, so, cur + by * 8 * sc + bx * 8, sc); } }
+  else { HM_PAR_FOR(b, 1) sum += had4(org, so, cur, sc); }
+  return hm_wave_sum(sum) >> (bitDepth - 8);
+}
+HM_DEV inline uint32_t dist_sad(const Pel *org, int so, const Pel *cur, int sc, int n, int subShift, int bitDepth)
+{ // xGetSAD*, TComRdCost.cpp:465-962
+  const int l2 = hm_log2(n), rows = n >> subShift;
+  uint32_t sum = 0;
+  HM_PAR_FOR(i, rows * n) { const int y = (i >> l2) << subShift, x = i & (n - 1); sum += (uint32_t)hm_abs(org[y * so + x] - cur[y * sc + x]); }
+  return (hm_wave_sum(sum) << subShift) >> (bitDepth - 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// transforms (TComTrQuant.cpp:387-935).  Blocks live in LDS with row stride HM_TSTRIDE.
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline void load_tmat(Shared *e)
+{
+  HM_PAR_FOR(i, 1024) {
+    const int k = i >> 5, n = i & 31, m = (k * (2 * n + 1)) & 127;
+    int v;
+    if (m <= 32) v = HM_DCT_C[m]; else if (m <= 64) v = -HM_DCT_C[64 - m]; else if (m <= 96) v = -HM_DCT_C[m - 64]; else v = HM_DCT_C[128 - m];
+    e->tmat[k * HM_TSTRIDE + n] = v;
+  }
+  HM_SYNC();
+}
+HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst ? HM_DST4[k * 4 + j] : e->tmat[(k * (32 / n)) * HM_TSTRIDE + j]; }
+
+// forward: src (bufA, [row][col]) -> dst (bufA); xTrMxN, TComTrQuant.cpp:836-890
+HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth)
+{
+  const int l2 = hm_log2(n), s1 = l2 + bitDepth + 6 - 15, s2 = l2 + 6;
+  const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
+  int32_t *A = e->bufA, *B = e->bufB;
+  HM_PAR_FOR(o, n * n) { // o = j*n + k with k fastest: lanes of one row share the source row (LDS broadcast)
+    const int j = o >> l2, k = o & (n - 1);
+    int32_t acc = 0;
+    for (int i = 0; i < n; i++) acc += tm(e, n, useDst, k, i) * A[j * HM_TSTRIDE + i];
+    B[k * HM_TSTRIDE + j] = (acc + a1) >> s1;
+  }
+  HM_SYNC();
+  HM_PAR_FOR(o, n * n) {
+    const int j = o >> l2, k = o & (n - 1);
+    int32_t acc = 0;
+    for (int i = 0; i < n; i++) acc += tm(e, n, useDst, k, i) * B[j * HM_TSTRIDE + i];
+    A[k * HM_TSTRIDE + j] = (acc + a2) >> s2;
+  }
+  HM_SYNC();
+}
+// inverse: coefficients in bufA -> residual in bufA; xITrMxN, TComTrQuant.cpp:894-935
+HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth)
+{
+  const int l2 = hm_log2(n), s1 = 7, s2 = 20 - bitDepth;
+  int32_t *A = e->bufA, *B = e->bufB;
+  HM_PAR_FOR(o, n * n) {
+    const int j = o >> l2, i = o & (n - 1);
+    int32_t acc = 0;
+    for (int k = 0; k < n; k++) acc += tm(e, n, useDst, k, i) * A[k * HM_TSTRIDE + j];
+    B[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (acc + (1 << (s1 - 1))) >> s1);
+  }
+  HM_SYNC();
+  HM_PAR_FOR(o, n * n) {
+    const int j = o >> l2, i = o & (n - 1);
+    int32_t acc = 0;
+    for (int k = 0; k < n; k++) acc += tm(e, n, useDst, k, i) * B[k * HM_TSTRIDE + j];
+    A[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (acc + (1 << (s2 - 1))) >> s2);
+  }
+  HM_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------
+// TU descriptor: the subset of TComTU (TComTU.h/.cpp) that 4:2:0 intra coding needs
+// ------------------------------------------------------------------------------------------------
+struct TU {
+  int16_t cuZ, cuDepth, cuParts, relZ, trDepth, log2, parts, section, x, y;
+  int16_t cW, cCodeAll, cTrDepth, cRelZ, cParts, cOff, cx, cy;
+};
+HM_DEV inline TU tu_root(const Shared *e, int cuZ, int cuDepth)
+{ // TComTU::TComTU(pcCU, absPartIdxCU, cuDepth, 0), TComTU.cpp:48
+  TU t;
+  t.cuZ = (int16_t)cuZ; t.cuDepth = (int16_t)cuDepth; t.cuParts = (int16_t)(256 >> (2 * cuDepth));
+  t.relZ = 0; t.trDepth = 0; t.log2 = (int16_t)(6 - cuDepth); t.parts = t.cuParts; t.section = 0;
+  const int r = e->tab->z2r[cuZ];
+  t.x = (int16_t)((r & 15) * 4); t.y = (int16_t)((r >> 4) * 4);
+  t.cW = (int16_t)(1 << (t.log2 - 1)); t.cCodeAll = 1; t.cTrDepth = 0; t.cRelZ = 0; t.cParts = t.parts; t.cOff = (int16_t)(cuZ * 4);
+  t.cx = t.x >> 1; t.cy = t.y >> 1;
+  return t;
+}
+HM_DEV inline TU tu_child(const TU *p, int section, int processLast)
+{ // TComTU::TComTU(parent, bProcessLastOfLevel, QUAD_SPLIT) + nextSection, TComTU.cpp:88-185
+  TU t = *p;
+  t.log2 = p->log2 - 1; t.trDepth = p->trDepth + 1; t.parts = p->parts >> 2; if (t.parts < 1) t.parts = 1;
+  t.relZ = (int16_t)(p->relZ + section * t.parts); t.section = (int16_t)section;
+  t.x = (int16_t)(p->x + (section & 1) * (1 << t.log2)); t.y = (int16_t)(p->y + (section >> 1) * (1 << t.log2));
+  if (t.log2 >= 3) {
+    t.cW = (int16_t)(1 << (t.log2 - 1)); t.cCodeAll = 1; t.cTrDepth = t.trDepth; t.cRelZ = t.relZ; t.cParts = t.parts;
+    t.cOff = (int16_t)((t.cuZ + t.relZ) * 4); t.cx = t.x >> 1; t.cy = t.y >> 1;
+  } else { // 4x4 luma: the 4x4 chroma block of the parent is carried by one quadrant
+    t.cCodeAll = 0; t.cTrDepth = p->cTrDepth; t.cRelZ = t.relZ & ~3; t.cParts = (int16_t)(t.parts * 4);
+    t.cOff = p->cOff; t.cx = p->cx; t.cy = p->cy;
+    t.cW = (section == (processLast ? 3 : 0)) ? 4 : 0;
+  }
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// neighbour helpers
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline const CtuMeta *meta_at(const Shared *e, int x4, int y4, int *z)
+{ *z = e->tab->r2z[((y4 & 15) << 4) | (x4 & 15)]; return e->fb.meta + ((y4 >> 4) * e->P->wCtu + (x4 >> 4)); }
+
+// TComDataCU::getIntraDirPredictor, TComDataCU.cpp:1513-1586 (luma)
+HM_DEV inline int intra_dir_predictor(const Shared *e, int z, int preds[3])
+{
+  const int r = e->tab->z2r[z];
+  const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4);
+  int left = DC_IDX, above = DC_IDX, zz;
+  if (x4 > 0) { const CtuMeta *m = meta_at(e, x4 - 1, y4, &zz); left = (m->pred[zz] == MODE_INTRA) ? m->dirL[zz] : DC_IDX; }
+  if ((y4 & 15) != 0) { const CtuMeta *m = meta_at(e, x4, y4 - 1, &zz); above = (m->pred[zz] == MODE_INTRA) ? m->dirL[zz] : DC_IDX; }
+  if (left == above) {
+    if (left > 1) { preds[0] = left; preds[1] = ((left + 29) % 32) + 2; preds[2] = ((left - 1) % 32) + 2; }
+    else { preds[0] = PLANAR_IDX; preds[1] = DC_IDX; preds[2] = VER_IDX; }
+    return 1;
+  }
+  preds[0] = left; preds[1] = above;
+  if (left && above) preds[2] = PLANAR_IDX; else preds[2] = (left + above) < 2 ? VER_IDX : DC_IDX;
+  return 2;
+}
+// TComDataCU::getCtxSplitFlag, TComDataCU.cpp:1587-1601
+HM_DEV inline int ctx_split_flag(const Shared *e, int z, int depth)
+{
+  const int r = e->tab->z2r[z];
+  const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4);
+  int ctx = 0, zz;
+  if (x4 > 0) { const CtuMeta *m = meta_at(e, x4 - 1, y4, &zz); ctx += m->depth[zz] > depth; }
+  if (y4 > 0) { const CtuMeta *m = meta_at(e, x4, y4 - 1, &zz); ctx += m->depth[zz] > depth; }
+  return ctx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// intra reference samples (TComPattern.cpp:107-500)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline int avail_above_right(const Shared *e, int rtx4, int rty4, int k)
+{ // TComDataCU::getPUAboveRightAdi, TComDataCU.cpp:1302-1360
+  if ((rtx4 + k) * 4 >= e->P->width) return 0;
+  const int cx = rtx4 & 15, cy = rty4 & 15;
+  if (cx + k <= 15) {
+    if (cy != 0) return e->tab->r2z[(cy << 4) | cx] > e->tab->r2z[((cy - 1) << 4) | (cx + k)];
+    return rty4 > 0;
+  }
+  if (cy != 0) return 0;
+  return rty4 > 0 && (rtx4 >> 4) < e->P->wCtu - 1;
+}
+HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
+{ // TComDataCU::getPUBelowLeftAdi, TComDataCU.cpp:1244-1300
+  if ((lby4 + k) * 4 >= e->P->height) return 0;
+  const int cx = lbx4 & 15, cy = lby4 & 15;
+  if (cy + k <= 15) {
+    if (cx != 0) return e->tab->r2z[(cy << 4) | cx] > e->tab->r2z[((cy + k) << 4) | (cx - 1)];
+    return lbx4 > 0;
+  }
+  return 0;
+}
+
+// TComPrediction::initAdiPatternChType + fillReferenceSamples + smoothing (TComPattern.cpp:107-500).
+// (px,py): block position in the component plane; n: block size; (x4,y4): top-left luma 4x4 unit;
+// units: block size in 4x4-luma units.  Result in e->refTop/refLeft[0] (and [1] when filter != 0).
+HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, int n, int x4, int y4, int units, int filter)
+{
+  const int uw = comp ? 2 : 4, total = 4 * units + 1, L = 2 * units, n2 = 2 * n;
+  const int bitDepth = e->P->bitDepth;
+  uint8_t *flags = e->flags;
+  // availability flag of every unit: one lane per unit, then a wave reduction for the count
+  int cnt = 0;
+  HM_PAR_FOR(u, total) {
+    int a;
+    if (u == L) a = (x4 > 0 && y4 > 0);
+    else if (u > L && u <= L + units) a = (y4 > 0);
+    else if (u > L + units) a = avail_above_right(e, x4 + units - 1, y4, u - L - units);
+    else if (u >= L - units) a = (x4 > 0);
+    else a = avail_below_left(e, x4, y4 + units - 1, L - units - u);
+    flags[u] = (uint8_t)a; cnt += a;
+  }
+  const int num = hm_wave_sum_i(cnt);
+  HM_SYNC();
+  const Pel *rec = e->fb.rec[comp]; const int st = e->P->stride[comp];
+  const int dc = 1 << (bitDepth - 1);
+  Pel *top = e->refTop[0], *left = e->refLeft[0];
+  if (num == 0) {
+    HM_PAR_FOR(i, n2 + 1) { top[i] = (Pel)dc; left[i] = (Pel)dc; }
+  } else if (num == total) {
+    HM_PAR_FOR(i, n2 + 1) { top[i] = rec[(py - 1) * st + px - 1 + i]; left[i] = rec[(py - 1 + i) * st + px - 1]; }
+  } else {
+    // line[]: 2n left samples bottom-to-top, uw copies of the corner, 2n above samples
+    Pel *line = e->line; const int nl = n2 + uw + n2;
+    HM_PAR_FOR(i, nl) {
+      int v = dc;
+      if (i < n2) { const int j = (n2 - 1 - i); if (flags[L - 1 - j / uw]) v = rec[(py + j) * st + px - 1]; }
+      else if (i < n2 + uw) { if (flags[L]) v = rec[(py - 1) * st + px - 1]; }
+      else { const int j = i - n2 - uw; if (flags[L + 1 + j / uw]) v = rec[(py - 1) * st + px + j]; }
+      line[i] = (Pel)v;
+    }
+    HM_SYNC();
+    // substitution process (TComPattern.cpp:432-484): serial over at most 65 units, uniform
+    int cur = 0;
+    if (!flags[0]) {
+      int next = 1; while (next < total && !flags[next]) next++;
+      const Pel ref = line[next * uw];
+      for (; cur < next; cur++) for (int i = 0; i < uw; i++) line[cur * uw + i] = ref;
+    }
+    for (; cur < total; cur++)
+      if (!flags[cur]) { const Pel ref = line[cur * uw - 1]; for (int i = 0; i < uw; i++) line[cur * uw + i] = ref; }
+    HM_SYNC();
+    HM_PAR_FOR(i, n2 + 1) { top[i] = line[n2 + uw - 1 + i]; left[i] = (i == 0) ? line[n2 + uw - 1] : line[n2 - i]; }
+  }
+  HM_SYNC();
+  if (!filter) return;
+  // smoothing, TComPattern.cpp:180-283
+  Pel *ft = e->refTop[1], *fl = e->refLeft[1];
+  int strong = (comp == 0);
+  const int bl = left[n2], tl = top[0], tr = top[n2];
+  if (strong) {
+    const int thr = 1 << (bitDepth - 5);
+    const int bilLeft = hm_abs((bl + tl) - 2 * left[n]) < thr, bilAbove = hm_abs((tl + tr) - 2 * top[n]) < thr;
+    if (n < 32 || !bilLeft || !bilAbove) strong = 0;
+  }
+  if (strong) {
+    const int shift = hm_log2(n) + 1;
+    HM_PAR_FOR(i, n2 + 1) {
+      if (i == 0) { ft[0] = (Pel)tl; fl[0] = (Pel)tl; }
+      else if (i == n2) { ft[n2] = (Pel)tr; fl[n2] = (Pel)bl; }
+      else { fl[i] = (Pel)((i * bl + (n2 - i) * tl + n) >> shift); ft[i] = (Pel)(((n2 - i) * tl + i * tr + n) >> shift); }
+    }
+  } else {
+    HM_PAR_FOR(i, n2 + 1) {
+      if (i == 0) { const Pel c = (Pel)((left[1] + 2 * top[0] + top[1] + 2) >> 2); ft[0] = c; fl[0] = c; }
+      else if (i == n2) { ft[n2] = top[n2]; fl[n2] = left[n2]; }
+      else { fl[i] = (Pel)((left[i + 1] + 2 * left[i] + left[i - 1] + 2) >> 2); ft[i] = (Pel)((top[i - 1] + 2 * top[i] + top[i + 1] + 2) >> 2); }
+    }
+  }
+  HM_SYNC();
+}
+
+// TComPrediction::filteringIntraReferenceSamples, TComPattern.cpp:514-540
+HM_DEV inline int use_filtered_refs(int comp, int mode, int n)
+{
+  if (comp != 0 || mode == DC_IDX) return 0;
+  const int d1 = hm_abs(mode - HOR_IDX), d2 = hm_abs(mode - VER_IDX);
+  return (d1 < d2 ? d1 : d2) > HM_INTRA_FILTER[hm_log2(n) - 2];
+}
+
+// TComPrediction::predIntraAng (+xPredIntraPlanar/xPredIntraAng/xDCPredFiltering), TComPrediction.cpp:182-840.
+// One lane per sample.
+HM_DEV HM_NOINLINE void pred_intra(Shared *e, int comp, int mode, int n, int filtered, Pel *dst, int ds)
+{
+  const Pel *top = e->refTop[filtered], *left = e->refLeft[filtered];
+  const int bitDepth = e->P->bitDepth, l2 = hm_log2(n);
+  if (mode == PLANAR_IDX) {
+    const int bottomLeft = left[n + 1], topRight = top[n + 1];
+    HM_PAR_FOR(i, n * n) {
+      const int y = i >> l2, x = i & (n - 1);
+      // closed form of the running sums of xPredIntraPlanar (integer arithmetic, identical values)
+      const int hor = (left[y + 1] << l2) + n + (x + 1) * (topRight - left[y + 1]);
+      const int ver = (top[x + 1] << l2) + (y + 1) * (bottomLeft - top[x + 1]);
+      dst[y * ds + x] = (Pel)((hor + ver) >> (l2 + 1));
+    }
+    HM_SYNC();
+    return;
+  }
+  if (mode == DC_IDX) {
+    int s = 0;
+    HM_PAR_FOR(i, n) s += top[i + 1] + left[i + 1];
+    const int dc = (hm_wave_sum_i(s) + n) / (n + n);
+    const int edge = (comp == 0 && n <= 16);
+    HM_PAR_FOR(i, n * n) {
+      const int y = i >> l2, x = i & (n - 1);
+      int v = dc;
+      if (edge) { // xDCPredFiltering
+        if (x == 0 && y == 0) v = (top[1] + left[1] + 2 * dc + 2) >> 2;
+        else if (y == 0) v = (top[x + 1] + 3 * dc + 2) >> 2;
+        else if (x == 0) v = (left[y + 1] + 3 * dc + 2) >> 2;
+      }
+      dst[y * ds + x] = (Pel)v;
+    }
+    HM_SYNC();
+    return;
+  }
+  const int isVer = mode >= 18;
+  const int angMode = isVer ? mode - VER_IDX : -(mode - HOR_IDX);
+  const int absAng = HM_ANG_TABLE[hm_abs(angMode)], invAngle = HM_INV_ANG_TABLE[hm_abs(angMode)];
+  const int angle = angMode < 0 ? -absAng : absAng;
+  Pel *refMain = e->refMain + 64, *refSide = e->refSide + 64;
+  if (angle < 0) {
+    HM_PAR_FOR(i, n + 1) { refMain[i] = isVer ? top[i] : left[i]; refSide[i] = isVer ? left[i] : top[i]; }
+    HM_SYNC();
+    const int lastK = (n * angle) >> 5;                 // extend the main reference to the left
+    HM_PAR_FOR(j, -1 - lastK) { const int k = -1 - j; refMain[k] = refSide[(128 + (j + 1) * invAngle) >> 8]; }
+  } else {
+    HM_PAR_FOR(i, 2 * n + 1) { refMain[i] = isVer ? top[i] : left[i]; refSide[i] = isVer ? left[i] : top[i]; }
+  }
+  HM_SYNC();
+  const int edge = (angle == 0 && comp == 0 && n <= 16);
+  HM_PAR_FOR(i, n * n) {
+    const int y = i >> l2, x = i & (n - 1);   // (x,y) in the prediction's own orientation
+    int v;
+    if (angle == 0) {
+      v = refMain[x + 1];
+      if (edge && x == 0) v = hm_clip3(0, (1 << bitDepth) - 1, v + ((refSide[y + 1] - refSide[0]) >> 1));
+    } else {
+      const int deltaPos = (y + 1) * angle, di = deltaPos >> 5, df = deltaPos & 31;
+      if (df) v = ((32 - df) * refMain[x + di + 1] + df * refMain[x + di + 2] + 16) >> 5;
+      else v = refMain[x + di + 1];
+    }
+    if (isVer) dst[y * ds + x] = (Pel)v; else dst[x * ds + y] = (Pel)v;
+  }
+  HM_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------
+// coefficient coding parameters
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline int coef_scan_idx(const CtuMeta *m, int z, int n, int comp)
+{ // TComDataCU::getCoefScanIdx, TComDataCU.cpp:3340-3380
+  if (n > (comp ? 4 : 8)) return SCAN_DIAG;
+  int dir = comp ? m->dirC[z] : m->dirL[z];
+  if (dir == DM_CHROMA_IDX) dir = m->dirL[z & ~3];
+  if (hm_abs(dir - VER_IDX) <= 4) return SCAN_HOR;
+  if (hm_abs(dir - HOR_IDX) <= 4) return SCAN_VER;
+  return SCAN_DIAG;
+}
+HM_DEV inline int first_sig_ctx(int n, int scanType, int chroma)
+{ // getTUEntropyCodingParameters, TComChromaFormat.cpp:75-130
+  if (n == 4) return 0;
+  if (n == 8) return 9 + ((scanType != SCAN_DIAG && !chroma) ? 6 : 0);
+  return chroma ? 12 : 21;
+}
+HM_DEV inline int sig_ctx_inc(int pattern, int firstCtx, int blkPos, int log2n, int chroma)
+{ // TComTrQuant::getSigCtxInc, TComTrQuant.cpp:2548-2640
+  const int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
+  if (posX + posY == 0) return 0;
+  int offset;
+  if (log2n == 2) offset = HM_CTX_IND_MAP_4x4[4 * posY + posX];
+  else {
+    int cnt; const int xs = posX & 3, ys = posY & 3;
+    if (pattern == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
+    else if (pattern == 1) cnt = (ys >= 2) ? 0 : ((ys >= 1) ? 1 : 2);
+    else if (pattern == 2) cnt = (xs >= 2) ? 0 : ((xs >= 1) ? 1 : 2);
+    else cnt = 2;
+    const int notFirst = ((posX >> 2) + (posY >> 2)) > 0;
+    offset = ((notFirst && !chroma) ? 3 : 0) + cnt;
+  }
+  return firstCtx + offset;
+}
+HM_DEV inline int pattern_sig_ctx(const uint8_t *cgFlag, int cgx, int cgy, int wg)
+{ // TComTrQuant::calcPatternSigCtx, TComTrQuant.cpp:2522-2535
+  if (wg <= 1) return 0;
+  int r = 0, l = 0;
+  if (cgx < wg - 1) r = cgFlag[cgy * wg + cgx + 1] != 0;
+  if (cgy < wg - 1) l = cgFlag[(cgy + 1) * wg + cgx] != 0;
+  return r + (l << 1);
+}
+HM_DEV inline int sig_cg_ctx(const uint8_t *cgFlag, int cgx, int cgy, int wg)
+{ // TComTrQuant::getSigCoeffGroupCtxInc, TComTrQuant.cpp:2872-2886
+  int r = 0, l = 0;
+  if (cgx < wg - 1) r = cgFlag[cgy * wg + cgx + 1] != 0;
+  if (cgy < wg - 1) l = cgFlag[(cgy + 1) * wg + cgx] != 0;
+  return (r + l) != 0;
+}
+HM_DEV inline int ctx_set_index(int chroma, int subset, int gt1)
+{ return (chroma ? 4 : 0) + ((!chroma && subset > 0) ? 2 : 0) + (gt1 ? 1 : 0); }   // TComChromaFormat.h:243
+HM_DEV inline void last_ctx_params(int chroma, int n, int *off, int *shift)
+{ // getLastSignificantContextParameters, TComChromaFormat.h:211
+  const int cv = hm_log2(n) - 2;
+  *off = chroma ? 0 : (cv * 3 + ((cv + 1) >> 2));
+  *shift = chroma ? cv : ((cv + 3) >> 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RDOQ (TComTrQuant::xRateDistOptQuant, TComTrQuant.cpp:1974-2511).  Source coefficients in LDS bufA
+// (stride HM_TSTRIDE); levels go to dst (dense n*n, HBM).  The level decision is a serial chain over
+// the scan (running c1/c2/Rice state), evaluated wave-uniformly.
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline int ic_rate(const Cabac *c, uint32_t absLevel, int ctxOne, int ctxAbs, int goRice, int c1Idx, int c2Idx)
+{ // xGetICRate, TComTrQuant.cpp:2725-2800
+  int rate = 32768;
+  const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
+  if (absLevel >= baseLevel) {
+    uint32_t symbol = absLevel - baseLevel, length;
+    if (symbol < (3u << goRice)) { length = symbol >> goRice; rate += (int)((length + 1 + goRice) << 15); }
+    else {
+      length = (uint32_t)goRice; symbol -= (3u << goRice);
+      while (symbol >= (1u << length)) symbol -= (1u << (length++));
+      rate += (int)((3 + length + 1 - goRice + length) << 15);
+    }
+    if (c1Idx < 8) { rate += ebits(c, C_ONE + ctxOne, 1); if (c2Idx < 1) rate += ebits(c, C_ABS + ctxAbs, 1); }
+  } else if (absLevel == 1) rate += ebits(c, C_ONE + ctxOne, 0);
+  else if (absLevel == 2) { rate += ebits(c, C_ONE + ctxOne, 1); rate += ebits(c, C_ABS + ctxAbs, 0); }
+  else rate = 0;
+  return rate;
+}
+
+HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanType, int cbfCtx)
+{
+  const Cabac *cb = &e->cur;
+  WorkSpace *ws = e->ws;
+  const int chroma = comp != 0, log2n = hm_log2(n), bitDepth = e->P->bitDepth;
+  const double lambda = chroma ? e->fb.lambdaC : e->fb.lambda;
+  const int transformShift = 15 - bitDepth - log2n;
+  const int qBits = 14 + e->fb.qpPer[chroma] + transformShift;
+  const int quantCoef = HM_QUANT_SCALES[e->fb.qpRem[chroma]];
+  const double errScale = e->fb.errScale[chroma][log2n - 2];
+  const int numCoef = n * n, wg = n >> 2, cgNum = numCoef >> 4;
+  const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
+  const int firstCtx = first_sig_ctx(n, scanType, chroma);
+  const int sigOff = C_SIG + (chroma ? 28 : 0);
+  const int32_t *src = e->bufA;
+  double *costCoeff = ws->costCoeff, *costSig = ws->costSig, *costCoeff0 = ws->costCoeff0;
+  int32_t *rateIncUp = ws->rateIncUp, *rateIncDown = ws->rateIncDown, *sigRateDelta = ws->sigRateDelta, *deltaU = ws->deltaU;
+  double costCGSig[64]; uint8_t cgFlag[64];
+  HM_PAR_FOR(i, numCoef) { costCoeff[i] = 0; costSig[i] = 0; rateIncUp[i] = 0; rateIncDown[i] = 0; sigRateDelta[i] = 0; deltaU[i] = 0; }
+  HM_SYNC();
+  for (int i = 0; i < 64; i++) { costCGSig[i] = 0; cgFlag[i] = 0; }
+  double blockUncodedCost = 0, baseCost = 0;
+  int cgLastScanPos = -1, lastScanPos = -1, ctxSet = 0, c1 = 1, c2 = 0, c1Idx = 0, c2Idx = 0, goRice = 0;
+  for (int cgScanPos = cgNum - 1; cgScanPos >= 0; cgScanPos--) {
+    const int cgBlkPos = scanCG[cgScanPos], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
+    double sigCost = 0, sigCost0 = 0, codedLevelAndDist = 0, uncodedDist = 0; int nnzBeforePos0 = 0;
+    const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
+    for (int posInCG = 15; posInCG >= 0; posInCG--) {
+      const int scanPos = cgScanPos * 16 + posInCG, blkPos = scan[scanPos];
+      const int32_t sc = src[(blkPos >> log2n) * HM_TSTRIDE + (blkPos & (n - 1))];
+      const int64_t tmpLevel = (int64_t)hm_abs(sc) * quantCoef;
+      const int64_t cap = 2147483647LL - (1LL << (qBits - 1));
+      const int32_t levelDouble = (int32_t)(tmpLevel < cap ? tmpLevel : cap);
+      uint32_t maxAbsLevel = (uint32_t)((levelDouble + (1 << (qBits - 1))) >> qBits);
+      if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
+      const double err = (double)levelDouble;
+      const double c0 = err * err * errScale;
+      costCoeff0[scanPos] = c0;
+      blockUncodedCost += c0;
+      uint32_t level = maxAbsLevel;
+      double cCoeff = 0, cSig = 0;
+      if (maxAbsLevel > 0 && lastScanPos < 0) { lastScanPos = scanPos; ctxSet = ctx_set_index(chroma, scanPos >> 4, 0); cgLastScanPos = cgScanPos; }
+      if (lastScanPos >= 0) {
+        const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
+        int ctxSig = 0; const int isLast = (scanPos == lastScanPos);
+        level = 0;
+        if (!isLast) ctxSig = sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
+        { // xGetCodedLevel, TComTrQuant.cpp:2660-2715
+          double currCostSig = 0; int done = 0;
+          if (!isLast && maxAbsLevel < 3) {
+            cSig = lambda * (double)ebits(cb, ctxSig, 0);
+            cCoeff = c0 + cSig;
+            if (maxAbsLevel == 0) done = 1;
+          } else cCoeff = HM_MAX_DOUBLE;
+          if (!done) {
+            if (!isLast) currCostSig = lambda * (double)ebits(cb, ctxSig, 1);
+            const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
+            for (int al = (int)maxAbsLevel; al >= (int)minAbs; al--) {
+              const double de = (double)(levelDouble - (int32_t)((uint32_t)al << qBits));
+              const double dist = de * de * errScale;
+              const double rc = lambda * (double)ic_rate(cb, (uint32_t)al, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
+              double cc = dist + rc;
+              cc += currCostSig;
+              if (cc < cCoeff) { level = (uint32_t)al; cCoeff = cc; cSig = currCostSig; }
+            }
+          }
+        }
+        if (!isLast) sigRateDelta[blkPos] = ebits(cb, ctxSig, 1) - ebits(cb, ctxSig, 0);
+        deltaU[blkPos] = (int32_t)((levelDouble - (int32_t)(level << qBits)) >> (qBits - 8));
+        if (level > 0) {
+          const int rateNow = ic_rate(cb, level, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
+          rateIncUp[blkPos] = ic_rate(cb, level + 1, ctxOne, ctxAbs, goRice, c1Idx, c2Idx) - rateNow;
+          rateIncDown[blkPos] = ic_rate(cb, level - 1, ctxOne, ctxAbs, goRice, c1Idx, c2Idx) - rateNow;
+        } else rateIncUp[blkPos] = ebits(cb, C_ONE + ctxOne, 0);
+        baseCost += cCoeff;
+        const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
+        if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
+        if (level >= 1) c1Idx++;
+        if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
+        else if (c1 < 3 && c1 > 0 && level) c1++;
+        if ((scanPos % 16 == 0) && scanPos > 0) {
+          ctxSet = ctx_set_index(chroma, (scanPos - 1) >> 4, c1 == 0);
+          c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
+        }
+      } else baseCost += c0;
+      costCoeff[scanPos] = cCoeff; costSig[scanPos] = cSig;
+      dst[blkPos] = (TCoeff)level;
+      sigCost += cSig;
+      if (posInCG == 0) sigCost0 = cSig;
+      if (level) {
+        cgFlag[cgBlkPos] = 1;
+        codedLevelAndDist += cCoeff - cSig;
+        uncodedDist += c0;
+        if (posInCG != 0) nnzBeforePos0++;
+      }
+    }
+    if (cgLastScanPos >= 0) {
+      if (cgScanPos) {
+        if (cgFlag[cgBlkPos] == 0) {
+          const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
+          const double r0 = lambda * (double)ebits(cb, ctx, 0);
+          baseCost += r0 - sigCost;
+          costCGSig[cgScanPos] = r0;
+        } else if (cgScanPos < cgLastScanPos) {
+          if (nnzBeforePos0 == 0) { baseCost -= sigCost0; sigCost -= sigCost0; }
+          double costZeroCG = baseCost;
+          const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
+          const double r0 = lambda * (double)ebits(cb, ctx, 0), r1 = lambda * (double)ebits(cb, ctx, 1);
+          baseCost += r1;
+          costZeroCG += r0;
+          costCGSig[cgScanPos] = r1;
+          costZeroCG += uncodedDist; costZeroCG -= codedLevelAndDist; costZeroCG -= sigCost;
+          if (costZeroCG < baseCost) {
+            cgFlag[cgBlkPos] = 0; baseCost = costZeroCG;
+            costCGSig[cgScanPos] = r0;
+            for (int posInCG = 15; posInCG >= 0; posInCG--) {
+              const int scanPos = cgScanPos * 16 + posInCG, blkPos = scan[scanPos];
+              if (dst[blkPos]) { dst[blkPos] = 0; costCoeff[scanPos] = costCoeff0[scanPos]; costSig[scanPos] = 0; }
+            }
+          }
+        }
+      } else cgFlag[cgBlkPos] = 1;
+    }
+  }
+  HM_SYNC();
+  if (lastScanPos < 0) return 0;
+  double bestCost = blockUncodedCost + lambda * (double)ebits(cb, C_QT_CBF + cbfCtx, 0);   // TComTrQuant.cpp:2310-2316
+  baseCost += lambda * (double)ebits(cb, C_QT_CBF + cbfCtx, 1);
+  int bestLastIdxP1 = 0, foundLast = 0;
+  int lastOff, lastShift; last_ctx_params(chroma, n, &lastOff, &lastShift);
+  const int cLX = C_LASTX + (chroma ? 15 : 0) + lastOff, cLY = C_LASTY + (chroma ? 15 : 0) + lastOff;
+  for (int cgScanPos = cgLastScanPos; cgScanPos >= 0 && !foundLast; cgScanPos--) {
+    const int cgBlkPos = scanCG[cgScanPos];
+    baseCost -= costCGSig[cgScanPos];
+    if (!cgFlag[cgBlkPos]) continue;
+    for (int posInCG = 15; posInCG >= 0; posInCG--) {
+      const int scanPos = cgScanPos * 16 + posInCG;
+      if (scanPos > lastScanPos) continue;
+      const int blkPos = scan[scanPos];
+      if (dst[blkPos]) {
+        int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
+        if (scanType == SCAN_VER) { const int t = posX; posX = posY; posY = t; }
+        // xGetRateLast, TComTrQuant.cpp:2815-2832 over estLastSignificantPositionBit, TEncSbac.cpp:1846-1892
+        const int gx = HM_GROUP_IDX[posX], gy = HM_GROUP_IDX[posY], gmax = HM_GROUP_IDX[n - 1];
+        int bx = 0, by = 0;
+        for (int c = 0; c < gx; c++) bx += ebits(cb, cLX + (c >> lastShift), 1);
+        if (gx < gmax) bx += ebits(cb, cLX + (gx >> lastShift), 0);
+        for (int c = 0; c < gy; c++) by += ebits(cb, cLY + (c >> lastShift), 1);
+        if (gy < gmax) by += ebits(cb, cLY + (gy >> lastShift), 0);
+        double cst = (double)(bx + by);
+        if (gx > 3) cst += 32768.0 * (double)((gx - 2) >> 1);
+        if (gy > 3) cst += 32768.0 * (double)((gy - 2) >> 1);
+        const double costLast = lambda * cst;
+        const double t1 = baseCost + costLast;
+        const double totalCost = t1 - costSig[scanPos];
+        if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
+        if (dst[blkPos] > 1) { foundLast = 1; break; }
+        baseCost -= costCoeff[scanPos]; baseCost += costCoeff0[scanPos];
+      } else baseCost -= costSig[scanPos];
+    }
+  }
+  int absSum = 0;
+  for (int sp = 0; sp < bestLastIdxP1; sp++) {
+    const int bp = scan[sp]; const TCoeff lv = dst[bp]; absSum += lv;
+    const int32_t sc = src[(bp >> log2n) * HM_TSTRIDE + (bp & (n - 1))];
+    dst[bp] = sc < 0 ? -lv : lv;
+  }
+  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dst[scan[sp]] = 0;
+  // sign bit hiding, TComTrQuant.cpp:2380-2510
+  if (absSum >= 2) {
+    const int64_t rdFactor = e->fb.rdFactor[chroma];
+    int lastCG = -1;
+    for (int subSet = (numCoef - 1) >> 4; subSet >= 0; subSet--) {
+      const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, k;
+      for (k = 15; k >= 0; --k) if (dst[scan[k + subPos]]) { lastNZ = k; break; }
+      for (k = 0; k < 16; k++) if (dst[scan[k + subPos]]) { firstNZ = k; break; }
+      for (k = firstNZ; k <= lastNZ; k++) sum += dst[scan[k + subPos]];
+      if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
+      if (lastNZ - firstNZ >= 4) {
+        const uint32_t signbit = dst[scan[subPos + firstNZ]] > 0 ? 0 : 1;
+        if (signbit != (uint32_t)(sum & 1)) {
+          const int64_t I64MAX = 0x7fffffffffffffffLL;
+          int64_t minCostInc = I64MAX, curCost = I64MAX; int minPos = -1, finalChange = 0, curChange = 0;
+          for (k = (lastCG == 1 ? lastNZ : 15); k >= 0; --k) {
+            const int bp = scan[k + subPos];
+            const TCoeff dv = dst[bp];
+            if (dv != 0) {
+              const int64_t costUp = rdFactor * (-deltaU[bp]) + rateIncUp[bp];
+              int64_t costDown = rdFactor * (deltaU[bp]) + rateIncDown[bp] - ((hm_abs(dv) == 1) ? sigRateDelta[bp] : 0);
+              if (lastCG == 1 && lastNZ == k && hm_abs(dv) == 1) costDown -= (4 << 15);
+              if (costUp < costDown) { curCost = costUp; curChange = 1; }
+              else { curChange = -1; if (k == firstNZ && hm_abs(dv) == 1) curCost = I64MAX; else curCost = costDown; }
+            } else {
+              curCost = rdFactor * (-(hm_abs(deltaU[bp]))) + (1 << 15) + rateIncUp[bp] + sigRateDelta[bp];
+              curChange = 1;
+              if (k < firstNZ) {
+                const int32_t sc = src[(bp >> log2n) * HM_TSTRIDE + (bp & (n - 1))];
+                const uint32_t thissign = sc >= 0 ? 0 : 1; if (thissign != signbit) curCost = I64MAX;
+              }
+            }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = bp; }
+          }
+          if (dst[minPos] == 32767 || dst[minPos] == -32768) finalChange = -1;
+          const int32_t sc = src[(minPos >> log2n) * HM_TSTRIDE + (minPos & (n - 1))];
+          if (sc >= 0) dst[minPos] += finalChange; else dst[minPos] -= finalChange;
+        }
+      }
+      if (lastCG == 1) lastCG = 0;
+    }
+  }
+  HM_SYNC();
+  return absSum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// syntax element coding on the estimator (TEncSbac.cpp)
+// ------------------------------------------------------------------------------------------------
+// TEncSbac::codeCoeffNxN, TEncSbac.cpp:1172-1525 (+codeLastSignificantXY :1106, xWriteCoefRemainExGolomb :337)
+HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
+{
+  const int chroma = comp != 0, log2n = hm_log2(n), wg = n >> 2;
+  if (n == 4) enc_bin(c, C_TSKIP + chroma, tskipFlag);           // codeTransformSkipFlags, TEncSbac.cpp:988
+  const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
+  int cnt = 0;
+  HM_PAR_FOR(i, n * n) cnt += coef[i] != 0;
+  int numSig = hm_wave_sum_i(cnt);
+  uint8_t cgFlag[64];
+  for (int i = 0; i < 64; i++) cgFlag[i] = 0;
+  int scanPosLast = -1, posLast;
+  do {
+    posLast = scan[++scanPosLast];
+    if (coef[posLast] != 0) { const int py = posLast >> log2n, px = posLast - (py << log2n); cgFlag[wg * (py >> 2) + (px >> 2)] = 1; numSig--; }
+  } while (numSig > 0);
+  {
+    int py = posLast >> log2n, px = posLast - (py << log2n);
+    if (scanType == SCAN_VER) { const int t = px; px = py; py = t; }
+    const int gx = HM_GROUP_IDX[px], gy = HM_GROUP_IDX[py], gmax = HM_GROUP_IDX[n - 1];
+    int off, shift; last_ctx_params(chroma, n, &off, &shift);
+    const int bxc = C_LASTX + (chroma ? 15 : 0) + off, byc = C_LASTY + (chroma ? 15 : 0) + off;
+    int k;
+    for (k = 0; k < gx; k++) enc_bin(c, bxc + (k >> shift), 1);
+    if (gx < gmax) enc_bin(c, bxc + (k >> shift), 0);
+    for (k = 0; k < gy; k++) enc_bin(c, byc + (k >> shift), 1);
+    if (gy < gmax) enc_bin(c, byc + (k >> shift), 0);
+    if (gx > 3) enc_ep(c, (gx - 2) >> 1);
+    if (gy > 3) enc_ep(c, (gy - 2) >> 1);
+  }
+  const int firstCtx = first_sig_ctx(n, scanType, chroma), sigOff = C_SIG + (chroma ? 28 : 0);
+  const int lastScanSet = scanPosLast >> 4;
+  uint32_t c1 = 1; int scanPosSig = scanPosLast;
+  for (int subSet = lastScanSet; subSet >= 0; subSet--) {
+    int numNonZero = 0; const int subPos = subSet << 4; uint32_t goRice = 0;
+    int absCoeff[16]; int lastNZ = -1, firstNZ = 16; int escape = 0;
+    if (scanPosSig == scanPosLast) { absCoeff[0] = hm_abs(coef[posLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
+    const int cgBlkPos = scanCG[subSet], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
+    if (subSet == lastScanSet || subSet == 0) cgFlag[cgBlkPos] = 1;
+    else enc_bin(c, C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg), cgFlag[cgBlkPos] != 0);
+    if (cgFlag[cgBlkPos]) {
+      const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
+      for (; scanPosSig >= subPos; scanPosSig--) {
+        const int blkPos = scan[scanPosSig]; const TCoeff cv = coef[blkPos]; const int sig = cv != 0;
+        if (scanPosSig > subPos || subSet == 0 || numNonZero)
+          enc_bin(c, sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma), sig);
+        if (sig) { absCoeff[numNonZero] = hm_abs(cv); numNonZero++; if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
+      }
+    } else scanPosSig = subPos - 1;
+    if (numNonZero > 0) {
+      const int signHidden = (lastNZ - firstNZ >= 4);
+      const int ctxSet = ctx_set_index(chroma, subSet, c1 == 0);
+      c1 = 1;
+      const int numC1 = numNonZero < 8 ? numNonZero : 8; int firstC2 = -1;
+      for (int idx = 0; idx < numC1; idx++) {
+        const int sym = absCoeff[idx] > 1;
+        enc_bin(c, C_ONE + 4 * ctxSet + (int)c1, sym);
+        if (sym) { c1 = 0; if (firstC2 == -1) firstC2 = idx; else escape = 1; }
+        else if (c1 < 3 && c1 > 0) c1++;
+      }
+      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; enc_bin(c, C_ABS + ctxSet, sym); if (sym) escape = 1; }
+      escape = escape || (numNonZero > 8);
+      enc_ep(c, signHidden ? numNonZero - 1 : numNonZero);
+      int firstCoeff2 = 1;
+      if (escape)
+        for (int idx = 0; idx < numNonZero; idx++) {
+          const int baseLevel = (idx < 8) ? (2 + firstCoeff2) : 1;
+          if (absCoeff[idx] >= baseLevel) {
+            uint32_t sym = (uint32_t)(absCoeff[idx] - baseLevel);
+            if (sym < (3u << goRice)) enc_ep(c, (int)((sym >> goRice) + 1 + goRice));
+            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++)); enc_ep(c, (int)(3 + len + 1 - goRice + len)); }
+            if ((uint32_t)absCoeff[idx] > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
+          }
+          if (absCoeff[idx] >= 2) firstCoeff2 = 0;
+        }
+    }
+  }
+}
+
+// TEncSbac::codeIntraDirLumaAng, TEncSbac.cpp:636-690
+HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
+{
+  const CtuMeta *m = e->cm;
+  const int partNum = multiple ? (m->part[z] == SIZE_NxN ? 4 : 1) : 1;
+  const int partOffset = (256 >> (m->depth[z] << 1)) >> 2;
+  int predIdx[4] = {-1, -1, -1, -1};
+  for (int j = 0; j < partNum; j++) {
+    int preds[3];
+    const int dir = m->dirL[z + partOffset * j];
+    intra_dir_predictor(e, z + partOffset * j, preds);
+    for (int i = 0; i < 3; i++) if (dir == preds[i]) predIdx[j] = i;
+    enc_bin(c, C_INTRA_LUMA, predIdx[j] != -1);
+  }
+  for (int j = 0; j < partNum; j++) {
+    if (predIdx[j] != -1) enc_ep(c, predIdx[j] ? 2 : 1);
+    else enc_ep(c, 5);
+  }
+}
+// TEncSbac::codeIntraDirChroma, TEncSbac.cpp:692-718
+HM_DEV inline void code_intra_dir_chroma(Shared *e, Cabac *c, int z)
+{
+  if (e->cm->dirC[z] == DM_CHROMA_IDX) enc_bin(c, C_CHROMA_PRED, 0);
+  else { enc_bin(c, C_CHROMA_PRED, 1); enc_ep(c, 2); }
+}
+// TEncSbac::codeQtCbf, TEncSbac.cpp:911-960 (square TUs)
+HM_DEV inline void code_qt_cbf(Shared *e, Cabac *c, const TU *t, int comp, int lowestLevel)
+{
+  const int z = t->cuZ + (comp ? t->cRelZ : t->relZ);
+  const int ctx = comp ? t->trDepth : (t->trDepth == 0 ? 1 : 0);
+  const int width = comp ? (1 << (t->log2 - 1)) : (1 << t->log2);
+  const int canQuadSplit = width >= 8;
+  const int lowestTUDepth = t->trDepth + ((!lowestLevel && !canQuadSplit) ? 1 : 0);
+  enc_bin(c, C_QT_CBF + (comp ? 5 : 0) + ctx, (e->cm->cbf[comp][z] >> lowestTUDepth) & 1);
+}
+
+HM_DEV inline int tr_min_size_in_cu(int cuLog2, int nxn)
+{ // TComDataCU::getQuadtreeTULog2MinSizeInCU, TComDataCU.cpp:1618-1643 (max depth intra 3, TU log2 2..5)
+  if (cuLog2 < 2 + 3 - 1 + nxn) return 2;
+  const int v = cuLog2 - (3 - 1 + nxn);
+  return v > 5 ? 5 : v;
+}
+// whether a transform_split flag is coded at this node (TEncSearch.cpp:869-888 / TEncEntropy.cpp:258-291)
+HM_DEV inline int codes_subdiv_flag(const CtuMeta *m, const TU *t)
+{
+  const int nxn = m->part[t->cuZ] == SIZE_NxN;
+  if (nxn && t->trDepth == 0) return 0;
+  if (t->log2 > 5) return 0;
+  if (t->log2 == 2) return 0;
+  if (t->log2 == tr_min_size_in_cu(6 - t->cuDepth, nxn)) return 0;
+  return 1;
+}
+
+// Pre-order walk of the residual quadtree with an explicit stack (no device recursion).
+// The callbacks of the reference's recursive functions become phases of one loop.
+struct TuWalk { TU node[5]; int8_t next[5]; int sp; };
+HM_DEV inline void walk_begin(TuWalk *w, const TU *root) { w->node[0] = *root; w->next[0] = -1; w->sp = 0; }
+
+// xEncSubdivCbfQT, TEncSearch.cpp:856-921
+HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int bChroma)
+{
+  const CtuMeta *m = e->cm;
+  TuWalk w; walk_begin(&w, root);
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ;
+    const int subdiv = m->tr[z] > t->trDepth;
+    if (w.next[w.sp] < 0) { // first visit
+      if (bLuma && codes_subdiv_flag(m, t)) enc_bin(&e->cur, C_SUBDIV + (5 - t->log2), subdiv);
+      if (bChroma)
+        for (int comp = 1; comp < 3; comp++)
+          if (t->cCodeAll && (t->trDepth == 0 || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)))
+            code_qt_cbf(e, &e->cur, t, comp, subdiv == 0);
+      if (!subdiv) { if (bLuma) code_qt_cbf(e, &e->cur, t, 0, 1); w.sp--; continue; }
+      w.next[w.sp] = 0;
+    }
+    if (w.next[w.sp] == 4) { w.sp--; continue; }
+    const int s = w.next[w.sp]++;
+    w.node[w.sp + 1] = tu_child(t, s, 0); w.next[w.sp + 1] = -1; w.sp++;
+  }
+}
+// xEncCoeffQT, TEncSearch.cpp:926-960 (coefficients from the QT layer buffers)
+HM_DEV inline void enc_coeff_qt(Shared *e, const TU *root, int comp)
+{
+  const CtuMeta *m = e->cm;
+  TuWalk w; walk_begin(&w, root);
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ;
+    if (m->tr[z] > t->trDepth) {
+      if (w.next[w.sp] < 0) w.next[w.sp] = 0;
+      if (w.next[w.sp] == 4) { w.sp--; continue; }
+      const int s = w.next[w.sp]++;
+      w.node[w.sp + 1] = tu_child(t, s, 0); w.next[w.sp + 1] = -1; w.sp++;
+      continue;
+    }
+    if (!(comp && !t->cW) && ((m->cbf[comp][z] >> t->trDepth) & 1)) {   // TEncEntropy::encodeCoeffNxN, TEncEntropy.cpp:683
+      const int layer = 5 - t->log2;
+      const int n = comp ? t->cW : (1 << t->log2);
+      const int zc = t->cuZ + (comp ? t->cRelZ : t->relZ);
+      const TCoeff *coef = e->ws->qtCoef[layer] + HM_PLANE_OFF(comp) + (comp ? t->cOff : z * 16);
+      code_coeff_nxn(e, &e->cur, coef, n, comp, coef_scan_idx(m, zc, n, comp), m->ts[comp][zc]);
+    }
+    w.sp--;
+  }
+}
+// xEncIntraHeader, TEncSearch.cpp:965-1032 (I slice, no PCM)
+HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChroma)
+{
+  const CtuMeta *m = e->cm; const int relZ = t->relZ;
+  if (bLuma) {
+    if (relZ == 0 && t->cuDepth == 3) enc_bin(&e->cur, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
+    if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, &e->cur, t->cuZ, 0); }
+    else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ % q) == 0) code_intra_dir_luma(e, &e->cur, t->cuZ + relZ, 0); }
+  }
+  if (bChroma && relZ == 0) code_intra_dir_chroma(e, &e->cur, t->cuZ + relZ);
+}
+// xGetIntraBitsQT, TEncSearch.cpp:1038-1060
+HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU *t, int bLuma, int bChroma)
+{
+  reset_bits(&e->cur);
+  enc_intra_header(e, t, bLuma, bChroma);
+  enc_subdiv_cbf_qt(e, t, bLuma, bChroma);
+  if (bLuma) enc_coeff_qt(e, t, 0);
+  if (bChroma) { enc_coeff_qt(e, t, 1); enc_coeff_qt(e, t, 2); }
+  return num_bits(&e->cur);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one TU: predict, transform, RDOQ, reconstruct (TEncSearch::xIntraCodingTUBlock :1074-1357)
+// ------------------------------------------------------------------------------------------------
+HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int comp, int save1load2)
+{
+  CtuMeta *m = e->cm; WorkSpace *ws = e->ws;
+  if (comp && !t->cW) return 0;
+  const int n = comp ? t->cW : (1 << t->log2), l2 = hm_log2(n);
+  const int relZ = comp ? t->cRelZ : t->relZ, z = t->cuZ + relZ;
+  const int bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
+  const int st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp);
+  const int layer = 5 - t->log2, parts = comp ? t->cParts : t->parts;
+  const int ps = e->P->stride[comp], bitDepth = e->P->bitDepth;
+  const Pel *org = e->fb.org[comp] + (e->ctuY * st + by) * ps + e->ctuX * st + bx;
+  Pel *recPic = e->fb.rec[comp] + (e->ctuY * st + by) * ps + e->ctuX * st + bx;
+  Pel *pred = ws->pred + po + by * st + bx, *resi = ws->resi + po + by * st + bx;
+  Pel *recQt = ws->qtRec[layer] + po + by * st + bx;
+  TCoeff *coef = ws->qtCoef[layer] + po + (comp ? t->cOff : z * 16);
+  const int tskip = m->ts[comp][z];
+  int mode = comp ? m->dirC[z] : m->dirL[z];
+  if (comp && mode == DM_CHROMA_IDX) mode = m->dirL[z & ~3];
+  if (save1load2 != 2) {
+    const int filt = use_filtered_refs(comp, mode, n);
+    const int r = e->tab->z2r[z];
+    init_adi_pattern(e, comp, e->ctuX * st + bx, e->ctuY * st + by, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), comp ? n / 2 : n / 4, filt);
+    pred_intra(e, comp, mode, n, filt, pred, st);
+    if (save1load2 == 1) { HM_PAR_FOR(i, 16) e->tsPred[comp][i] = pred[(i >> 2) * st + (i & 3)]; HM_SYNC(); }
+  } else { HM_PAR_FOR(i, 16) pred[(i >> 2) * st + (i & 3)] = e->tsPred[comp][i]; HM_SYNC(); }
+  if (comp == 0) par_set8(m->tr + z, t->trDepth, parts);             // setTrIdxSubParts, TEncSearch.cpp:1229
+  // residual straight into the LDS transform buffer (and the scratch plane, as the reference keeps it)
+  const int tshift = 15 - bitDepth - l2;
+  HM_PAR_FOR(i, n * n) {
+    const int y = i >> l2, x = i & (n - 1);
+    const int r = org[y * ps + x] - pred[y * st + x];
+    resi[y * st + x] = (Pel)r;
+    e->bufA[y * HM_TSTRIDE + x] = tskip ? (r << tshift) : r;         // xTransformSkip, TComTrQuant.cpp:1874
+  }
+  HM_SYNC();
+  if (!tskip) fwd_transform(e, n, comp == 0 && n == 4, bitDepth);      // TComTrQuant::xT, :1805
+  const int cbfCtx = comp ? 5 + t->trDepth : (t->trDepth == 0 ? 1 : 0);
+  const int absSum = rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx);
+  par_set8(m->cbf[comp] + z, (absSum > 0 ? 1 : 0) << t->trDepth, parts);   // setCbfPartRange, TComTrQuant.cpp:1419
+  if (absSum > 0) { // invTransformNxN, TComTrQuant.cpp:1423-1545; xDeQuant (flat), :1276-1312
+    const int rightShift = 6 - (tshift + e->fb.qpPer[comp != 0]);
+    const int scale = HM_INV_QUANT_SCALES[e->fb.qpRem[comp != 0]];
+    int tgt = 25 + rightShift; if (tgt > 16) tgt = 16;
+    const int imin = -(1 << (tgt - 1)), imax = (1 << (tgt - 1)) - 1;
+    HM_PAR_FOR(i, n * n) {
+      const int y = i >> l2, x = i & (n - 1);
+      const int c = hm_clip3(imin, imax, coef[i]);
+      int v;
+      if (rightShift > 0) v = (c * scale + (1 << (rightShift - 1))) >> rightShift;
+      else v = (int)((unsigned)(c * scale) << (-rightShift));
+      e->bufA[y * HM_TSTRIDE + x] = hm_clip3(-32768, 32767, v);
+    }
+    HM_SYNC();
+    if (!tskip) inv_transform(e, n, comp == 0 && n == 4, bitDepth);
+    const int off = tshift == 0 ? 0 : (1 << (tshift - 1));
+    HM_PAR_FOR(i, n * n) {
+      const int y = i >> l2, x = i & (n - 1);
+      const int v = e->bufA[y * HM_TSTRIDE + x];
+      resi[y * st + x] = (Pel)(tskip ? ((v + off) >> tshift) : v);      // xITransformSkip, :1920
+    }
+  } else {
+    HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); coef[i] = 0; resi[y * st + x] = 0; }
+  }
+  HM_SYNC();
+  const int maxv = (1 << bitDepth) - 1, shiftSse = (bitDepth - 8) << 1;
+  uint32_t sse = 0;
+  HM_PAR_FOR(i, n * n) { // reconstruction + SSE fused (TEncSearch.cpp:1338-1356)
+    const int y = i >> l2, x = i & (n - 1);
+    const int r = hm_clip3(0, maxv, pred[y * st + x] + resi[y * st + x]);
+    pred[y * st + x] = (Pel)r; recQt[y * st + x] = (Pel)r; recPic[y * ps + x] = (Pel)r;   // piReco aliases piPred
+    const int d = org[y * ps + x] - r; sse += (uint32_t)((d * d) >> shiftSse);
+  }
+  uint32_t d = hm_wave_sum(sse);
+  HM_SYNC();
+  if (comp) d = (uint32_t)(e->fb.chromaWeight * (double)d);            // getDistPart, TComRdCost.cpp:447-450
+  return d;
+}
+
+// xStoreIntraResultQT / xLoadIntraResultQT, TEncSearch.cpp:1790-1880 (4x4 blocks only: transform-skip trials)
+HM_DEV inline void store_intra_result_qt(Shared *e, const TU *t, int comp)
+{
+  const int st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp), layer = 5 - t->log2;
+  const int bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
+  const TCoeff *coef = e->ws->qtCoef[layer] + po + (comp ? t->cOff : (t->cuZ + t->relZ) * 16);
+  const Pel *rq = e->ws->qtRec[layer] + po + by * st + bx;
+  HM_PAR_FOR(i, 16) { e->tsCoef[comp][i] = coef[i]; e->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; }
+  HM_SYNC();
+}
+HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
+{
+  const int st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp), layer = 5 - t->log2, ps = e->P->stride[comp];
+  const int bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
+  TCoeff *coef = e->ws->qtCoef[layer] + po + (comp ? t->cOff : (t->cuZ + t->relZ) * 16);
+  Pel *rq = e->ws->qtRec[layer] + po + by * st + bx;
+  Pel *recPic = e->fb.rec[comp] + (e->ctuY * st + by) * ps + e->ctuX * st + bx;
+  HM_PAR_FOR(i, 16) { coef[i] = e->tsCoef[comp][i]; const Pel v = e->tsRec[comp][i]; rq[(i >> 2) * st + (i & 3)] = v; recPic[(i >> 2) * ps + (i & 3)] = v; }
+  HM_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------
+// luma residual quadtree (TEncSearch::xRecurIntraCodingQT :1364-1733, bLumaOnly), explicit stack
+// ------------------------------------------------------------------------------------------------
+struct RqtFrame {
+  TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf; double singleCost, splitCost;
+};
+// returns distortion through *distY and adds the RD cost to *rdCost, exactly like the recursive reference
+HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU *root, uint32_t *distY, int checkFirst, double *rdCost)
+{
+  CtuMeta *m = e->cm;
+  RqtFrame fr[4]; int sp = 0;
+  uint32_t retDist[5]; double retCost[5];     // accumulators handed to each level by its parent
+  fr[0].t = *root; fr[0].phase = 0; retDist[0] = 0; retCost[0] = 0.0;
+  while (sp >= 0) {
+    RqtFrame *f = &fr[sp]; const TU *t = &f->t;
+    const int z = t->cuZ + t->relZ, fullDepth = t->cuDepth + t->trDepth, log2 = t->log2;
+    if (f->phase == 0) {
+      const int nxn = m->part[t->cuZ] == SIZE_NxN;
+      f->checkFull = log2 <= 5;
+      f->checkSplit = log2 > tr_min_size_in_cu(6 - t->cuDepth, nxn);
+      if (checkFirst && f->checkFull) f->checkSplit = 0;              // HHI_RQT_INTRA_SPEEDUP
+      f->singleCost = HM_MAX_DOUBLE; f->singleDist = 0; f->singleCbf = 0; f->bestModeId = 0;
+      const int checkTS = (log2 == 2) && (m->part[z] == SIZE_NxN);    // TransformSkip + TransformSkipFast
+      if (f->checkFull) {
+        if (checkTS) {
+          cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+          for (int modeId = 0; modeId < 2; modeId++) {
+            double costTmp;
+            par_set8(m->ts[0] + z, modeId, t->parts);
+            const uint32_t distTmp = intra_coding_tu_block(e, t, 0, modeId == 0 ? 1 : 2);
+            const uint32_t cbfTmp = (m->cbf[0][z] >> t->trDepth) & 1;
+            if (modeId == 1 && cbfTmp == 0) costTmp = HM_MAX_DOUBLE;
+            else { const uint32_t bits = intra_bits_qt(e, t, 1, 0); costTmp = calc_rd_cost(e, bits, distTmp); }
+            if (costTmp < f->singleCost) {
+              f->singleCost = costTmp; f->singleDist = distTmp; f->singleCbf = cbfTmp; f->bestModeId = (int8_t)modeId;
+              if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->slot[fullDepth][CI_TEMP_BEST], &e->cur); }
+            }
+            if (modeId == 0) cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]);
+          }
+          par_set8(m->ts[0] + z, f->bestModeId, t->parts);
+          if (f->bestModeId == 0) {
+            load_intra_result_qt(e, t, 0);
+            par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
+            cabac_copy(&e->cur, &e->slot[fullDepth][CI_TEMP_BEST]);
+          }
+        } else {
+          if (f->checkSplit) cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+          par_set8(m->ts[0] + z, 0, t->parts);
+          f->singleDist = intra_coding_tu_block(e, t, 0, 0);
+          if (f->checkSplit) f->singleCbf = (m->cbf[0][z] >> t->trDepth) & 1;
+          const uint32_t bits = intra_bits_qt(e, t, 1, 0);
+          f->singleCost = calc_rd_cost(e, bits, f->singleDist);
+        }
+      }
+      if (!f->checkSplit) { retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue; }
+      if (f->checkFull) { cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_TEST], &e->cur); cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]); }
+      else cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+      f->splitCost = 0.0; f->splitDist = 0; f->splitCbf = 0; f->child = 0; f->phase = 1;
+      retDist[sp + 1] = 0; retCost[sp + 1] = 0.0;
+    }
+    if (f->phase == 1) {
+      if (f->child > 0) { // a child just returned
+        const TU ch = tu_child(t, f->child - 1, 0);
+        f->splitCbf |= (m->cbf[0][ch.cuZ + ch.relZ] >> ch.trDepth) & 1;
+      }
+      if (f->child < 4) {
+        fr[sp + 1].t = tu_child(t, f->child, 0); fr[sp + 1].phase = 0; f->child++;
+        sp++; continue;
+      }
+      f->splitDist = retDist[sp + 1];
+      if (f->splitCbf) { HM_PAR_FOR(o, t->parts) m->cbf[0][z + o] |= (uint8_t)(1 << t->trDepth); HM_SYNC(); }
+      cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]);
+      const uint32_t splitBits = intra_bits_qt(e, t, 1, 0);
+      f->splitCost = calc_rd_cost(e, splitBits, f->splitDist);
+      if (f->splitCost < f->singleCost) { retDist[sp] += f->splitDist; retCost[sp] += f->splitCost; sp--; continue; }
+      cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_TEST]);
+      par_set8(m->tr + z, t->trDepth, t->parts);
+      par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
+      par_set8(m->ts[0] + z, f->bestModeId, t->parts);
+      { // reconstruction of the unsplit TU back into the picture for the following blocks
+        const int n = 1 << log2, layer = 5 - log2, ps = e->P->stride[0];
+        par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + t->y) * ps + e->ctuX * 64 + t->x, ps, e->ws->qtRec[layer] + t->y * 64 + t->x, 64, n);
+      }
+      retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue;
+    }
+  }
+  *distY += retDist[0]; *rdCost += retCost[0];
+}
+
+// leaves of the decided residual quadtree inside [relZ0, relZ0+parts0): visit in z order
+// xSetIntraResultQT, TEncSearch.cpp:1737-1788 (luma)
+HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
+{
+  const CtuMeta *m = e->cm;
+  for (int rel = root->relZ; rel < root->relZ + root->parts;) {
+    const int z = root->cuZ + rel, trd = m->tr[z];
+    const int log2 = 6 - root->cuDepth - trd, n = 1 << log2, layer = 5 - log2;
+    const int parts = root->cuParts >> (2 * trd) > 0 ? root->cuParts >> (2 * trd) : 1;
+    const int r = e->tab->z2r[z], x = (r & 15) * 4, y = (r >> 4) * 4;
+    par_copy32(e->cc + z * 16, e->ws->qtCoef[layer] + z * 16, n * n);
+    par_copy_blk(e->ws->reco + y * 64 + x, 64, e->ws->qtRec[layer] + y * 64 + x, 64, n);
+    rel += parts;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// luma mode decision of one CU (TEncSearch::estIntraPredQT :2289-2692)
+// ------------------------------------------------------------------------------------------------
+HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
+{
+  CtuMeta *m = e->cm; WorkSpace *ws = e->ws;
+  const int cuParts = 256 >> (2 * cuDepth);
+  const int nxn = m->part[cuZ] == SIZE_NxN;
+  const int numPU = nxn ? 4 : 1, puParts = cuParts / numPU;
+  const int puLog2 = 6 - cuDepth - nxn, n = 1 << puLog2;
+  const int bitDepth = e->P->bitDepth, ps = e->P->stride[0];
+  uint32_t overallDistY = 0;
+  const TU root = tu_root(e, cuZ, cuDepth);
+  for (int pu = 0; pu < numPU; pu++) {
+    const TU t = nxn ? tu_child(&root, pu, 0) : root;
+    const int z = cuZ + t.relZ;
+    int numModesForFullRD = HM_INTRA_MODE_NUM_FAST[puLog2 - 1];
+    int rdModeList[12]; double candCost[12];
+    { // SATD pre-selection over the 35 modes, :2360-2410
+      const int r = e->tab->z2r[z];
+      init_adi_pattern(e, 0, e->ctuX * 64 + t.x, e->ctuY * 64 + t.y, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), n / 4, 1);
+      for (int i = 0; i < numModesForFullRD; i++) candCost[i] = HM_MAX_DOUBLE;
+      const Pel *org = e->fb.org[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x;
+      Pel *pred = ws->pred + t.y * 64 + t.x;
+      int preds[3];
+      const int numMpm = intra_dir_predictor(e, z, preds);
+      // xModeBitsIntra (TEncSearch.cpp:5456-5478) depends only on whether the mode is an MPM and which
+      const uint64_t frac0 = e->slot[cuDepth][CI_CURR_BEST].frac & 32767;
+      const uint8_t st0 = e->slot[cuDepth][CI_CURR_BEST].s[C_INTRA_LUMA];
+      for (int mode = 0; mode < 35; mode++) {
+        pred_intra(e, 0, mode, n, use_filtered_refs(0, mode, n), pred, 64);
+        const uint32_t sad = dist_hads(org, ps, pred, 64, n, bitDepth);
+        int predIdx = -1;
+        for (int i = 0; i < 3; i++) if (mode == preds[i]) predIdx = i;
+        uint64_t fb = frac0 + (uint64_t)HM_ENTROPY_BITS[st0 ^ (predIdx != -1)];
+        fb += (uint64_t)32768 * (uint64_t)(predIdx == -1 ? 5 : (predIdx ? 2 : 1));
+        const uint32_t modeBits = (uint32_t)(fb >> 15);
+        const double cost = (double)sad + (double)modeBits * e->fb.sqrtLambda;
+        // xUpdateCandList, TEncSearch.cpp:5484-5505
+        int shift = 0;
+        while (shift < numModesForFullRD && cost < candCost[numModesForFullRD - 1 - shift]) shift++;
+        if (shift != 0) {
+          for (int i = 1; i < shift; i++) { rdModeList[numModesForFullRD - i] = rdModeList[numModesForFullRD - 1 - i]; candCost[numModesForFullRD - i] = candCost[numModesForFullRD - 1 - i]; }
+          rdModeList[numModesForFullRD - shift] = mode; candCost[numModesForFullRD - shift] = cost;
+        }
+      }
+      for (int j = 0; j < numMpm; j++) { // numCand = *piMode quirk, TEncSearch.cpp:2415-2420
+        int included = 0;
+        for (int i = 0; i < numModesForFullRD; i++) included |= (preds[j] == rdModeList[i]);
+        if (!included) rdModeList[numModesForFullRD++] = preds[j];
+      }
+    }
+    int bestPUMode = 0; uint32_t bestPUDistY = 0; double bestPUCost = HM_MAX_DOUBLE;
+    for (int pass = 0; pass <= numModesForFullRD; pass++) {
+      const int last = (pass == numModesForFullRD);
+      const int orgMode = last ? bestPUMode : rdModeList[pass];
+      par_set8(m->dirL + z, orgMode, puParts);
+      cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+      uint32_t puDistY = 0; double puCost = 0.0;
+      recur_intra_coding_qt(e, &t, &puDistY, !last, &puCost);
+      if (puCost < bestPUCost) {
+        bestPUMode = orgMode; bestPUDistY = puDistY; bestPUCost = puCost;
+        set_intra_result_qt(e, &t);
+        HM_PAR_FOR(i, puParts) { ws->tmpTr[i] = m->tr[z + i]; for (int c = 0; c < 3; c++) { ws->tmpCbf[c][i] = m->cbf[c][z + i]; ws->tmpTs[c][i] = m->ts[c][z + i]; } }
+        HM_SYNC();
+      }
+    }
+    overallDistY += bestPUDistY;
+    HM_PAR_FOR(i, puParts) { m->tr[z + i] = ws->tmpTr[i]; for (int c = 0; c < 3; c++) { m->cbf[c][z + i] = ws->tmpCbf[c][i]; m->ts[c][z + i] = ws->tmpTs[c][i]; } m->dirL[z + i] = (uint8_t)bestPUMode; }
+    HM_SYNC();
+    if (pu != numPU - 1) // reconstruction for the next PU, :2632-2660
+      par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x, ps, ws->reco + t.y * 64 + t.x, 64, n);
+  }
+  if (numPU > 1) {
+    uint8_t comb[3] = {0, 0, 0};
+    for (int p = 0; p < 4; p++) for (int c = 0; c < 3; c++) comb[c] |= (m->cbf[c][cuZ + p * puParts] >> 1) & 1;
+    HM_PAR_FOR(o, cuParts) for (int c = 0; c < 3; c++) m->cbf[c][cuZ + o] |= comb[c];
+    HM_SYNC();
+  }
+  cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+  return overallDistY;
+}
+
+// ------------------------------------------------------------------------------------------------
+// chroma (TEncSearch::xRecurIntraChromaCodingQT :1958-2145, estIntraPredChromaQT :2698-2849)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
+{ // the leaf part of xRecurIntraChromaCodingQT
+  CtuMeta *m = e->cm; const int z = t->cuZ + t->relZ;
+  const int fullDepth = t->cuDepth + t->trDepth;
+  int checkTS = (t->cW == 4) && (t->log2 == 2);
+  if (checkTS) { int nb = 0; for (int s = 0; s < 4; s++) nb += m->ts[0][z + s]; checkTS = nb > 0; }
+  const int zc = t->cuZ + t->cRelZ;
+  uint32_t dist = 0;
+  for (int comp = 1; comp < 3; comp++) {
+    cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+    double singleCost = HM_MAX_DOUBLE, costTmp = 0; uint32_t singleDistC = 0, singleCbfC = 0; int bestTS = 0, bestModeId = 0, currModeId = 0;
+    const int total = checkTS ? 2 : 1;
+    for (int tsMode = 0; tsMode < total; tsMode++) {
+      par_set8(m->ts[comp] + zc, tsMode, t->cParts);
+      currModeId++;
+      const int isOne = (total == 1), isLast = (currModeId == total);
+      const uint32_t distTmp = intra_coding_tu_block(e, t, comp, isOne ? 0 : (tsMode == 0 ? 1 : 2));
+      const uint32_t cbfTmp = (m->cbf[comp][zc] >> t->trDepth) & 1;
+      if (tsMode == 1 && cbfTmp == 0) costTmp = HM_MAX_DOUBLE;
+      else if (!isOne) { reset_bits(&e->cur); enc_coeff_qt(e, t, comp); costTmp = calc_rd_cost(e, num_bits(&e->cur), distTmp); }   // xGetIntraBitsQTChroma
+      if (costTmp < singleCost) {
+        singleCost = costTmp; singleDistC = distTmp; bestTS = tsMode; bestModeId = currModeId; singleCbfC = cbfTmp;
+        if (!isOne && !isLast) { store_intra_result_qt(e, t, comp); cabac_copy(&e->slot[fullDepth][CI_TEMP_BEST], &e->cur); }
+      }
+      if (!isOne && !isLast) cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]);
+    }
+    if (bestModeId < total) {
+      load_intra_result_qt(e, t, comp);
+      par_set8(m->cbf[comp] + zc, (int)(singleCbfC << t->trDepth), t->cParts);
+      cabac_copy(&e->cur, &e->slot[fullDepth][CI_TEMP_BEST]);
+    }
+    par_set8(m->ts[comp] + zc, bestTS, t->cParts);
+    dist += singleDistC;
+  }
+  return dist;
+}
+HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU *root)
+{
+  CtuMeta *m = e->cm;
+  uint32_t dist = 0;
+  TuWalk w; walk_begin(&w, root);
+  uint8_t splitCbf[5][2];
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ;
+    if (m->tr[z] == t->trDepth) { if (t->cW) dist += chroma_tu(e, t); w.sp--; continue; }
+    if (w.next[w.sp] < 0) { w.next[w.sp] = 0; splitCbf[w.sp][0] = splitCbf[w.sp][1] = 0; }
+    if (w.next[w.sp] > 0) { // a child just returned
+      const TU ch = tu_child(t, w.next[w.sp] - 1, 0);
+      for (int c = 1; c < 3; c++) splitCbf[w.sp][c - 1] |= (m->cbf[c][ch.cuZ + ch.relZ] >> ch.trDepth) & 1;
+    }
+    if (w.next[w.sp] == 4) {
+      HM_PAR_FOR(o, t->parts) for (int c = 1; c < 3; c++) if (splitCbf[w.sp][c - 1]) m->cbf[c][z + o] |= (uint8_t)(1 << t->trDepth);
+      HM_SYNC();
+      w.sp--; continue;
+    }
+    const int s = w.next[w.sp]++;
+    w.node[w.sp + 1] = tu_child(t, s, 0); w.next[w.sp + 1] = -1; w.sp++;
+  }
+  return dist;
+}
+// xSetIntraResultChromaQT, TEncSearch.cpp:2150-2200: visit the chroma leaves
+HM_DEV inline void set_intra_result_chroma_qt(Shared *e, const TU *root)
+{
+  const CtuMeta *m = e->cm;
+  TuWalk w; walk_begin(&w, root);
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ;
+    if (!t->cW) { w.sp--; continue; }
+    if (m->tr[z] == t->trDepth) {
+      const int n = t->cW, layer = 5 - t->log2;
+      for (int c = 1; c < 3; c++) {
+        const int po = HM_PLANE_OFF(c);
+        par_copy32(e->cc + po + t->cOff, e->ws->qtCoef[layer] + po + t->cOff, n * n);
+        par_copy_blk(e->ws->reco + po + t->cy * 32 + t->cx, 32, e->ws->qtRec[layer] + po + t->cy * 32 + t->cx, 32, n);
+      }
+      w.sp--; continue;
+    }
+    if (w.next[w.sp] < 0) w.next[w.sp] = 0;
+    if (w.next[w.sp] == 4) { w.sp--; continue; }
+    const int s = w.next[w.sp]++;
+    w.node[w.sp + 1] = tu_child(t, s, 0); w.next[w.sp + 1] = -1; w.sp++;
+  }
+}
+HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuDepth)
+{
+  CtuMeta *m = e->cm; WorkSpace *ws = e->ws; const int cuParts = 256 >> (2 * cuDepth);
+  const TU t = tu_root(e, cuZ, cuDepth);
+  int bestMode = 0; uint32_t bestDist = 0; double bestCost = HM_MAX_DOUBLE;
+  int modeList[5] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX, DM_CHROMA_IDX};       // getAllowedChromaDir, TComDataCU.cpp:1486
+  for (int i = 0; i < 4; i++) if (m->dirL[cuZ] == modeList[i]) { modeList[i] = 34; break; }
+  for (int mi = 0; mi < 5; mi++) {
+    cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+    par_set8(m->dirC + cuZ, modeList[mi], cuParts);
+    const uint32_t dist = recur_intra_chroma_coding_qt(e, &t);
+    cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+    const uint32_t bits = intra_bits_qt(e, &t, 0, 1);
+    const double cost = calc_rd_cost(e, bits, dist);
+    if (cost < bestCost) {
+      bestCost = cost; bestDist = dist; bestMode = modeList[mi];
+      set_intra_result_chroma_qt(e, &t);
+      HM_PAR_FOR(i, cuParts) for (int c = 1; c < 3; c++) { ws->saveCbf[c][i] = m->cbf[c][cuZ + i]; ws->saveTs[c][i] = m->ts[c][cuZ + i]; }
+      HM_SYNC();
+    }
+  }
+  HM_PAR_FOR(i, cuParts) { for (int c = 1; c < 3; c++) { m->cbf[c][cuZ + i] = ws->saveCbf[c][i]; m->ts[c][cuZ + i] = ws->saveTs[c][i]; } m->dirC[cuZ + i] = (uint8_t)bestMode; }
+  HM_SYNC();
+  cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+  return bestDist;
+}
+
+// ------------------------------------------------------------------------------------------------
+// final syntax of a CU (TEncEntropy::xEncodeTransform, TEncEntropy.cpp:222-412)
+// ------------------------------------------------------------------------------------------------
+HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDepth)
+{ // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
+  const CtuMeta *m = e->cm;
+  if (cuDepth == 3) enc_bin(c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
+  code_intra_dir_luma(e, c, cuZ, 1);
+  code_intra_dir_chroma(e, c, cuZ);
+  const TU root = tu_root(e, cuZ, cuDepth);
+  TuWalk w; walk_begin(&w, &root);
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ;
+    const int subdiv = m->tr[z] > t->trDepth;
+    if (w.next[w.sp] < 0) {
+      if (codes_subdiv_flag(m, t)) enc_bin(c, C_SUBDIV + (5 - t->log2), subdiv);
+      const int first = t->trDepth == 0;
+      for (int comp = 1; comp < 3; comp++)
+        if (first || t->cCodeAll)
+          if (first || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)) code_qt_cbf(e, c, t, comp, subdiv == 0);
+      if (!subdiv) {
+        code_qt_cbf(e, c, t, 0, 1);
+        for (int comp = 0; comp < 3; comp++) {
+          if (comp && !t->cW) continue;
+          if (!((m->cbf[comp][z] >> t->trDepth) & 1)) continue;
+          const int n = comp ? t->cW : (1 << t->log2);
+          const int zc = t->cuZ + (comp ? t->cRelZ : t->relZ);
+          const TCoeff *coef = e->cc + HM_PLANE_OFF(comp) + (comp ? t->cOff : z * 16);
+          code_coeff_nxn(e, c, coef, n, comp, coef_scan_idx(m, zc, n, comp), m->ts[comp][zc]);
+        }
+        w.sp--; continue;
+      }
+      w.next[w.sp] = 0;
+    }
+    if (w.next[w.sp] == 4) { w.sp--; continue; }
+    const int s = w.next[w.sp]++;
+    w.node[w.sp + 1] = tu_child(t, s, 1); w.next[w.sp + 1] = -1; w.sp++;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CU quadtree (TEncCu::xCompressCU :466-1122, xCheckRDCostIntra :1574-1646), explicit stack
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline void init_est_data(Shared *e, int cuZ, int cuDepth)
+{ // TComDataCU::initEstData, TComDataCU.cpp:484-552
+  CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
+  HM_PAR_FOR(i, parts) {
+    const int z = cuZ + i;
+    m->depth[z] = (uint8_t)cuDepth; m->part[z] = SIZE_NONE; m->pred[z] = MODE_NONE; m->dirL[z] = DC_IDX; m->dirC[z] = 0; m->tr[z] = 0;
+    for (int c = 0; c < 3; c++) { m->cbf[c][z] = 0; m->ts[c][z] = 0; }
+  }
+  HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = 0;
+  HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = 0; e->cc[5120 + cuZ * 4 + i] = 0; }
+  HM_SYNC();
+}
+HM_DEV inline void meta_copy_range(CtuMeta *d, const CtuMeta *s, int z0, int parts)
+{
+  HM_PAR_FOR(i, parts) {
+    const int z = z0 + i;
+    d->depth[z] = s->depth[z]; d->part[z] = s->part[z]; d->pred[z] = s->pred[z]; d->dirL[z] = s->dirL[z]; d->dirC[z] = s->dirC[z]; d->tr[z] = s->tr[z];
+    for (int c = 0; c < 3; c++) { d->cbf[c][z] = s->cbf[c][z]; d->ts[c][z] = s->ts[c][z]; }
+  }
+}
+HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
+{
+  Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
+  meta_copy_range(&b->m, e->cm, cuZ, parts);
+  HM_PAR_FOR(i, parts * 16) b->coef[cuZ * 16 + i] = e->cc[cuZ * 16 + i];
+  HM_PAR_FOR(i, parts * 4) { b->coef[4096 + cuZ * 4 + i] = e->cc[4096 + cuZ * 4 + i]; b->coef[5120 + cuZ * 4 + i] = e->cc[5120 + cuZ * 4 + i]; }
+  const int r = e->tab->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
+  HM_PAR_FOR(i, n * n) { const int yy = i >> l2, xx = i & (n - 1); b->reco[(y + yy) * 64 + x + xx] = e->ws->reco[(y + yy) * 64 + x + xx]; }
+  HM_PAR_FOR(i, (n * n) >> 2) {
+    const int yy = i >> (l2 - 1), xx = i & ((n >> 1) - 1), o = ((y >> 1) + yy) * 32 + (x >> 1) + xx;
+    b->reco[4096 + o] = e->ws->reco[4096 + o]; b->reco[5120 + o] = e->ws->reco[5120 + o];
+  }
+  HM_SYNC();
+}
+HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
+{ // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
+  const Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
+  meta_copy_range(e->cm, &b->m, cuZ, parts);
+  HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = b->coef[cuZ * 16 + i];
+  HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = b->coef[4096 + cuZ * 4 + i]; e->cc[5120 + cuZ * 4 + i] = b->coef[5120 + cuZ * 4 + i]; }
+  const int r = e->tab->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
+  Pel *ry = e->fb.rec[0] + (e->ctuY * 64 + y) * e->P->stride[0] + e->ctuX * 64 + x;
+  HM_PAR_FOR(i, n * n) { const int yy = i >> l2, xx = i & (n - 1); ry[yy * e->P->stride[0] + xx] = b->reco[(y + yy) * 64 + x + xx]; }
+  Pel *ru = e->fb.rec[1] + (e->ctuY * 32 + (y >> 1)) * e->P->stride[1] + e->ctuX * 32 + (x >> 1);
+  Pel *rv = e->fb.rec[2] + (e->ctuY * 32 + (y >> 1)) * e->P->stride[2] + e->ctuX * 32 + (x >> 1);
+  HM_PAR_FOR(i, (n * n) >> 2) {
+    const int yy = i >> (l2 - 1), xx = i & ((n >> 1) - 1), o = ((y >> 1) + yy) * 32 + (x >> 1) + xx;
+    ru[yy * e->P->stride[1] + xx] = b->reco[4096 + o]; rv[yy * e->P->stride[2] + xx] = b->reco[5120 + o];
+  }
+  HM_SYNC();
+}
+
+// xCheckRDCostIntra, TEncCu.cpp:1574-1646; leaves the trial in place
+HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int partSize, double *cost, uint32_t *bits, uint32_t *dist)
+{
+  CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
+  init_est_data(e, cuZ, cuDepth);
+  HM_PAR_FOR(i, parts) { m->part[cuZ + i] = (uint8_t)partSize; m->pred[cuZ + i] = MODE_INTRA; }
+  HM_SYNC();
+  uint32_t d = est_intra_pred_qt(e, cuZ, cuDepth);
+  { // luma reconstruction of the CU into the picture, TEncCu.cpp:1608
+    const int r = e->tab->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, ps = e->P->stride[0];
+    par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + y) * ps + e->ctuX * 64 + x, ps, e->ws->reco + y * 64 + x, 64, n);
+  }
+  d += est_intra_pred_chroma_qt(e, cuZ, cuDepth);
+  reset_bits(&e->cur);
+  encode_cu_syntax(e, &e->cur, cuZ, cuDepth);
+  cabac_copy(&e->slot[cuDepth][CI_TEMP_BEST], &e->cur);
+  *bits = num_bits(&e->cur); *dist = d;
+  *cost = calc_rd_cost(e, *bits, *dist);
+}
+
+struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
+
+// TEncCu::compressCtu -> xCompressCU recursion as a 4-level state machine
+HM_DEV HM_NOINLINE void compress_ctu(Shared *e, double *outCost, uint32_t *outBits, uint32_t *outDist)
+{
+  CtuMeta *m = e->cm;
+  CuFrame fr[4]; int sp = 0;
+  fr[0].cuZ = 0; fr[0].phase = 0;
+  double retCost = 0; uint32_t retBits = 0, retDist = 0;
+  while (sp >= 0) {
+    CuFrame *f = &fr[sp]; const int cuDepth = sp, cuZ = f->cuZ;
+    const int size = 64 >> cuDepth, parts = 256 >> (2 * cuDepth), q = parts >> 2;
+    if (f->phase == 0) {
+      const int r = e->tab->z2r[cuZ];
+      const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
+      f->boundary = !((lx + size - 1 < e->P->width) && (ty + size - 1 < e->P->height));
+      f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
+      if (!f->boundary) {
+        double c; uint32_t b, d;
+        check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N, &c, &b, &d);
+        if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]); }
+        if (cuDepth == 3) {
+          check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN, &c, &b, &d);
+          if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]); }
+        }
+        // split flag of the unsplit candidate, TEncCu.cpp:859-863 (coded on the go-on coder as it stands)
+        reset_bits(&e->cur);
+        if (cuDepth != 3) enc_bin(&e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
+        f->bestBits += num_bits(&e->cur);
+        f->bestCost = calc_rd_cost(e, f->bestBits, f->bestDist);
+      }
+      if (cuDepth == 3) { restore_best(e, cuZ, cuDepth); retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue; }
+      init_est_data(e, cuZ, cuDepth);
+      f->splitBits = 0; f->splitDist = 0; f->sub = 0; f->phase = 1;
+    }
+    if (f->phase == 1) {
+      if (f->sub < 4) {
+        const int s = f->sub++;
+        const int subZ = cuZ + s * q, r = e->tab->z2r[subZ];
+        const int sx = e->ctuX * 64 + (r & 15) * 4, sy = e->ctuY * 64 + (r >> 4) * 4;
+        // TComDataCU::initSubCU, TComDataCU.cpp:555-640
+        HM_PAR_FOR(i, q) { m->depth[subZ + i] = (uint8_t)(cuDepth + 1); m->part[subZ + i] = SIZE_NONE; m->pred[subZ + i] = MODE_NONE; }
+        HM_SYNC();
+        if (sx < e->P->width && sy < e->P->height) {
+          if (s == 0) cabac_copy(&e->slot[cuDepth + 1][CI_CURR_BEST], &e->slot[cuDepth][CI_CURR_BEST]);
+          else cabac_copy(&e->slot[cuDepth + 1][CI_CURR_BEST], &e->slot[cuDepth + 1][CI_NEXT_BEST]);
+          fr[sp + 1].cuZ = (int16_t)subZ; fr[sp + 1].phase = 0;
+          f->phase = 2; sp++; continue;
+        }
+        continue;
+      }
+      if (!f->boundary) {
+        reset_bits(&e->cur);
+        enc_bin(&e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), m->depth[cuZ] > cuDepth);
+        f->splitBits += num_bits(&e->cur);
+      }
+      f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
+      cabac_copy(&e->slot[cuDepth][CI_TEMP_BEST], &e->slot[cuDepth + 1][CI_NEXT_BEST]);
+      if (f->splitCost < f->bestCost) {
+        f->bestCost = f->splitCost; f->bestBits = f->splitBits; f->bestDist = f->splitDist;
+        cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]);
+      } else restore_best(e, cuZ, cuDepth);
+      retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
+    }
+    if (f->phase == 2) { // a sub-CU returned
+      f->splitBits += retBits; f->splitDist += retDist; f->phase = 1; continue;
+    }
+  }
+  *outCost = retCost; *outBits = retBits; *outDist = retDist;
+}
+
+// TEncCu::xEncodeCU, TEncCu.cpp:1185-1295: re-encode the decided CTU to advance the contexts
+HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
+{
+  const CtuMeta *m = e->cm;
+  int16_t stackZ[4]; int8_t stackNext[4]; int sp = 0;
+  stackZ[0] = 0; stackNext[0] = -1;
+  while (sp >= 0) {
+    const int depth = sp, z = stackZ[sp], size = 64 >> depth;
+    const int r = e->tab->z2r[z];
+    const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
+    const int inside = (lx + size - 1 < e->P->width) && (ty + size - 1 < e->P->height);
+    if (stackNext[sp] < 0) {
+      if (inside && depth != 3) enc_bin(c, C_SPLIT + ctx_split_flag(e, z, depth), m->depth[z] > depth);
+      if (!((depth < m->depth[z] && depth < 3) || !inside)) {
+        encode_cu_syntax(e, c, z, depth);
+        // finishCU, TEncCu.cpp:1130-1147
+        const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->P->width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->P->height);
+        if (lastX && lastY && !lastCtuOfSlice) enc_trm(c, 0);
+        sp--; continue;
+      }
+      stackNext[sp] = 0;
+    }
+    if (stackNext[sp] == 4) { sp--; continue; }
+    const int s = stackNext[sp]++;
+    const int q = (256 >> (2 * depth)) >> 2, sz = z + s * q, rr = e->tab->z2r[sz];
+    const int sx = e->ctuX * 64 + (rr & 15) * 4, sy = e->ctuY * 64 + (rr >> 4) * 4;
+    if (sx < e->P->width && sy < e->P->height) { stackZ[sp + 1] = (int16_t)sz; stackNext[sp + 1] = -1; sp++; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one CTU of TEncSlice::compressSlice (TEncSlice.cpp:724-892)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, int wsIndex)
+{
+  // uniform context (every lane writes the same values)
+  e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab;
+  e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
+  e->cm = e->fb.meta + e->ctuAddr; e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
+  HM_SYNC();
+  load_tmat(e);
+  const int a = e->ctuAddr, numCtus = P->wCtu * P->hCtu;
+  { // TComDataCU::initCtu, TComDataCU.cpp:357-470
+    CtuMeta *m = e->cm;
+    HM_PAR_FOR(z, 256) {
+      m->depth[z] = 0; m->part[z] = SIZE_NONE; m->pred[z] = MODE_NONE; m->dirL[z] = DC_IDX; m->dirC[z] = 0; m->tr[z] = 0;
+      for (int c = 0; c < 3; c++) { m->cbf[c][z] = 0; m->ts[c][z] = 0; }
+    }
+    HM_SYNC();
+  }
+  // CABAC state hand-off (TEncSlice.cpp:733-761)
+  Cabac *cb0 = &e->slot[0][CI_CURR_BEST];
+  if (a == 0) cabac_init(cb0, e->fb.qp);
+  else if (e->ctuX == 0 && P->wpp) {
+    cabac_init(cb0, e->fb.qp);
+    if (e->ctuY > 0 && P->wCtu > 1) { // contexts of the 2nd CTU of the row above, fresh bit accumulator
+      const Cabac *src = e->fb.endState + ((e->ctuY - 1) * P->wCtu + 1);
+      HM_PAR_FOR(i, HM_NUM_CTX) cb0->s[i] = src->s[i];
+      HM_SYNC();
+    }
+  } else cabac_copy(cb0, e->fb.endState + (a - 1));
+  cabac_copy(&e->cur, cb0);
+  double cost; uint32_t bits, dist;
+  compress_ctu(e, &cost, &bits, &dist);
+  e->fb.stat[a].cost = cost; e->fb.stat[a].bits = bits; e->fb.stat[a].dist = dist;
+  // TEncCu::encodeCtu on m_pppcRDSbacCoder[0][CI_CURR_BEST], TEncSlice.cpp:818-825
+  reset_bits(cb0);
+  encode_ctu(e, cb0, a == numCtus - 1);
+  cabac_copy(e->fb.endState + a, cb0);
+}

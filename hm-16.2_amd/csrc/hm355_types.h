@@ -1,0 +1,80 @@
+// hm355 device/host shared data layout (HBM-resident structures of the CTU RD search).
+// No reference code is copied here: the layouts are our own; where a field mirrors an array of the
+// reference's TComDataCU the comment names it (source/Lib/TLibCommon/TComDataCU.h:86-157).
+#pragma once
+#include <stdint.h>
+
+typedef int16_t Pel;      // TypeDef.h:692  (RExt__HIGH_BIT_DEPTH_SUPPORT=0)
+typedef int32_t TCoeff;   // TypeDef.h:693
+
+// ---- CABAC estimator state: one byte per context model + the Q15 fractional-bit accumulator ----
+// context numbering is ours; group sizes follow ContextTables.h:51-161 (intra subset)
+enum {
+  C_SPLIT = 0, C_PART = 3, C_INTRA_LUMA = 7, C_CHROMA_PRED = 8, C_SUBDIV = 10, C_QT_CBF = 13, C_SIG_CG = 23,
+  C_SIG = 27, C_LASTX = 71, C_LASTY = 101, C_ONE = 131, C_ABS = 155, C_TSKIP = 161, HM_NUM_CTX = 163
+};
+struct Cabac {
+  uint8_t s[168];          // HM_NUM_CTX used, padded to 8-byte multiple
+  uint64_t frac;           // TEncBinCABAC::m_fracBits
+};
+enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
+
+// ---- per-CTU decision arrays, 256 4x4 partitions in z-scan order ----
+struct CtuMeta {
+  uint8_t depth[256], part[256], pred[256], dirL[256], dirC[256], tr[256], cbf[3][256], ts[3][256];
+};
+struct CtuStat { double cost; uint32_t bits, dist; };
+
+// planes of one CTU-sized scratch picture: Y 64x64 at 0, Cb 32x32 at 4096, Cr 32x32 at 5120
+#define HM_PLANE_OFF(c) ((c) == 0 ? 0 : ((c) == 1 ? 4096 : 5120))
+#define HM_PLANE_STRIDE(c) ((c) == 0 ? 64 : 32)
+// coefficients of one CTU in the reference's packing: Y at 0 (z*16), Cb at 4096 (z*4), Cr at 5120 (z*4)
+#define HM_COEF_CTU 6144
+
+struct Best {              // best mode of one CU depth (the role of m_ppcBestCU[d] / m_ppcRecoYuvBest[d])
+  CtuMeta m;
+  TCoeff coef[HM_COEF_CTU];
+  Pel reco[HM_COEF_CTU];
+};
+
+// per-workgroup scratch in HBM (one CTU in flight per workgroup)
+struct WorkSpace {
+  Best best[4];
+  Pel pred[HM_COEF_CTU], resi[HM_COEF_CTU], reco[HM_COEF_CTU];
+  Pel qtRec[4][HM_COEF_CTU];         // m_pcQTTempTComYuv[layer]
+  TCoeff qtCoef[4][HM_COEF_CTU];     // m_ppcQTTempCoeff[comp][layer]
+  double costCoeff[1024], costSig[1024], costCoeff0[1024];          // RDOQ per-coefficient state
+  int32_t rateIncUp[1024], rateIncDown[1024], sigRateDelta[1024], deltaU[1024];
+  uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
+};
+
+// lookup tables generated on the host at create time (scan orders: TComRom.cpp:52-225)
+struct Tables {
+  uint8_t z2r[256], r2z[256];
+  uint16_t scan[3][4][1024];         // [scanType][log2-2][pos] grouped-4x4 scan -> raster position
+  uint16_t scanCG[3][4][64];         // [scanType][log2-2][cg]  scan of the coefficient-group grid
+};
+
+// one picture resident in HBM
+struct FrameBuf {
+  Pel *org[3], *rec[3];              // planes padded to whole CTUs (stride = wCtu*64 / wCtu*32)
+  CtuMeta *meta;                     // [numCtus]
+  TCoeff *coef;                      // [numCtus][HM_COEF_CTU]
+  CtuStat *stat;                     // [numCtus]
+  Cabac *endState;                   // [numCtus] estimator state after encodeCtu of that CTU
+  // slice parameters (TEncSlice::setUpLambda, TEncSlice.cpp:132-159)
+  double lambda, sqrtLambda, lambdaC, chromaWeight;
+  double errScale[2][4];             // [luma/chroma][log2-2]  TComTrQuant::setErrScaleCoeff :2933
+  int64_t rdFactor[2];               // sign-bit-hiding factor  TComTrQuant.cpp:2382-2386
+  int32_t qp, qpPer[2], qpRem[2];
+};
+
+struct Params {
+  int32_t width, height, bitDepth, wpp;
+  int32_t wCtu, hCtu, stride[3];
+  const Tables *tab;
+  WorkSpace *ws;
+  FrameBuf *frames;
+};
+
+struct WorkItem { int32_t frame, ctuX, ctuY, pad; };

@@ -1,0 +1,167 @@
+"""ctypes binding of libhm355.so (the C ABI in include/hm355.h) plus small test/bench helpers.
+
+PyTorch is not needed here: the library owns its device buffers.  The binding fails loudly when the
+HIP library is missing or no GPU is usable -- there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhm355.so")
+
+
+class SeqCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "bit_depth", "ctu_size", "max_cu_depth", "tu_log2_max",
+                                          "tu_log2_min", "tu_max_depth_intra", "wavefront_synchro", "max_batch")]
+
+
+class SliceDesc(C.Structure):
+    _fields_ = [("slice_type", C.c_int32), ("qp", C.c_int32), ("lambda_", C.c_double), ("chroma_weight", C.c_double)]
+
+
+class Planes(C.Structure):
+    _fields_ = [("plane", C.POINTER(C.c_uint16) * 3)]
+
+
+class CtuOut(C.Structure):
+    _fields_ = [("total_cost", C.c_double), ("total_bits", C.c_uint32), ("total_dist", C.c_uint32),
+                ("depth", C.c_uint8 * 256), ("part_size", C.c_uint8 * 256), ("pred_mode", C.c_uint8 * 256),
+                ("intra_dir_luma", C.c_uint8 * 256), ("intra_dir_chroma", C.c_uint8 * 256), ("tr_idx", C.c_uint8 * 256),
+                ("cbf", (C.c_uint8 * 256) * 3), ("tskip", (C.c_uint8 * 256) * 3),
+                ("coeff_y", C.c_int32 * 4096), ("coeff_cb", C.c_int32 * 1024), ("coeff_cr", C.c_int32 * 1024)]
+
+
+class SliceStats(C.Structure):
+    _fields_ = [("pic_total_bits", C.c_uint64), ("pic_rd_cost", C.c_double), ("pic_dist", C.c_uint64)]
+
+
+CTU_DTYPE = np.dtype([("total_cost", "<f8"), ("total_bits", "<u4"), ("total_dist", "<u4"),
+                      ("depth", "u1", 256), ("part_size", "u1", 256), ("pred_mode", "u1", 256),
+                      ("intra_dir_luma", "u1", 256), ("intra_dir_chroma", "u1", 256), ("tr_idx", "u1", 256),
+                      ("cbf", "u1", (3, 256)), ("tskip", "u1", (3, 256)),
+                      ("coeff_y", "<i4", 4096), ("coeff_cb", "<i4", 1024), ("coeff_cr", "<i4", 1024)])
+assert CTU_DTYPE.itemsize == C.sizeof(CtuOut)
+
+EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
+           "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
+           "hm355_transform_batch"]
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hm355 has no CPU fallback)")
+    lib = C.CDLL(path)
+    for name in EXPORTS:
+        getattr(lib, name)
+    lib.hm355_create.argtypes = [C.POINTER(SeqCfg), C.POINTER(C.c_void_p)]
+    lib.hm355_destroy.argtypes = [C.c_void_p]
+    lib.hm355_last_error.argtypes = [C.c_void_p]
+    lib.hm355_last_error.restype = C.c_char_p
+    lib.hm355_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes)]
+    lib.hm355_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SliceDesc)]
+    lib.hm355_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes), C.c_void_p, C.POINTER(SliceStats)]
+    lib.hm355_last_run_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    lib.hm355_compress_slice.argtypes = [C.c_void_p, C.POINTER(SliceDesc), C.POINTER(Planes), C.POINTER(Planes), C.c_void_p,
+                                         C.POINTER(SliceStats)]
+    lib.hm355_dist_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hm355_transform_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def intra_lambda(qp):
+    """I-slice lambda / chroma distortion weight of an all-intra GOP
+    (TEncSlice::initEncSlice, TEncSlice.cpp:323-352; setUpLambda :132-159)."""
+    chroma_scale = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
+                    29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48,
+                    49, 50, 51]
+    lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
+    qpc = chroma_scale[min(max(qp, 0), 57)]
+    return lam, 2.0 ** ((qp - qpc) / 3.0)
+
+
+def _planes(arrs):
+    p = Planes()
+    for k in range(3):
+        a = arrs[k]
+        assert a.dtype == np.uint16 and a.flags["C_CONTIGUOUS"]
+        p.plane[k] = a.ctypes.data_as(C.POINTER(C.c_uint16))
+    return p
+
+
+class Encoder:
+    """Thin object wrapper of a hm355_ctx (one per TEncTop-like encoder instance)."""
+
+    def __init__(self, width, height, bit_depth, wpp=0, max_batch=1, lib=None):
+        self.lib = lib or load_library()
+        self.w, self.h, self.bd, self.wpp, self.max_batch = width, height, bit_depth, wpp, max_batch
+        self.num_ctus = ((width + 63) // 64) * ((height + 63) // 64)
+        cfg = SeqCfg(width, height, bit_depth, 64, 4, 5, 2, 3, wpp, max_batch)
+        h = C.c_void_p()
+        rc = self.lib.hm355_create(C.byref(cfg), C.byref(h))
+        self.h_ = h
+        if rc != 0:
+            msg = self.lib.hm355_last_error(h).decode() if h else ""
+            if h:
+                self.lib.hm355_destroy(h)
+                self.h_ = None
+            raise RuntimeError(f"hm355_create failed rc={rc} {msg}")
+
+    def close(self):
+        if getattr(self, "h_", None):
+            self.lib.hm355_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed rc={rc}: {self.lib.hm355_last_error(self.h_).decode()}")
+
+    def upload(self, slot, planes):
+        p = _planes(planes)
+        self._check(self.lib.hm355_upload(self.h_, slot, C.byref(p)), "hm355_upload")
+
+    def run(self, n, qp):
+        lam, cw = intra_lambda(qp)
+        sl = (SliceDesc * n)(*[SliceDesc(2, qp, lam, cw) for _ in range(n)])
+        self._check(self.lib.hm355_run(self.h_, n, sl), "hm355_run")
+        ms, launches = C.c_double(), C.c_int()
+        self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
+        return ms.value, launches.value
+
+    def download(self, slot, want_ctus=True):
+        rec = [np.zeros((self.h, self.w), np.uint16), np.zeros((self.h // 2, self.w // 2), np.uint16),
+               np.zeros((self.h // 2, self.w // 2), np.uint16)]
+        p = _planes(rec)
+        ctus = np.zeros(self.num_ctus, CTU_DTYPE) if want_ctus else None
+        st = SliceStats()
+        self._check(self.lib.hm355_download(self.h_, slot, C.byref(p), ctus.ctypes.data if want_ctus else None, C.byref(st)),
+                    "hm355_download")
+        return rec, ctus, (st.pic_total_bits, st.pic_rd_cost, st.pic_dist)
+
+    def compress(self, frames, qp):
+        """frames: list of (Y,U,V) uint16 planes -> list of (rec, ctus, stats)"""
+        for i, f in enumerate(frames):
+            self.upload(i, f)
+        self.run(len(frames), qp)
+        return [self.download(i) for i in range(len(frames))]
+
+    def dist_batch(self, kind, org, cur, bit_depth):
+        """org/cur: (count, n, n) int16; kind 0 SAD, 1 SSE, 2 SATD, 3 SAD with row sub-sampling"""
+        count, n = org.shape[0], org.shape[1]
+        out = np.zeros(count, np.uint32)
+        o, c = np.ascontiguousarray(org, np.int16), np.ascontiguousarray(cur, np.int16)
+        self._check(self.lib.hm355_dist_batch(self.h_, kind, n, bit_depth, count, o.ctypes.data, c.ctypes.data, out.ctypes.data),
+                    "hm355_dist_batch")
+        return out
+
+    def transform_batch(self, inverse, blocks, bit_depth, use_dst=0):
+        count, n = blocks.shape[0], blocks.shape[1]
+        b = np.ascontiguousarray(blocks, np.int32)
+        out = np.zeros_like(b)
+        self._check(self.lib.hm355_transform_batch(self.h_, inverse, n, bit_depth, use_dst, count, b.ctypes.data, out.ctypes.data),
+                    "hm355_transform_batch")
+        return out

@@ -1,0 +1,112 @@
+/* hm355 -- MI355X-native replacement for the CTU-level RD search of HM-16.2 (liron88/HM-16.2).
+ *
+ * C ABI of the drop-in boundary.  The reference has no FFI layer; the seam is the C++ member
+ *     Void TEncSlice::compressSlice( TComPic* pcPic )      source/Lib/TLibEncoder/TEncSlice.h:118
+ *                                                           (body TEncSlice.cpp:640-904, caller TEncGOP.cpp:1138)
+ * The entry points below are what a binding of that member would call: plain pointers and sizes,
+ * caller-owned buffers, blocking calls, negative return codes instead of assert/exit.
+ * INTEGRATION.md shows the few lines a reference maintainer adds inside TEncSlice::compressSlice.
+ *
+ * All work is done by hand-written HIP kernels (hm-16.2_amd/csrc/hm355_kernels.hip).  There is NO
+ * CPU fallback: without a usable gfx950 device hm355_create() fails with HM355_ERR_NO_DEVICE.
+ */
+#ifndef HM355_H
+#define HM355_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HM355_OK               0
+#define HM355_ERR_ARG         -1   /* bad argument / unsupported configuration */
+#define HM355_ERR_NO_DEVICE   -2   /* no HIP device or kernel image not loadable */
+#define HM355_ERR_NOMEM       -3
+#define HM355_ERR_DEVICE      -4   /* a HIP call or a kernel failed */
+
+/* Sequence-level parameters: the SPS/PPS/TEncCfg getters compressSlice reads
+ * (TEncCfg.h; cfg/encoder_intra_main.cfg, cfg/encoder_intra_main10.cfg).  Values other than the
+ * ones of those cfg files are rejected with HM355_ERR_ARG rather than silently ignored. */
+typedef struct {
+  int32_t width, height;          /* SourceWidth/Height, multiples of 8 (min CU) */
+  int32_t bit_depth;              /* InternalBitDepth 8 or 10 (luma == chroma) */
+  int32_t ctu_size;               /* MaxCUWidth = 64 */
+  int32_t max_cu_depth;           /* MaxPartitionDepth = 4 */
+  int32_t tu_log2_max, tu_log2_min;   /* 5, 2 */
+  int32_t tu_max_depth_intra;     /* QuadtreeTUMaxDepthIntra = 3 */
+  int32_t wavefront_synchro;      /* WaveFrontSynchro 0/1 (TEncSlice.cpp:740-755,855-858) */
+  int32_t max_batch;              /* how many independent pictures one call may carry (>=1) */
+} hm355_seq_cfg;
+
+/* Slice-level parameters: what TEncSlice::initEncSlice / setUpLambda (TEncSlice.cpp:132-159,180-481)
+ * push into TComRdCost / TComTrQuant before compressSlice runs. */
+typedef struct {
+  int32_t slice_type;             /* 2 = I_SLICE (only value supported this round) */
+  int32_t qp;                     /* TComSlice::getSliceQp() */
+  double  lambda;                 /* TComRdCost::m_dLambda */
+  double  chroma_weight;          /* TComRdCost::m_distortionWeight[Cb]==[Cr] */
+} hm355_slice_desc;
+
+/* planar 4:2:0 picture, 16-bit samples, tightly packed rows (stride == width of the plane) */
+typedef struct {
+  uint16_t *plane[3];
+} hm355_planes;
+
+/* Per-CTU result: the TComDataCU arrays compressSlice leaves in pcPic->getCtu(rs)
+ * (TComDataCU.h:86-157), 256 4x4 partitions in z-scan order, and m_pcTrCoeff in HM's TU packing
+ * (TU with z-order index z starts at z*16 for luma, z*4 for chroma; row-major inside the TU). */
+typedef struct {
+  double   total_cost;            /* m_dTotalCost */
+  uint32_t total_bits;            /* m_uiTotalBits */
+  uint32_t total_dist;            /* m_uiTotalDistortion */
+  uint8_t  depth[256], part_size[256], pred_mode[256], intra_dir_luma[256], intra_dir_chroma[256],
+           tr_idx[256], cbf[3][256], tskip[3][256];
+  int32_t  coeff_y[4096], coeff_cb[1024], coeff_cr[1024];
+} hm355_ctu_out;
+
+/* m_uiPicTotalBits / m_dPicRdCost / m_uiPicDist (TEncSlice.cpp:889-891) */
+typedef struct {
+  uint64_t pic_total_bits;
+  double   pic_rd_cost;
+  uint64_t pic_dist;
+} hm355_slice_stats;
+
+typedef struct hm355_ctx hm355_ctx;
+
+/* TEncTop::create/init equivalent for the hot path: allocates every device buffer once. */
+int  hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out);
+void hm355_destroy(hm355_ctx *ctx);
+const char *hm355_last_error(const hm355_ctx *ctx);
+
+/* Replacement of TEncSlice::compressSlice for one picture (host buffers in, host buffers out).
+ *   org  : TComPic::getPicYuvOrg()          rec : TComPic::getPicYuvRec() (pre-deblocking)
+ *   ctus : one record per CTU, raster order  stats : may be NULL */
+int hm355_compress_slice(hm355_ctx *ctx, const hm355_slice_desc *slice, const hm355_planes *org,
+                         hm355_planes *rec, hm355_ctu_out *ctus, hm355_slice_stats *stats);
+
+/* The same for n independent pictures (all-intra: every picture is an IDR-like I slice with its own
+ * CABAC reset, TEncSlice.cpp:653-654), evaluated concurrently.  n <= max_batch. */
+int hm355_compress_slices(hm355_ctx *ctx, int n, const hm355_slice_desc *slices, const hm355_planes *org,
+                          hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_slice_stats *stats);
+
+/* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
+ * Upload / run / download are separate so that a caller can keep pictures resident. */
+int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */
+int hm355_run(hm355_ctx *ctx, int n, const hm355_slice_desc *slices);         /* slots [0,n) -> results in HBM; blocking */
+int hm355_download(hm355_ctx *ctx, int slot, hm355_planes *rec, hm355_ctu_out *ctus, hm355_slice_stats *stats);
+/* kernel time of the last hm355_run in milliseconds, measured with HIP events on the launch stream,
+ * and the number of kernel launches it took */
+int hm355_last_run_info(const hm355_ctx *ctx, double *kernel_ms, int *launches);
+
+/* ---- distortion / transform primitives as batched kernels (TComRdCost.cpp:465-1606,
+ *      TComTrQuant.cpp:836-935); used by the known-answer parity tests and micro-benchmarks ----
+ * blocks are n x n, tightly packed, `count` of them back to back. kind: 0 SAD, 1 SSE, 2 SATD */
+int hm355_dist_batch(hm355_ctx *ctx, int kind, int n, int bit_depth, int count,
+                     const int16_t *org, const int16_t *cur, uint32_t *out);
+int hm355_transform_batch(hm355_ctx *ctx, int inverse, int n, int bit_depth, int use_dst, int count,
+                          const int32_t *in, int32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,67 @@
+// DEBUGGING AID, NOT PRODUCT: compiles hm-16.2_amd/csrc/hm355_core.h -- the very source the gfx950
+// kernel is built from -- for the host with one "lane" (HM_NT == 1), so that the decision logic can be
+// stepped through and diffed against the oracle in a container that has no GPU.  It is built only by
+// tests/ (never linked into libhm355.so) and it cannot exercise cross-lane behaviour; the GPU parity
+// tests remain the gate.  With -DHM355_HOSTSIM_REVERSE every lane-parallel loop runs backwards, which
+// exposes accidental order dependences between "lanes".
+//   hostsim <in.yuv> <w> <h> <bitdepth> <frames> <qp> <wpp> <dump.bin>       (same dump as oracle CLI)
+#define HM355_HOSTSIM 1
+#include "../../hm-16.2_amd/csrc/hm355_core.h"
+#include "../../hm-16.2_amd/csrc/hm355_host_common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+int main(int argc, char **argv)
+{
+  if (argc < 9) { fprintf(stderr, "usage: %s in.yuv w h bd frames qp wpp dump.bin\n", argv[0]); return 2; }
+  const int w = atoi(argv[2]), h = atoi(argv[3]), bd = atoi(argv[4]), frames = atoi(argv[5]), qp = atoi(argv[6]), wpp = atoi(argv[7]);
+  FILE *fi = fopen(argv[1], "rb"), *fo = fopen(argv[8], "wb");
+  if (!fi || !fo) { perror("open"); return 1; }
+  Params P; memset(&P, 0, sizeof(P));
+  P.width = w; P.height = h; P.bitDepth = bd; P.wpp = wpp; P.wCtu = (w + 63) / 64; P.hCtu = (h + 63) / 64;
+  P.stride[0] = P.wCtu * 64; P.stride[1] = P.stride[2] = P.wCtu * 32;
+  const int nctu = P.wCtu * P.hCtu;
+  Tables *tab = new Tables; hm355_build_tables(tab); P.tab = tab;
+  P.ws = (WorkSpace *)calloc(1, sizeof(WorkSpace));
+  std::vector<FrameBuf> fbs(frames);
+  double lambda, cw; hm355_intra_lambda(qp, &lambda, &cw);
+  for (int f = 0; f < frames; f++) {
+    FrameBuf &fb = fbs[f]; memset(&fb, 0, sizeof(fb));
+    for (int c = 0; c < 3; c++) {
+      const size_t n = (size_t)P.stride[c] * P.hCtu * (c ? 32 : 64);
+      fb.org[c] = (Pel *)calloc(n, sizeof(Pel)); fb.rec[c] = (Pel *)calloc(n, sizeof(Pel));
+      const int pw = w >> (c ? 1 : 0), ph = h >> (c ? 1 : 0);
+      for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) {
+        unsigned v;
+        if (bd == 8) { unsigned char t; if (fread(&t, 1, 1, fi) != 1) return 3; v = t; } else { unsigned short t; if (fread(&t, 2, 1, fi) != 1) return 3; v = t; }
+        fb.org[c][y * P.stride[c] + x] = (Pel)v;
+      }
+    }
+    fb.meta = (CtuMeta *)calloc(nctu, sizeof(CtuMeta)); fb.coef = (TCoeff *)calloc((size_t)nctu * HM_COEF_CTU, sizeof(TCoeff));
+    fb.stat = (CtuStat *)calloc(nctu, sizeof(CtuStat)); fb.endState = (Cabac *)calloc(nctu, sizeof(Cabac));
+    hm355_fill_slice_params(&fb, bd, qp, lambda, cw);
+  }
+  P.frames = fbs.data();
+  std::vector<WorkItem> items; std::vector<int> stepStart;
+  hm355_build_schedule(P.wCtu, P.hCtu, wpp, frames, items, stepStart);
+  static Shared sh;
+  for (size_t i = 0; i < items.size(); i++) process_ctu(&sh, &P, &items[i], 0);
+  fwrite("HMD1", 1, 4, fo);
+  uint32_t hdr[5] = { (uint32_t)w, (uint32_t)h, (uint32_t)bd, 64, (uint32_t)frames }; fwrite(hdr, 4, 5, fo);
+  for (int f = 0; f < frames; f++) {
+    FrameBuf &fb = fbs[f];
+    uint32_t u[2] = { (uint32_t)f, (uint32_t)nctu }; fwrite(u, 4, 2, fo);
+    for (int a = 0; a < nctu; a++) {
+      fwrite(&fb.stat[a].cost, 8, 1, fo); fwrite(&fb.stat[a].bits, 4, 1, fo); fwrite(&fb.stat[a].dist, 4, 1, fo);
+      fwrite(&fb.meta[a], 1, sizeof(CtuMeta), fo);
+      fwrite(fb.coef + (size_t)a * HM_COEF_CTU, 4, HM_COEF_CTU, fo);
+    }
+    for (int c = 0; c < 3; c++) {
+      const int pw = w >> (c ? 1 : 0), ph = h >> (c ? 1 : 0);
+      for (int y = 0; y < ph; y++) for (int x = 0; x < pw; x++) { unsigned short v = (unsigned short)fb.rec[c][y * P.stride[c] + x]; fwrite(&v, 2, 1, fo); }
+    }
+  }
+  fclose(fo); fclose(fi);
+  return 0;
+}

@@ -1,0 +1,99 @@
+"""GPU suite (-m gpu): the HIP path through the C ABI against (1) the golden vectors of the real
+reference encoder, (2) the oracle on freshly seeded inputs, (3) the primitive KATs."""
+import numpy as np
+import pytest
+
+import common
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hm():
+    import hm355
+    return hm355
+
+
+@pytest.mark.parametrize("name", common.CASES)
+def test_hip_matches_reference_fixture(hm, name):
+    cfg, frames = common.load_case(name)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=cfg["frames"])
+    planes = [synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], i, cfg["seed"]) for i in range(cfg["frames"])]
+    res = enc.compress(planes, cfg["qp"])
+    for i, (ctus, rec) in enumerate(frames):
+        got_rec, got_ctus, stats = res[i]
+        common.assert_ctus_equal(got_ctus, ctus, f"{name} frame {i}", (cfg["width"], cfg["height"]))
+        common.assert_rec_equal(got_rec, rec, cfg["width"], cfg["height"], f"{name} frame {i}")
+        assert stats[0] == int(ctus["total_bits"].sum()) and stats[2] == int(ctus["total_dist"].sum())
+    enc.close()
+
+
+@pytest.mark.parametrize("w,h,bd,qp,wpp,seed", [(192, 128, 8, 30, 1, 11), (128, 72, 10, 34, 0, 12), (64, 64, 8, 25, 0, 13)])
+def test_hip_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, qp, wpp, seed):
+    import oracle
+    planes = synth.frame(w, h, bd, 0, seed)
+    want_rec, want_ctus = oracle.compress(planes, bd, qp, wpp)
+    enc = hm.Encoder(w, h, bd, wpp, max_batch=1)
+    (got_rec, got_ctus, _), = enc.compress([planes], qp)
+    common.assert_ctus_equal(got_ctus, want_ctus, f"{w}x{h}")
+    for k in range(3):
+        assert np.array_equal(got_rec[k], want_rec[k])
+    enc.close()
+
+
+def test_hip_batch_equals_single(hm):
+    """pictures of a batch are independent: batched results == one-at-a-time results"""
+    w, h, bd, qp = 128, 128, 8, 32
+    planes = [synth.frame(w, h, bd, i, 5) for i in range(3)]
+    enc = hm.Encoder(w, h, bd, 1, max_batch=3)
+    batch = enc.compress(planes, qp)
+    for i in range(3):
+        (rec, ctus, _), = enc.compress([planes[i]], qp)
+        common.assert_ctus_equal(batch[i][1], ctus, f"picture {i}")
+        for k in range(3):
+            assert np.array_equal(batch[i][0][k], rec[k])
+    enc.close()
+
+
+def test_hip_primitive_kats(hm):
+    """SAD/SSE/SATD and transform kernels vs the reference's known answers"""
+    k = np.load(common.GOLD + "/kat_primitives.npz")
+    enc = hm.Encoder(64, 64, 8, 0, 1)
+    off = k["dist_in_off"]
+    for r in range(len(k["dist_out"])):
+        v = k["dist_in"][off[r]:off[r + 1]]
+        tag = int(v[0])
+        if tag == 1:
+            bd, n, sub = int(v[1]), int(v[2]), int(v[3]); data = v[4:]
+        else:
+            bd, n, sub = int(v[1]), int(v[2]), 0; data = v[3:]
+        a = data[:n * n].astype(np.int16).reshape(1, n, n); b = data[n * n:].astype(np.int16).reshape(1, n, n)
+        kind = {1: (3 if sub else 0), 2: 1, 3: 2}[tag]
+        got = int(enc.dist_batch(kind, a, b, bd)[0])
+        assert got == int(k["dist_out"][r]), f"record {r} tag {tag} n {n} bd {bd} sub {sub}"
+    ioff, ooff = k["tr_in_off"], k["tr_out_off"]
+    for r in range(len(ioff) - 1):
+        v = k["tr_in"][ioff[r]:ioff[r + 1]]
+        tag, bd, n, dst = int(v[0]), int(v[1]), int(v[2]), int(v[3])
+        blk = v[4:].astype(np.int32).reshape(1, n, n)
+        want = k["tr_out"][ooff[r]:ooff[r + 1]].reshape(n, n)
+        got = enc.transform_batch(1 if tag == 5 else 0, blk, bd, dst)[0]
+        assert np.array_equal(got, want), f"record {r} tag {tag} n {n} bd {bd}"
+    enc.close()
+
+
+def test_hip_primitives_linearity_at_scale(hm):
+    """size-independent property at a large batch: SAD(a,b) == SAD(a-b,0) and SSE symmetric; transform of
+    0 is 0 and forward transform is odd: T(-x) == -T(x) up to the rounding offset identity for zero input"""
+    rng = np.random.default_rng(3)
+    n, count = 16, 4096
+    a = rng.integers(0, 1023, (count, n, n)).astype(np.int16); b = rng.integers(0, 1023, (count, n, n)).astype(np.int16)
+    enc = hm.Encoder(64, 64, 10, 0, 1)
+    s1 = enc.dist_batch(0, a, b, 10); s2 = enc.dist_batch(0, b, a, 10)
+    assert np.array_equal(s1, s2)
+    ref = (np.abs(a.astype(np.int64) - b).sum(axis=(1, 2)) >> 2).astype(np.uint32)
+    assert np.array_equal(s1, ref)
+    z = enc.transform_batch(0, np.zeros((8, n, n), np.int32), 10)
+    assert not z.any()
+    enc.close()

@@ -1,0 +1,99 @@
+"""CPU suite: host-side logic of the product (schedule, ABI surface, library exports)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+
+ROOT = common.ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    """libhm355.so must load without a GPU and export every function include/hm355.h declares"""
+    import hm355
+    hdr = open(os.path.join(ROOT, "include", "hm355.h")).read()
+    declared = sorted(set(re.findall(r"\b(hm355_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    lib = ctypes.CDLL(hm355.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/hm355.h but not exported"
+    assert set(hm355.EXPORTS) == set(declared)
+
+
+def test_create_rejects_bad_config_and_missing_gpu():
+    """argument errors are reported as HM355_ERR_ARG; without a device create() must fail (no CPU fallback)"""
+    import hm355
+    lib = hm355.load_library()
+    h = ctypes.c_void_p()
+    bad = hm355.SeqCfg(417, 240, 8, 64, 4, 5, 2, 3, 0, 1)
+    assert lib.hm355_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    bad = hm355.SeqCfg(416, 240, 9, 64, 4, 5, 2, 3, 0, 1)
+    assert lib.hm355_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    import torch
+    if not torch.cuda.is_available():
+        ok = hm355.SeqCfg(416, 240, 8, 64, 4, 5, 2, 3, 0, 1)
+        rc = lib.hm355_create(ctypes.byref(ok), ctypes.byref(h))
+        assert rc == -2, "hm355_create must fail with HM355_ERR_NO_DEVICE when there is no GPU"
+
+
+def _schedule(wc, hc, wpp, frames):
+    """python mirror of hm355_build_schedule (hm355_host_common.h) for property checks"""
+    steps = wc + 2 * (hc - 1) if wpp else wc * hc
+    out = []
+    for s in range(steps):
+        items = []
+        for f in range(frames):
+            if wpp:
+                for y in range(hc):
+                    x = s - 2 * y
+                    if 0 <= x < wc:
+                        items.append((f, x, y))
+            else:
+                items.append((f, s % wc, s // wc))
+        out.append(items)
+    return out
+
+
+@pytest.mark.parametrize("wc,hc,wpp", [(7, 4, 1), (7, 4, 0), (60, 34, 1), (1, 3, 1), (2, 2, 1)])
+def test_schedule_respects_dependencies(wc, hc, wpp):
+    sched = _schedule(wc, hc, wpp, 2)
+    done = {}
+    for s, items in enumerate(sched):
+        for (f, x, y) in items:
+            deps = [(x - 1, y), (x, y - 1), (x - 1, y - 1), (x + 1, y - 1)]
+            if not wpp and (x, y) != (0, 0):
+                px, py = (x - 1, y) if x > 0 else (wc - 1, y - 1)
+                deps.append((px, py))
+            if wpp and x == 0 and y > 0 and wc > 1:
+                deps.append((1, y - 1))
+            for (dx, dy) in deps:
+                if 0 <= dx < wc and 0 <= dy < hc:
+                    assert done.get((f, dx, dy), 10 ** 9) < s, f"CTU {(x, y)} scheduled before {(dx, dy)}"
+        for it in items:
+            done[it] = s
+    assert len(done) == 2 * wc * hc
+
+
+def test_hostsim_of_kernel_source_matches_reference_fixture(tmp_path):
+    """The kernel source (hm355_core.h) compiled for the host with one lane, forwards and with every
+    lane-parallel loop reversed, reproduces the reference fixture.  Debugging aid: the GPU tests are the gate."""
+    import synth
+    cfg, frames = common.load_case("small_128x128_10b_qp37")
+    yuv = tmp_path / "in.yuv"
+    synth.write_yuv(str(yuv), cfg["width"], cfg["height"], cfg["bit_depth"], cfg["frames"], cfg["seed"])
+    import gen_golden
+    for flag, exe in (("", "hostsim"), ("-DHM355_HOSTSIM_REVERSE", "hostsim_rev")):
+        out = tmp_path / exe
+        cmd = ["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-w"] + ([flag] if flag else []) + ["-o", str(out), os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")]
+        subprocess.run(cmd, check=True)
+        dump = tmp_path / (exe + ".bin")
+        subprocess.run([str(out), str(yuv), str(cfg["width"]), str(cfg["height"]), str(cfg["bit_depth"]), str(cfg["frames"]),
+                        str(cfg["qp"]), str(cfg["wpp"]), str(dump)], check=True)
+        got = gen_golden.parse_dump(str(dump))
+        for i, (ctus, rec) in enumerate(frames):
+            common.assert_ctus_equal(got[i][0], ctus, f"{exe} frame {i}", (cfg["width"], cfg["height"]))
+            assert np.array_equal(got[i][1], rec)

@@ -1,0 +1,53 @@
+"""CPU suite: the oracle (oracle/hm_oracle.c) against the golden vectors produced by the real
+reference encoder (tests/gen_golden.py -> oracle/_ref/hm_dump).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+import common
+import synth
+
+
+@pytest.mark.parametrize("name", common.CASES)
+def test_oracle_matches_reference_fixture(built, name):
+    import oracle
+    cfg, frames = common.load_case(name)
+    for i, (ctus, rec) in enumerate(frames):
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], i, cfg["seed"])
+        got_rec, got_ctus = oracle.compress(planes, cfg["bit_depth"], cfg["qp"], cfg["wpp"])
+        common.assert_ctus_equal(got_ctus, ctus, f"{name} frame {i}", (cfg["width"], cfg["height"]))
+        common.assert_rec_equal(got_rec, rec, cfg["width"], cfg["height"], f"{name} frame {i}")
+
+
+def _kat():
+    return np.load(common.GOLD + "/kat_primitives.npz")
+
+
+def test_oracle_distortion_kats(built):
+    """SAD (with and without FEN row sub-sampling), SSE, SATD vs TComRdCost of the reference"""
+    import oracle
+    k = _kat()
+    off = k["dist_in_off"]
+    for r in range(len(k["dist_out"])):
+        v = k["dist_in"][off[r]:off[r + 1]]
+        tag = int(v[0])
+        if tag == 1:
+            bd, n, sub = int(v[1]), int(v[2]), int(v[3]); data = v[4:]
+        else:
+            bd, n, sub = int(v[1]), int(v[2]), 0; data = v[3:]
+        a = data[:n * n].astype(np.int16).reshape(n, n); b = data[n * n:].astype(np.int16).reshape(n, n)
+        got = oracle.dist({1: 0, 2: 1, 3: 2}[tag], a, b, bd, sub)
+        assert got == int(k["dist_out"][r]), f"record {r} tag {tag} n {n} bd {bd}"
+
+
+def test_oracle_transform_kats(built):
+    """forward / inverse 4..32-point DCT and the 4x4 DST vs xTrMxN / xITrMxN of the reference"""
+    import oracle
+    k = _kat()
+    ioff, ooff = k["tr_in_off"], k["tr_out_off"]
+    for r in range(len(ioff) - 1):
+        v = k["tr_in"][ioff[r]:ioff[r + 1]]
+        tag, bd, n, dst = int(v[0]), int(v[1]), int(v[2]), int(v[3])
+        blk = v[4:].astype(np.int32).reshape(n, n)
+        want = k["tr_out"][ooff[r]:ooff[r + 1]].reshape(n, n)
+        got = oracle.transform(tag == 5, blk, bd, dst)
+        assert np.array_equal(got, want), f"record {r} tag {tag} n {n} bd {bd} dst {dst}"
