@@ -136,7 +136,10 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
     HM_CHECK(c, hipMalloc((void **)&fb.stat, sizeof(CtuStat) * c->numCtus));
     HM_CHECK(c, hipMalloc((void **)&fb.endState, sizeof(Cabac) * c->numCtus));
   }
-  P.tab = c->dTab; P.ws = c->dWs; P.frames = c->dFrames;
+  P.tab = c->dTab; P.ws = c->dWs; P.frames = c->dFrames; P.prof = NULL;
+#ifdef HM355_PROFILE
+  HM_CHECK(c, hipMalloc((void **)&P.prof, 64 * sizeof(unsigned long long))); HM_CHECK(c, hipMemset(P.prof, 0, 64 * sizeof(unsigned long long)));
+#endif
   HM_CHECK(c, hipMemcpy(c->dP, &P, sizeof(Params), hipMemcpyHostToDevice));
   return HM355_OK;
 }
@@ -209,6 +212,11 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
   c->lastKernelMs = ms; c->lastLaunches = launches;
   return HM355_OK;
 }
+
+#ifdef HM355_PROFILE
+extern "C" int hm355_read_profile(hm355_ctx *c, unsigned long long *out32)
+{ return hipMemcpy(out32, c->hp.prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : HM355_ERR_DEVICE; }
+#endif
 
 extern "C" int hm355_last_run_info(const hm355_ctx *c, double *kernel_ms, int *launches)
 {

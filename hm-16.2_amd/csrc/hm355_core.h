@@ -32,6 +32,7 @@ static inline int hm_lane() { return 0; }
 #define HM_SYNC() ((void)0)
 static inline uint32_t hm_wave_sum(uint32_t v) { return v; }
 static inline int hm_wave_sum_i(int v) { return v; }
+static inline int hm_wave_max_i(int v) { return v; }
 #ifdef HM355_HOSTSIM_REVERSE   /* run every lane-parallel loop backwards: catches order dependence */
 #define HM_PAR_FOR(i, n) for (int i = (n) - 1; i >= 0; i--)
 #else
@@ -56,8 +57,25 @@ __device__ __forceinline__ int hm_wave_sum_i(int v)
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+__device__ __forceinline__ int hm_wave_max_i(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
 #define HM_PAR_FOR(i, n) for (int i = hm_lane(); i < (n); i += HM_NT)
 #endif
+
+// optional in-kernel cycle accounting (diagnostic build only: -DHM355_PROFILE, never in the product build)
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+#define HM_PROF_N 16
+#define HM_PROF_BEGIN(e, id) const unsigned long long prof_t0_##id = __builtin_readcyclecounter()
+#define HM_PROF_END(e, id) do { (e)->prof[id] += __builtin_readcyclecounter() - prof_t0_##id; (e)->profCnt[id] += 1; } while (0)
+#else
+#define HM_PROF_BEGIN(e, id) ((void)0)
+#define HM_PROF_END(e, id) ((void)0)
+#endif
+enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBLK, PR_SAVE, PR_CHROMA, PR_LUMA, PR_ENCCU, PR_TOTAL };
 
 #define HM_MAX_DOUBLE 1.7e+308
 #define PLANAR_IDX 0
@@ -134,10 +152,25 @@ struct Shared {
   TCoeff tsCoef[3][16];
   uint8_t flags[72];
   Pel line[272];
+  int32_t entBits[128];              // ContextModel::m_entropyBits staged in LDS
+  uint8_t nextSt[256];               // [state*2 + bin] -> next state
+  // RDOQ per-call state, indexed by scan position
+  int32_t estB[HM_NUM_CTX * 2 + 2];  // bit cost of (context, bin) for the current estimator state
+  int32_t rqLvl[1024];               // |coef| * quant scale (lLevelDouble)
+  int32_t rqSigBits[1024];           // chosen significance bits (cost = lambda * bits)
+  uint32_t rqState[1024];            // packed decision-time state (contexts, Rice parameter, counters)
+  uint16_t rqPos[1024];              // raster position | sign << 15
+  uint16_t rqDec[1024];              // level at decision time
+  int16_t rqCur[1024];               // working / final level
+  double costCGSig[64];
+  uint8_t cgFlag[64];
   // uniform per-CTU context
   const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
   CtuMeta *cm; TCoeff *cc;
   int32_t ctuX, ctuY, ctuAddr;
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  unsigned long long prof[HM_PROF_N]; unsigned long long profCnt[HM_PROF_N];
+#endif
 };
 
 HM_DEV inline int hm_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -179,17 +212,16 @@ HM_DEV inline void cabac_init(Cabac *c, int qp)
   c->frac = 0;
   HM_SYNC();
 }
-HM_DEV inline void enc_bin(Cabac *c, int ctx, int bin)
+HM_DEV inline void enc_bin(const Shared *e, Cabac *c, int ctx, int bin)
 {
-  const uint8_t st = c->s[ctx];
-  c->frac += (uint64_t)HM_ENTROPY_BITS[st ^ bin];
-  c->s[ctx] = ((st & 1) == bin) ? HM_NEXT_MPS[st] : HM_NEXT_LPS[st];
+  const int st = c->s[ctx];
+  c->frac += (uint64_t)e->entBits[st ^ bin];
+  c->s[ctx] = e->nextSt[st * 2 + bin];
 }
 HM_DEV inline void enc_ep(Cabac *c, int n) { c->frac += (uint64_t)32768 * (uint64_t)n; }
-HM_DEV inline void enc_trm(Cabac *c, int bin) { c->frac += (uint64_t)HM_ENTROPY_BITS[126 ^ bin]; }
+HM_DEV inline void enc_trm(const Shared *e, Cabac *c, int bin) { c->frac += (uint64_t)e->entBits[126 ^ bin]; }
 HM_DEV inline void reset_bits(Cabac *c) { c->frac &= 32767; }           // TEncBinCoderCABAC.cpp:161
 HM_DEV inline uint32_t num_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
-HM_DEV inline int ebits(const Cabac *c, int ctx, int bin) { return HM_ENTROPY_BITS[c->s[ctx] ^ bin]; }
 
 HM_DEV inline double calc_rd_cost(const Shared *e, uint32_t bits, uint32_t dist)
 { // TComRdCost::calcRdCost, TComRdCost.cpp:56-123 (DF_DEFAULT, lossy)
@@ -278,6 +310,7 @@ HM_DEV inline uint32_t dist_sad(const Pel *org, int so, const Pel *cur, int sc, 
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline void load_tmat(Shared *e)
 {
+  HM_PAR_FOR(i, 128) { e->entBits[i] = HM_ENTROPY_BITS[i]; e->nextSt[i * 2 + (i & 1)] = HM_NEXT_MPS[i]; e->nextSt[i * 2 + ((i & 1) ^ 1)] = HM_NEXT_LPS[i]; }
   HM_PAR_FOR(i, 1024) {
     const int k = i >> 5, n = i & 31, m = (k * (2 * n + 1)) & 127;
     int v;
@@ -642,7 +675,7 @@ HM_DEV inline void last_ctx_params(int chroma, int n, int *off, int *shift)
 // (stride HM_TSTRIDE); levels go to dst (dense n*n, HBM).  The level decision is a serial chain over
 // the scan (running c1/c2/Rice state), evaluated wave-uniformly.
 // ------------------------------------------------------------------------------------------------
-HM_DEV inline int ic_rate(const Cabac *c, uint32_t absLevel, int ctxOne, int ctxAbs, int goRice, int c1Idx, int c2Idx)
+HM_DEV inline int ic_rate(const int32_t *estB, uint32_t absLevel, int ctxOne, int ctxAbs, int goRice, int c1Idx, int c2Idx)
 { // xGetICRate, TComTrQuant.cpp:2725-2800
   int rate = 32768;
   const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
@@ -654,141 +687,156 @@ HM_DEV inline int ic_rate(const Cabac *c, uint32_t absLevel, int ctxOne, int ctx
       while (symbol >= (1u << length)) symbol -= (1u << (length++));
       rate += (int)((3 + length + 1 - goRice + length) << 15);
     }
-    if (c1Idx < 8) { rate += ebits(c, C_ONE + ctxOne, 1); if (c2Idx < 1) rate += ebits(c, C_ABS + ctxAbs, 1); }
-  } else if (absLevel == 1) rate += ebits(c, C_ONE + ctxOne, 0);
-  else if (absLevel == 2) { rate += ebits(c, C_ONE + ctxOne, 1); rate += ebits(c, C_ABS + ctxAbs, 0); }
+    if (c1Idx < 8) { rate += estB[(C_ONE + ctxOne) * 2 + 1]; if (c2Idx < 1) rate += estB[(C_ABS + ctxAbs) * 2 + 1]; }
+  } else if (absLevel == 1) rate += estB[(C_ONE + ctxOne) * 2];
+  else if (absLevel == 2) { rate += estB[(C_ONE + ctxOne) * 2 + 1]; rate += estB[(C_ABS + ctxAbs) * 2]; }
   else rate = 0;
   return rate;
 }
 
+// Structure on the wavefront:
+//   1. lane-parallel pre-pass over the scan: |c|*scale, sign, raster position -> LDS; wave-max gives the
+//      last significant scan position, all-zero blocks leave here;
+//   2. the bit cost of every (context, bin) for the current estimator state is tabulated once (estB);
+//   3. the level decision is the reference's serial chain (running c1/c2/Rice state, double costs in the
+//      reference's operation order), evaluated wave-uniformly on LDS-resident data;
+//   4. sign-bit hiding re-derives its rate deltas from the packed decision-time state only for the
+//      coefficient groups that need a parity fix; the final levels go out lane-parallel.
 HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanType, int cbfCtx)
 {
   const Cabac *cb = &e->cur;
-  WorkSpace *ws = e->ws;
   const int chroma = comp != 0, log2n = hm_log2(n), bitDepth = e->P->bitDepth;
   const double lambda = chroma ? e->fb.lambdaC : e->fb.lambda;
   const int transformShift = 15 - bitDepth - log2n;
   const int qBits = 14 + e->fb.qpPer[chroma] + transformShift;
   const int quantCoef = HM_QUANT_SCALES[e->fb.qpRem[chroma]];
   const double errScale = e->fb.errScale[chroma][log2n - 2];
-  const int numCoef = n * n, wg = n >> 2, cgNum = numCoef >> 4;
+  const int numCoef = n * n, wg = n >> 2;
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
   const int firstCtx = first_sig_ctx(n, scanType, chroma);
   const int sigOff = C_SIG + (chroma ? 28 : 0);
   const int32_t *src = e->bufA;
-  double *costCoeff = ws->costCoeff, *costSig = ws->costSig, *costCoeff0 = ws->costCoeff0;
-  int32_t *rateIncUp = ws->rateIncUp, *rateIncDown = ws->rateIncDown, *sigRateDelta = ws->sigRateDelta, *deltaU = ws->deltaU;
-  double costCGSig[64]; uint8_t cgFlag[64];
-  HM_PAR_FOR(i, numCoef) { costCoeff[i] = 0; costSig[i] = 0; rateIncUp[i] = 0; rateIncDown[i] = 0; sigRateDelta[i] = 0; deltaU[i] = 0; }
+  const int32_t *estB = e->estB;
+  double *costCoeff = e->ws->costCoeff;
+  // ---- 1. pre-pass
+  int lastLocal = -1;
+  {
+    const int64_t cap = 2147483647LL - (1LL << (qBits - 1));
+    HM_PAR_FOR(sp, numCoef) {
+      const int blkPos = scan[sp];
+      const int32_t sc = src[(blkPos >> log2n) * HM_TSTRIDE + (blkPos & (n - 1))];
+      const int64_t tmpLevel = (int64_t)hm_abs(sc) * quantCoef;
+      const int32_t lvl = (int32_t)(tmpLevel < cap ? tmpLevel : cap);
+      e->rqLvl[sp] = lvl;
+      e->rqPos[sp] = (uint16_t)(blkPos | (sc < 0 ? 0x8000 : 0));
+      if (((lvl + (1 << (qBits - 1))) >> qBits) > 0 && sp > lastLocal) lastLocal = sp;
+      dst[sp] = 0;
+    }
+  }
+  const int lastScanPos = hm_wave_max_i(lastLocal);
   HM_SYNC();
-  for (int i = 0; i < 64; i++) { costCGSig[i] = 0; cgFlag[i] = 0; }
-  double blockUncodedCost = 0, baseCost = 0;
-  int cgLastScanPos = -1, lastScanPos = -1, ctxSet = 0, c1 = 1, c2 = 0, c1Idx = 0, c2Idx = 0, goRice = 0;
-  for (int cgScanPos = cgNum - 1; cgScanPos >= 0; cgScanPos--) {
+  if (lastScanPos < 0) return 0;
+  // ---- 2. bit-cost table of the current estimator state (TEncSbac::estBit, TEncSbac.cpp:1717-1956)
+  HM_PAR_FOR(i, HM_NUM_CTX * 2) e->estB[i] = e->entBits[cb->s[i >> 1] ^ (i & 1)];
+  HM_PAR_FOR(i, 64) { e->costCGSig[i] = 0; e->cgFlag[i] = 0; }
+  HM_SYNC();
+  uint8_t *cgFlag = e->cgFlag; double *costCGSig = e->costCGSig;
+  // ---- 3. serial decision chain
+  double blockUncodedCost = 0;
+  for (int sp = numCoef - 1; sp > lastScanPos; sp--) { const double err = (double)e->rqLvl[sp]; blockUncodedCost += err * err * errScale; }
+  double baseCost = blockUncodedCost;
+  const int cgLastScanPos = lastScanPos >> 4;
+  int ctxSet = ctx_set_index(chroma, lastScanPos >> 4, 0), c1 = 1, c2 = 0, c1Idx = 0, c2Idx = 0, goRice = 0;
+  for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
     const int cgBlkPos = scanCG[cgScanPos], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
     double sigCost = 0, sigCost0 = 0, codedLevelAndDist = 0, uncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
-    for (int posInCG = 15; posInCG >= 0; posInCG--) {
-      const int scanPos = cgScanPos * 16 + posInCG, blkPos = scan[scanPos];
-      const int32_t sc = src[(blkPos >> log2n) * HM_TSTRIDE + (blkPos & (n - 1))];
-      const int64_t tmpLevel = (int64_t)hm_abs(sc) * quantCoef;
-      const int64_t cap = 2147483647LL - (1LL << (qBits - 1));
-      const int32_t levelDouble = (int32_t)(tmpLevel < cap ? tmpLevel : cap);
+    for (int posInCG = (cgScanPos == cgLastScanPos ? (lastScanPos & 15) : 15); posInCG >= 0; posInCG--) {
+      const int scanPos = cgScanPos * 16 + posInCG, blkPos = e->rqPos[scanPos] & 0x3ff;
+      const int32_t levelDouble = e->rqLvl[scanPos];
       uint32_t maxAbsLevel = (uint32_t)((levelDouble + (1 << (qBits - 1))) >> qBits);
       if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
       const double err = (double)levelDouble;
       const double c0 = err * err * errScale;
-      costCoeff0[scanPos] = c0;
       blockUncodedCost += c0;
-      uint32_t level = maxAbsLevel;
-      double cCoeff = 0, cSig = 0;
-      if (maxAbsLevel > 0 && lastScanPos < 0) { lastScanPos = scanPos; ctxSet = ctx_set_index(chroma, scanPos >> 4, 0); cgLastScanPos = cgScanPos; }
-      if (lastScanPos >= 0) {
-        const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
-        int ctxSig = 0; const int isLast = (scanPos == lastScanPos);
-        level = 0;
-        if (!isLast) ctxSig = sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
-        { // xGetCodedLevel, TComTrQuant.cpp:2660-2715
-          double currCostSig = 0; int done = 0;
-          if (!isLast && maxAbsLevel < 3) {
-            cSig = lambda * (double)ebits(cb, ctxSig, 0);
-            cCoeff = c0 + cSig;
-            if (maxAbsLevel == 0) done = 1;
-          } else cCoeff = HM_MAX_DOUBLE;
-          if (!done) {
-            if (!isLast) currCostSig = lambda * (double)ebits(cb, ctxSig, 1);
-            const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
-            for (int al = (int)maxAbsLevel; al >= (int)minAbs; al--) {
-              const double de = (double)(levelDouble - (int32_t)((uint32_t)al << qBits));
-              const double dist = de * de * errScale;
-              const double rc = lambda * (double)ic_rate(cb, (uint32_t)al, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
-              double cc = dist + rc;
-              cc += currCostSig;
-              if (cc < cCoeff) { level = (uint32_t)al; cCoeff = cc; cSig = currCostSig; }
-            }
+      const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
+      const int isLast = (scanPos == lastScanPos);
+      int ctxSig = 0, sigBits = 0;
+      uint32_t level = 0;
+      double cCoeff;
+      if (!isLast) ctxSig = sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
+      e->rqState[scanPos] = (uint32_t)ctxSig | ((uint32_t)ctxOne << 8) | ((uint32_t)ctxSet << 13) | ((uint32_t)goRice << 16) | ((uint32_t)c1Idx << 19) | ((uint32_t)c2Idx << 24) | ((uint32_t)isLast << 29);
+      { // xGetCodedLevel, TComTrQuant.cpp:2660-2715
+        int currSigBits = 0; int done = 0;
+        if (!isLast && maxAbsLevel < 3) {
+          sigBits = estB[ctxSig * 2];
+          cCoeff = c0 + lambda * (double)sigBits;
+          if (maxAbsLevel == 0) done = 1;
+        } else cCoeff = HM_MAX_DOUBLE;
+        if (!done) {
+          double currCostSig = 0;
+          if (!isLast) { currSigBits = estB[ctxSig * 2 + 1]; currCostSig = lambda * (double)currSigBits; }
+          const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
+          for (int al = (int)maxAbsLevel; al >= (int)minAbs; al--) {
+            const double de = (double)(levelDouble - (int32_t)((uint32_t)al << qBits));
+            const double dist = de * de * errScale;
+            const double rc = lambda * (double)ic_rate(estB, (uint32_t)al, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
+            double cc = dist + rc;
+            cc += currCostSig;
+            if (cc < cCoeff) { level = (uint32_t)al; cCoeff = cc; sigBits = currSigBits; }
           }
         }
-        if (!isLast) sigRateDelta[blkPos] = ebits(cb, ctxSig, 1) - ebits(cb, ctxSig, 0);
-        deltaU[blkPos] = (int32_t)((levelDouble - (int32_t)(level << qBits)) >> (qBits - 8));
-        if (level > 0) {
-          const int rateNow = ic_rate(cb, level, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
-          rateIncUp[blkPos] = ic_rate(cb, level + 1, ctxOne, ctxAbs, goRice, c1Idx, c2Idx) - rateNow;
-          rateIncDown[blkPos] = ic_rate(cb, level - 1, ctxOne, ctxAbs, goRice, c1Idx, c2Idx) - rateNow;
-        } else rateIncUp[blkPos] = ebits(cb, C_ONE + ctxOne, 0);
-        baseCost += cCoeff;
-        const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
-        if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
-        if (level >= 1) c1Idx++;
-        if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
-        else if (c1 < 3 && c1 > 0 && level) c1++;
-        if ((scanPos % 16 == 0) && scanPos > 0) {
-          ctxSet = ctx_set_index(chroma, (scanPos - 1) >> 4, c1 == 0);
-          c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
-        }
-      } else baseCost += c0;
-      costCoeff[scanPos] = cCoeff; costSig[scanPos] = cSig;
-      dst[blkPos] = (TCoeff)level;
+      }
+      const double cSig = lambda * (double)sigBits;
+      baseCost += cCoeff;
+      const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
+      if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
+      if (level >= 1) c1Idx++;
+      if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
+      else if (c1 < 3 && c1 > 0 && level) c1++;
+      if ((scanPos % 16 == 0) && scanPos > 0) {
+        ctxSet = ctx_set_index(chroma, (scanPos - 1) >> 4, c1 == 0);
+        c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
+      }
+      e->rqSigBits[scanPos] = sigBits; e->rqDec[scanPos] = (uint16_t)level; e->rqCur[scanPos] = (int16_t)level;
       sigCost += cSig;
       if (posInCG == 0) sigCost0 = cSig;
       if (level) {
+        costCoeff[scanPos] = cCoeff;
         cgFlag[cgBlkPos] = 1;
         codedLevelAndDist += cCoeff - cSig;
         uncodedDist += c0;
         if (posInCG != 0) nnzBeforePos0++;
       }
     }
-    if (cgLastScanPos >= 0) {
-      if (cgScanPos) {
-        if (cgFlag[cgBlkPos] == 0) {
-          const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
-          const double r0 = lambda * (double)ebits(cb, ctx, 0);
-          baseCost += r0 - sigCost;
+    if (cgScanPos) {
+      if (cgFlag[cgBlkPos] == 0) {
+        const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
+        const double r0 = lambda * (double)estB[ctx * 2];
+        baseCost += r0 - sigCost;
+        costCGSig[cgScanPos] = r0;
+      } else if (cgScanPos < cgLastScanPos) {
+        if (nnzBeforePos0 == 0) { baseCost -= sigCost0; sigCost -= sigCost0; }
+        double costZeroCG = baseCost;
+        const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
+        const double r0 = lambda * (double)estB[ctx * 2], r1 = lambda * (double)estB[ctx * 2 + 1];
+        baseCost += r1;
+        costZeroCG += r0;
+        costCGSig[cgScanPos] = r1;
+        costZeroCG += uncodedDist; costZeroCG -= codedLevelAndDist; costZeroCG -= sigCost;
+        if (costZeroCG < baseCost) {
+          cgFlag[cgBlkPos] = 0; baseCost = costZeroCG;
           costCGSig[cgScanPos] = r0;
-        } else if (cgScanPos < cgLastScanPos) {
-          if (nnzBeforePos0 == 0) { baseCost -= sigCost0; sigCost -= sigCost0; }
-          double costZeroCG = baseCost;
-          const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
-          const double r0 = lambda * (double)ebits(cb, ctx, 0), r1 = lambda * (double)ebits(cb, ctx, 1);
-          baseCost += r1;
-          costZeroCG += r0;
-          costCGSig[cgScanPos] = r1;
-          costZeroCG += uncodedDist; costZeroCG -= codedLevelAndDist; costZeroCG -= sigCost;
-          if (costZeroCG < baseCost) {
-            cgFlag[cgBlkPos] = 0; baseCost = costZeroCG;
-            costCGSig[cgScanPos] = r0;
-            for (int posInCG = 15; posInCG >= 0; posInCG--) {
-              const int scanPos = cgScanPos * 16 + posInCG, blkPos = scan[scanPos];
-              if (dst[blkPos]) { dst[blkPos] = 0; costCoeff[scanPos] = costCoeff0[scanPos]; costSig[scanPos] = 0; }
-            }
+          for (int posInCG = 15; posInCG >= 0; posInCG--) {
+            const int scanPos = cgScanPos * 16 + posInCG;
+            if (e->rqCur[scanPos]) { e->rqCur[scanPos] = 0; e->rqSigBits[scanPos] = 0; }
           }
         }
-      } else cgFlag[cgBlkPos] = 1;
-    }
+      }
+    } else cgFlag[cgBlkPos] = 1;
   }
-  HM_SYNC();
-  if (lastScanPos < 0) return 0;
-  double bestCost = blockUncodedCost + lambda * (double)ebits(cb, C_QT_CBF + cbfCtx, 0);   // TComTrQuant.cpp:2310-2316
-  baseCost += lambda * (double)ebits(cb, C_QT_CBF + cbfCtx, 1);
+  double bestCost = blockUncodedCost + lambda * (double)estB[(C_QT_CBF + cbfCtx) * 2];   // TComTrQuant.cpp:2310-2316
+  baseCost += lambda * (double)estB[(C_QT_CBF + cbfCtx) * 2 + 1];
   int bestLastIdxP1 = 0, foundLast = 0;
   int lastOff, lastShift; last_ctx_params(chroma, n, &lastOff, &lastShift);
   const int cLX = C_LASTX + (chroma ? 15 : 0) + lastOff, cLY = C_LASTY + (chroma ? 15 : 0) + lastOff;
@@ -799,78 +847,96 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG;
       if (scanPos > lastScanPos) continue;
-      const int blkPos = scan[scanPos];
-      if (dst[blkPos]) {
+      const int cur = e->rqCur[scanPos];
+      const double cSig = lambda * (double)e->rqSigBits[scanPos];
+      if (cur) {
+        const int blkPos = e->rqPos[scanPos] & 0x3ff;
         int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
         if (scanType == SCAN_VER) { const int t = posX; posX = posY; posY = t; }
         // xGetRateLast, TComTrQuant.cpp:2815-2832 over estLastSignificantPositionBit, TEncSbac.cpp:1846-1892
         const int gx = HM_GROUP_IDX[posX], gy = HM_GROUP_IDX[posY], gmax = HM_GROUP_IDX[n - 1];
         int bx = 0, by = 0;
-        for (int c = 0; c < gx; c++) bx += ebits(cb, cLX + (c >> lastShift), 1);
-        if (gx < gmax) bx += ebits(cb, cLX + (gx >> lastShift), 0);
-        for (int c = 0; c < gy; c++) by += ebits(cb, cLY + (c >> lastShift), 1);
-        if (gy < gmax) by += ebits(cb, cLY + (gy >> lastShift), 0);
+        for (int c = 0; c < gx; c++) bx += estB[(cLX + (c >> lastShift)) * 2 + 1];
+        if (gx < gmax) bx += estB[(cLX + (gx >> lastShift)) * 2];
+        for (int c = 0; c < gy; c++) by += estB[(cLY + (c >> lastShift)) * 2 + 1];
+        if (gy < gmax) by += estB[(cLY + (gy >> lastShift)) * 2];
         double cst = (double)(bx + by);
         if (gx > 3) cst += 32768.0 * (double)((gx - 2) >> 1);
         if (gy > 3) cst += 32768.0 * (double)((gy - 2) >> 1);
         const double costLast = lambda * cst;
         const double t1 = baseCost + costLast;
-        const double totalCost = t1 - costSig[scanPos];
+        const double totalCost = t1 - cSig;
         if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
-        if (dst[blkPos] > 1) { foundLast = 1; break; }
-        baseCost -= costCoeff[scanPos]; baseCost += costCoeff0[scanPos];
-      } else baseCost -= costSig[scanPos];
+        if (cur > 1) { foundLast = 1; break; }
+        const double err = (double)e->rqLvl[scanPos];
+        baseCost -= costCoeff[scanPos]; baseCost += err * err * errScale;
+      } else baseCost -= cSig;
     }
   }
-  int absSum = 0;
-  for (int sp = 0; sp < bestLastIdxP1; sp++) {
-    const int bp = scan[sp]; const TCoeff lv = dst[bp]; absSum += lv;
-    const int32_t sc = src[(bp >> log2n) * HM_TSTRIDE + (bp & (n - 1))];
-    dst[bp] = sc < 0 ? -lv : lv;
+  // ---- levels with signs, truncated at the chosen last position (lane-parallel)
+  int absPart = 0;
+  HM_PAR_FOR(sp, lastScanPos + 1) {
+    int lv = sp < bestLastIdxP1 ? e->rqCur[sp] : 0;
+    absPart += lv;
+    e->rqCur[sp] = (int16_t)((e->rqPos[sp] & 0x8000) ? -lv : lv);
   }
-  for (int sp = bestLastIdxP1; sp <= lastScanPos; sp++) dst[scan[sp]] = 0;
-  // sign bit hiding, TComTrQuant.cpp:2380-2510
+  const int absSum = hm_wave_sum_i(absPart);
+  HM_SYNC();
+  // ---- 4. sign bit hiding, TComTrQuant.cpp:2380-2510
   if (absSum >= 2) {
     const int64_t rdFactor = e->fb.rdFactor[chroma];
     int lastCG = -1;
-    for (int subSet = (numCoef - 1) >> 4; subSet >= 0; subSet--) {
+    for (int subSet = cgLastScanPos; subSet >= 0; subSet--) {
       const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, k;
-      for (k = 15; k >= 0; --k) if (dst[scan[k + subPos]]) { lastNZ = k; break; }
-      for (k = 0; k < 16; k++) if (dst[scan[k + subPos]]) { firstNZ = k; break; }
-      for (k = firstNZ; k <= lastNZ; k++) sum += dst[scan[k + subPos]];
+      const int top = (subPos + 15 <= lastScanPos) ? 15 : (lastScanPos - subPos);
+      for (k = top; k >= 0; --k) if (e->rqCur[k + subPos]) { lastNZ = k; break; }
+      for (k = 0; k <= top; k++) if (e->rqCur[k + subPos]) { firstNZ = k; break; }
+      for (k = firstNZ; k <= lastNZ; k++) sum += e->rqCur[k + subPos];
       if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
       if (lastNZ - firstNZ >= 4) {
-        const uint32_t signbit = dst[scan[subPos + firstNZ]] > 0 ? 0 : 1;
+        const uint32_t signbit = e->rqCur[subPos + firstNZ] > 0 ? 0 : 1;
         if (signbit != (uint32_t)(sum & 1)) {
           const int64_t I64MAX = 0x7fffffffffffffffLL;
-          int64_t minCostInc = I64MAX, curCost = I64MAX; int minPos = -1, finalChange = 0, curChange = 0;
+          int64_t minCostInc = I64MAX, curCost = I64MAX; int minSp = -1, finalChange = 0, curChange = 0;
           for (k = (lastCG == 1 ? lastNZ : 15); k >= 0; --k) {
-            const int bp = scan[k + subPos];
-            const TCoeff dv = dst[bp];
+            const int sp = k + subPos;
+            // rate deltas of this position from its decision-time state
+            const uint32_t stt = e->rqState[sp];
+            const int ctxSig = (int)(stt & 0xff), ctxOne = (int)((stt >> 8) & 31), ctxSetD = (int)((stt >> 13) & 7), goR = (int)((stt >> 16) & 7);
+            const int c1I = (int)((stt >> 19) & 31), c2I = (int)((stt >> 24) & 31), wasLast = (int)((stt >> 29) & 1);
+            const uint32_t dec = e->rqDec[sp];
+            const int32_t lvlD = e->rqLvl[sp];
+            const int32_t deltaU = (int32_t)((lvlD - (int32_t)(dec << qBits)) >> (qBits - 8));
+            const int sigRateDelta = wasLast ? 0 : (estB[ctxSig * 2 + 1] - estB[ctxSig * 2]);
+            int rateIncUp, rateIncDown = 0;
+            if (dec > 0) {
+              const int rateNow = ic_rate(estB, dec, ctxOne, ctxSetD, goR, c1I, c2I);
+              rateIncUp = ic_rate(estB, dec + 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
+              rateIncDown = ic_rate(estB, dec - 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
+            } else rateIncUp = estB[(C_ONE + ctxOne) * 2];
+            const int dv = e->rqCur[sp];
             if (dv != 0) {
-              const int64_t costUp = rdFactor * (-deltaU[bp]) + rateIncUp[bp];
-              int64_t costDown = rdFactor * (deltaU[bp]) + rateIncDown[bp] - ((hm_abs(dv) == 1) ? sigRateDelta[bp] : 0);
+              const int64_t costUp = rdFactor * (-deltaU) + rateIncUp;
+              int64_t costDown = rdFactor * (deltaU) + rateIncDown - ((hm_abs(dv) == 1) ? sigRateDelta : 0);
               if (lastCG == 1 && lastNZ == k && hm_abs(dv) == 1) costDown -= (4 << 15);
               if (costUp < costDown) { curCost = costUp; curChange = 1; }
               else { curChange = -1; if (k == firstNZ && hm_abs(dv) == 1) curCost = I64MAX; else curCost = costDown; }
             } else {
-              curCost = rdFactor * (-(hm_abs(deltaU[bp]))) + (1 << 15) + rateIncUp[bp] + sigRateDelta[bp];
+              curCost = rdFactor * (-(hm_abs(deltaU))) + (1 << 15) + rateIncUp + sigRateDelta;
               curChange = 1;
-              if (k < firstNZ) {
-                const int32_t sc = src[(bp >> log2n) * HM_TSTRIDE + (bp & (n - 1))];
-                const uint32_t thissign = sc >= 0 ? 0 : 1; if (thissign != signbit) curCost = I64MAX;
-              }
+              if (k < firstNZ) { const uint32_t thissign = (e->rqPos[sp] & 0x8000) ? 1 : 0; if (thissign != signbit) curCost = I64MAX; }
             }
-            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = bp; }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minSp = sp; }
           }
-          if (dst[minPos] == 32767 || dst[minPos] == -32768) finalChange = -1;
-          const int32_t sc = src[(minPos >> log2n) * HM_TSTRIDE + (minPos & (n - 1))];
-          if (sc >= 0) dst[minPos] += finalChange; else dst[minPos] -= finalChange;
+          if (e->rqCur[minSp] == 32767 || e->rqCur[minSp] == -32768) finalChange = -1;
+          if (!(e->rqPos[minSp] & 0x8000)) e->rqCur[minSp] = (int16_t)(e->rqCur[minSp] + finalChange); else e->rqCur[minSp] = (int16_t)(e->rqCur[minSp] - finalChange);
         }
       }
       if (lastCG == 1) lastCG = 0;
     }
   }
+  HM_SYNC();
+  HM_PAR_FOR(sp, lastScanPos + 1) dst[e->rqPos[sp] & 0x3ff] = e->rqCur[sp];
   HM_SYNC();
   return absSum;
 }
@@ -882,7 +948,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
 HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
 {
   const int chroma = comp != 0, log2n = hm_log2(n), wg = n >> 2;
-  if (n == 4) enc_bin(c, C_TSKIP + chroma, tskipFlag);           // codeTransformSkipFlags, TEncSbac.cpp:988
+  if (n == 4) enc_bin(e, c, C_TSKIP + chroma, tskipFlag);           // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
   int cnt = 0;
   HM_PAR_FOR(i, n * n) cnt += coef[i] != 0;
@@ -901,10 +967,10 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
     int off, shift; last_ctx_params(chroma, n, &off, &shift);
     const int bxc = C_LASTX + (chroma ? 15 : 0) + off, byc = C_LASTY + (chroma ? 15 : 0) + off;
     int k;
-    for (k = 0; k < gx; k++) enc_bin(c, bxc + (k >> shift), 1);
-    if (gx < gmax) enc_bin(c, bxc + (k >> shift), 0);
-    for (k = 0; k < gy; k++) enc_bin(c, byc + (k >> shift), 1);
-    if (gy < gmax) enc_bin(c, byc + (k >> shift), 0);
+    for (k = 0; k < gx; k++) enc_bin(e, c, bxc + (k >> shift), 1);
+    if (gx < gmax) enc_bin(e, c, bxc + (k >> shift), 0);
+    for (k = 0; k < gy; k++) enc_bin(e, c, byc + (k >> shift), 1);
+    if (gy < gmax) enc_bin(e, c, byc + (k >> shift), 0);
     if (gx > 3) enc_ep(c, (gx - 2) >> 1);
     if (gy > 3) enc_ep(c, (gy - 2) >> 1);
   }
@@ -917,13 +983,13 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
     if (scanPosSig == scanPosLast) { absCoeff[0] = hm_abs(coef[posLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
     const int cgBlkPos = scanCG[subSet], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
     if (subSet == lastScanSet || subSet == 0) cgFlag[cgBlkPos] = 1;
-    else enc_bin(c, C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg), cgFlag[cgBlkPos] != 0);
+    else enc_bin(e, c, C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg), cgFlag[cgBlkPos] != 0);
     if (cgFlag[cgBlkPos]) {
       const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
       for (; scanPosSig >= subPos; scanPosSig--) {
         const int blkPos = scan[scanPosSig]; const TCoeff cv = coef[blkPos]; const int sig = cv != 0;
         if (scanPosSig > subPos || subSet == 0 || numNonZero)
-          enc_bin(c, sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma), sig);
+          enc_bin(e, c, sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma), sig);
         if (sig) { absCoeff[numNonZero] = hm_abs(cv); numNonZero++; if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
     } else scanPosSig = subPos - 1;
@@ -934,11 +1000,11 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
       const int numC1 = numNonZero < 8 ? numNonZero : 8; int firstC2 = -1;
       for (int idx = 0; idx < numC1; idx++) {
         const int sym = absCoeff[idx] > 1;
-        enc_bin(c, C_ONE + 4 * ctxSet + (int)c1, sym);
+        enc_bin(e, c, C_ONE + 4 * ctxSet + (int)c1, sym);
         if (sym) { c1 = 0; if (firstC2 == -1) firstC2 = idx; else escape = 1; }
         else if (c1 < 3 && c1 > 0) c1++;
       }
-      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; enc_bin(c, C_ABS + ctxSet, sym); if (sym) escape = 1; }
+      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; enc_bin(e, c, C_ABS + ctxSet, sym); if (sym) escape = 1; }
       escape = escape || (numNonZero > 8);
       enc_ep(c, signHidden ? numNonZero - 1 : numNonZero);
       int firstCoeff2 = 1;
@@ -969,7 +1035,7 @@ HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
     const int dir = m->dirL[z + partOffset * j];
     intra_dir_predictor(e, z + partOffset * j, preds);
     for (int i = 0; i < 3; i++) if (dir == preds[i]) predIdx[j] = i;
-    enc_bin(c, C_INTRA_LUMA, predIdx[j] != -1);
+    enc_bin(e, c, C_INTRA_LUMA, predIdx[j] != -1);
   }
   for (int j = 0; j < partNum; j++) {
     if (predIdx[j] != -1) enc_ep(c, predIdx[j] ? 2 : 1);
@@ -979,8 +1045,8 @@ HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
 // TEncSbac::codeIntraDirChroma, TEncSbac.cpp:692-718
 HM_DEV inline void code_intra_dir_chroma(Shared *e, Cabac *c, int z)
 {
-  if (e->cm->dirC[z] == DM_CHROMA_IDX) enc_bin(c, C_CHROMA_PRED, 0);
-  else { enc_bin(c, C_CHROMA_PRED, 1); enc_ep(c, 2); }
+  if (e->cm->dirC[z] == DM_CHROMA_IDX) enc_bin(e, c, C_CHROMA_PRED, 0);
+  else { enc_bin(e, c, C_CHROMA_PRED, 1); enc_ep(c, 2); }
 }
 // TEncSbac::codeQtCbf, TEncSbac.cpp:911-960 (square TUs)
 HM_DEV inline void code_qt_cbf(Shared *e, Cabac *c, const TU *t, int comp, int lowestLevel)
@@ -990,7 +1056,7 @@ HM_DEV inline void code_qt_cbf(Shared *e, Cabac *c, const TU *t, int comp, int l
   const int width = comp ? (1 << (t->log2 - 1)) : (1 << t->log2);
   const int canQuadSplit = width >= 8;
   const int lowestTUDepth = t->trDepth + ((!lowestLevel && !canQuadSplit) ? 1 : 0);
-  enc_bin(c, C_QT_CBF + (comp ? 5 : 0) + ctx, (e->cm->cbf[comp][z] >> lowestTUDepth) & 1);
+  enc_bin(e, c, C_QT_CBF + (comp ? 5 : 0) + ctx, (e->cm->cbf[comp][z] >> lowestTUDepth) & 1);
 }
 
 HM_DEV inline int tr_min_size_in_cu(int cuLog2, int nxn)
@@ -1025,7 +1091,7 @@ HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int b
     const int z = t->cuZ + t->relZ;
     const int subdiv = m->tr[z] > t->trDepth;
     if (w.next[w.sp] < 0) { // first visit
-      if (bLuma && codes_subdiv_flag(m, t)) enc_bin(&e->cur, C_SUBDIV + (5 - t->log2), subdiv);
+      if (bLuma && codes_subdiv_flag(m, t)) enc_bin(e, &e->cur, C_SUBDIV + (5 - t->log2), subdiv);
       if (bChroma)
         for (int comp = 1; comp < 3; comp++)
           if (t->cCodeAll && (t->trDepth == 0 || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)))
@@ -1068,7 +1134,7 @@ HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChro
 {
   const CtuMeta *m = e->cm; const int relZ = t->relZ;
   if (bLuma) {
-    if (relZ == 0 && t->cuDepth == 3) enc_bin(&e->cur, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
+    if (relZ == 0 && t->cuDepth == 3) enc_bin(e, &e->cur, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
     if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, &e->cur, t->cuZ, 0); }
     else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ % q) == 0) code_intra_dir_luma(e, &e->cur, t->cuZ + relZ, 0); }
   }
@@ -1077,11 +1143,13 @@ HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChro
 // xGetIntraBitsQT, TEncSearch.cpp:1038-1060
 HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU *t, int bLuma, int bChroma)
 {
+  HM_PROF_BEGIN(e, PR_BITS);
   reset_bits(&e->cur);
   enc_intra_header(e, t, bLuma, bChroma);
   enc_subdiv_cbf_qt(e, t, bLuma, bChroma);
   if (bLuma) enc_coeff_qt(e, t, 0);
   if (bChroma) { enc_coeff_qt(e, t, 1); enc_coeff_qt(e, t, 2); }
+  HM_PROF_END(e, PR_BITS);
   return num_bits(&e->cur);
 }
 
@@ -1109,8 +1177,8 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int co
   if (save1load2 != 2) {
     const int filt = use_filtered_refs(comp, mode, n);
     const int r = e->tab->z2r[z];
-    init_adi_pattern(e, comp, e->ctuX * st + bx, e->ctuY * st + by, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), comp ? n / 2 : n / 4, filt);
-    pred_intra(e, comp, mode, n, filt, pred, st);
+    { HM_PROF_BEGIN(e, PR_ADI); init_adi_pattern(e, comp, e->ctuX * st + bx, e->ctuY * st + by, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), comp ? n / 2 : n / 4, filt); HM_PROF_END(e, PR_ADI); }
+    { HM_PROF_BEGIN(e, PR_PRED); pred_intra(e, comp, mode, n, filt, pred, st); HM_PROF_END(e, PR_PRED); }
     if (save1load2 == 1) { HM_PAR_FOR(i, 16) e->tsPred[comp][i] = pred[(i >> 2) * st + (i & 3)]; HM_SYNC(); }
   } else { HM_PAR_FOR(i, 16) pred[(i >> 2) * st + (i & 3)] = e->tsPred[comp][i]; HM_SYNC(); }
   if (comp == 0) par_set8(m->tr + z, t->trDepth, parts);             // setTrIdxSubParts, TEncSearch.cpp:1229
@@ -1123,10 +1191,13 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int co
     e->bufA[y * HM_TSTRIDE + x] = tskip ? (r << tshift) : r;         // xTransformSkip, TComTrQuant.cpp:1874
   }
   HM_SYNC();
-  if (!tskip) fwd_transform(e, n, comp == 0 && n == 4, bitDepth);      // TComTrQuant::xT, :1805
+  { HM_PROF_BEGIN(e, PR_FWD); if (!tskip) fwd_transform(e, n, comp == 0 && n == 4, bitDepth); HM_PROF_END(e, PR_FWD); }      // TComTrQuant::xT, :1805
   const int cbfCtx = comp ? 5 + t->trDepth : (t->trDepth == 0 ? 1 : 0);
+  HM_PROF_BEGIN(e, PR_RDOQ);
   const int absSum = rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx);
+  HM_PROF_END(e, PR_RDOQ);
   par_set8(m->cbf[comp] + z, (absSum > 0 ? 1 : 0) << t->trDepth, parts);   // setCbfPartRange, TComTrQuant.cpp:1419
+  HM_PROF_BEGIN(e, PR_INV);
   if (absSum > 0) { // invTransformNxN, TComTrQuant.cpp:1423-1545; xDeQuant (flat), :1276-1312
     const int rightShift = 6 - (tshift + e->fb.qpPer[comp != 0]);
     const int scale = HM_INV_QUANT_SCALES[e->fb.qpRem[comp != 0]];
@@ -1152,6 +1223,7 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int co
     HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); coef[i] = 0; resi[y * st + x] = 0; }
   }
   HM_SYNC();
+  HM_PROF_END(e, PR_INV);
   const int maxv = (1 << bitDepth) - 1, shiftSse = (bitDepth - 8) << 1;
   uint32_t sse = 0;
   HM_PAR_FOR(i, n * n) { // reconstruction + SSE fused (TEncSearch.cpp:1338-1356)
@@ -1321,6 +1393,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       // xModeBitsIntra (TEncSearch.cpp:5456-5478) depends only on whether the mode is an MPM and which
       const uint64_t frac0 = e->slot[cuDepth][CI_CURR_BEST].frac & 32767;
       const uint8_t st0 = e->slot[cuDepth][CI_CURR_BEST].s[C_INTRA_LUMA];
+      HM_PROF_BEGIN(e, PR_SATD35);
       for (int mode = 0; mode < 35; mode++) {
         pred_intra(e, 0, mode, n, use_filtered_refs(0, mode, n), pred, 64);
         const uint32_t sad = dist_hads(org, ps, pred, 64, n, bitDepth);
@@ -1338,6 +1411,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
           rdModeList[numModesForFullRD - shift] = mode; candCost[numModesForFullRD - shift] = cost;
         }
       }
+      HM_PROF_END(e, PR_SATD35);
       for (int j = 0; j < numMpm; j++) { // numCand = *piMode quirk, TEncSearch.cpp:2415-2420
         int included = 0;
         for (int i = 0; i < numModesForFullRD; i++) included |= (preds[j] == rdModeList[i]);
@@ -1496,7 +1570,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
 HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDepth)
 { // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
   const CtuMeta *m = e->cm;
-  if (cuDepth == 3) enc_bin(c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
+  if (cuDepth == 3) enc_bin(e, c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
   code_intra_dir_luma(e, c, cuZ, 1);
   code_intra_dir_chroma(e, c, cuZ);
   const TU root = tu_root(e, cuZ, cuDepth);
@@ -1506,7 +1580,7 @@ HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDep
     const int z = t->cuZ + t->relZ;
     const int subdiv = m->tr[z] > t->trDepth;
     if (w.next[w.sp] < 0) {
-      if (codes_subdiv_flag(m, t)) enc_bin(c, C_SUBDIV + (5 - t->log2), subdiv);
+      if (codes_subdiv_flag(m, t)) enc_bin(e, c, C_SUBDIV + (5 - t->log2), subdiv);
       const int first = t->trDepth == 0;
       for (int comp = 1; comp < 3; comp++)
         if (first || t->cCodeAll)
@@ -1556,6 +1630,7 @@ HM_DEV inline void meta_copy_range(CtuMeta *d, const CtuMeta *s, int z0, int par
 }
 HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
 {
+  HM_PROF_BEGIN(e, PR_SAVE);
   Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
   meta_copy_range(&b->m, e->cm, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) b->coef[cuZ * 16 + i] = e->cc[cuZ * 16 + i];
@@ -1567,6 +1642,7 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
     b->reco[4096 + o] = e->ws->reco[4096 + o]; b->reco[5120 + o] = e->ws->reco[5120 + o];
   }
   HM_SYNC();
+  HM_PROF_END(e, PR_SAVE);
 }
 HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
 { // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
@@ -1593,14 +1669,16 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
   init_est_data(e, cuZ, cuDepth);
   HM_PAR_FOR(i, parts) { m->part[cuZ + i] = (uint8_t)partSize; m->pred[cuZ + i] = MODE_INTRA; }
   HM_SYNC();
+  HM_PROF_BEGIN(e, PR_LUMA);
   uint32_t d = est_intra_pred_qt(e, cuZ, cuDepth);
+  HM_PROF_END(e, PR_LUMA);
   { // luma reconstruction of the CU into the picture, TEncCu.cpp:1608
     const int r = e->tab->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, ps = e->P->stride[0];
     par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + y) * ps + e->ctuX * 64 + x, ps, e->ws->reco + y * 64 + x, 64, n);
   }
-  d += est_intra_pred_chroma_qt(e, cuZ, cuDepth);
+  { HM_PROF_BEGIN(e, PR_CHROMA); d += est_intra_pred_chroma_qt(e, cuZ, cuDepth); HM_PROF_END(e, PR_CHROMA); }
   reset_bits(&e->cur);
-  encode_cu_syntax(e, &e->cur, cuZ, cuDepth);
+  { HM_PROF_BEGIN(e, PR_ENCCU); encode_cu_syntax(e, &e->cur, cuZ, cuDepth); HM_PROF_END(e, PR_ENCCU); }
   cabac_copy(&e->slot[cuDepth][CI_TEMP_BEST], &e->cur);
   *bits = num_bits(&e->cur); *dist = d;
   *cost = calc_rd_cost(e, *bits, *dist);
@@ -1633,7 +1711,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e, double *outCost, uint32_t *outBi
         }
         // split flag of the unsplit candidate, TEncCu.cpp:859-863 (coded on the go-on coder as it stands)
         reset_bits(&e->cur);
-        if (cuDepth != 3) enc_bin(&e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
+        if (cuDepth != 3) enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
         f->bestBits += num_bits(&e->cur);
         f->bestCost = calc_rd_cost(e, f->bestBits, f->bestDist);
       }
@@ -1659,7 +1737,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e, double *outCost, uint32_t *outBi
       }
       if (!f->boundary) {
         reset_bits(&e->cur);
-        enc_bin(&e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), m->depth[cuZ] > cuDepth);
+        enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), m->depth[cuZ] > cuDepth);
         f->splitBits += num_bits(&e->cur);
       }
       f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
@@ -1689,12 +1767,12 @@ HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
     const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
     const int inside = (lx + size - 1 < e->P->width) && (ty + size - 1 < e->P->height);
     if (stackNext[sp] < 0) {
-      if (inside && depth != 3) enc_bin(c, C_SPLIT + ctx_split_flag(e, z, depth), m->depth[z] > depth);
+      if (inside && depth != 3) enc_bin(e, c, C_SPLIT + ctx_split_flag(e, z, depth), m->depth[z] > depth);
       if (!((depth < m->depth[z] && depth < 3) || !inside)) {
         encode_cu_syntax(e, c, z, depth);
         // finishCU, TEncCu.cpp:1130-1147
         const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->P->width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->P->height);
-        if (lastX && lastY && !lastCtuOfSlice) enc_trm(c, 0);
+        if (lastX && lastY && !lastCtuOfSlice) enc_trm(e, c, 0);
         sp--; continue;
       }
       stackNext[sp] = 0;
@@ -1717,6 +1795,10 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
   e->cm = e->fb.meta + e->ctuAddr; e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
   HM_SYNC();
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  for (int i = 0; i < HM_PROF_N; i++) { e->prof[i] = 0; e->profCnt[i] = 0; }
+#endif
+  HM_PROF_BEGIN(e, PR_TOTAL);
   load_tmat(e);
   const int a = e->ctuAddr, numCtus = P->wCtu * P->hCtu;
   { // TComDataCU::initCtu, TComDataCU.cpp:357-470
@@ -1746,4 +1828,8 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   reset_bits(cb0);
   encode_ctu(e, cb0, a == numCtus - 1);
   cabac_copy(e->fb.endState + a, cb0);
+  HM_PROF_END(e, PR_TOTAL);
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  if (hm_lane() == 0 && P->prof) for (int i = 0; i < HM_PROF_N; i++) { atomicAdd(P->prof + i, e->prof[i]); atomicAdd(P->prof + HM_PROF_N + i, e->profCnt[i]); }
+#endif
 }

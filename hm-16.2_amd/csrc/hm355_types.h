@@ -75,6 +75,7 @@ struct Params {
   const Tables *tab;
   WorkSpace *ws;
   FrameBuf *frames;
+  unsigned long long *prof;          // diagnostic builds only (HM355_PROFILE), else NULL
 };
 
 struct WorkItem { int32_t frame, ctuX, ctuY, pad; };
