@@ -158,7 +158,10 @@ struct Shared {
   int32_t estB[HM_NUM_CTX * 2 + 2];  // bit cost of (context, bin) for the current estimator state
   int32_t rqLvl[1024];               // |coef| * quant scale (lLevelDouble)
   int32_t rqSigBits[1024];           // chosen significance bits (cost = lambda * bits)
-  uint32_t rqState[1024];            // packed decision-time state (contexts, Rice parameter, counters)
+  uint8_t rqCtxSig[1024];            // significance context of each scan position
+  uint8_t cgCtxSet[64];              // context set each coefficient group started with
+  double cgC0[16], cgCoef[16], cgSigC[16];   // per-position costs of the current group (zero-level hypothesis)
+  uint16_t cgMax[16];
   uint16_t rqPos[1024];              // raster position | sign << 15
   uint16_t rqDec[1024];              // level at decision time
   int16_t rqCur[1024];               // working / final level
@@ -741,7 +744,9 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   HM_PAR_FOR(i, 64) { e->costCGSig[i] = 0; e->cgFlag[i] = 0; }
   HM_SYNC();
   uint8_t *cgFlag = e->cgFlag; double *costCGSig = e->costCGSig;
-  // ---- 3. serial decision chain
+  // ---- 3. decision chain.  Per coefficient group: the 16 positions are costed lane-parallel under the
+  //         zero-level hypothesis (state independent); the serial part only decides the positions whose
+  //         quantised magnitude is non-zero and adds the costs up in the reference's order.
   double blockUncodedCost = 0;
   for (int sp = numCoef - 1; sp > lastScanPos; sp--) { const double err = (double)e->rqLvl[sp]; blockUncodedCost += err * err * errScale; }
   double baseCost = blockUncodedCost;
@@ -751,29 +756,38 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     const int cgBlkPos = scanCG[cgScanPos], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
     double sigCost = 0, sigCost0 = 0, codedLevelAndDist = 0, uncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
-    for (int posInCG = (cgScanPos == cgLastScanPos ? (lastScanPos & 15) : 15); posInCG >= 0; posInCG--) {
-      const int scanPos = cgScanPos * 16 + posInCG, blkPos = e->rqPos[scanPos] & 0x3ff;
-      const int32_t levelDouble = e->rqLvl[scanPos];
-      uint32_t maxAbsLevel = (uint32_t)((levelDouble + (1 << (qBits - 1))) >> qBits);
-      if (maxAbsLevel > 32767u) maxAbsLevel = 32767u;
-      const double err = (double)levelDouble;
-      const double c0 = err * err * errScale;
+    const int startPos = (cgScanPos == cgLastScanPos ? (lastScanPos & 15) : 15);
+    e->cgCtxSet[cgScanPos] = (uint8_t)ctxSet;
+    HM_PAR_FOR(k, 16) {
+      const int scanPos = cgScanPos * 16 + k, blkPos = e->rqPos[scanPos] & 0x3ff;
+      const int32_t lvl = e->rqLvl[scanPos];
+      uint32_t mx = (uint32_t)((lvl + (1 << (qBits - 1))) >> qBits); if (mx > 32767u) mx = 32767u;
+      const double err = (double)lvl, c0 = err * err * errScale;
+      const int ctxSig = (scanPos == lastScanPos) ? 0 : sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
+      const int b0 = estB[ctxSig * 2];
+      const double s0 = lambda * (double)b0;
+      e->cgMax[k] = (uint16_t)mx; e->cgC0[k] = c0; e->cgSigC[k] = s0; e->cgCoef[k] = c0 + s0;
+      e->rqCtxSig[scanPos] = (uint8_t)ctxSig; e->rqSigBits[scanPos] = b0; e->rqDec[scanPos] = 0; e->rqCur[scanPos] = 0;
+    }
+    HM_SYNC();
+    for (int posInCG = startPos; posInCG >= 0; posInCG--) {
+      const int scanPos = cgScanPos * 16 + posInCG;
+      const uint32_t maxAbsLevel = e->cgMax[posInCG];
+      const double c0 = e->cgC0[posInCG];
       blockUncodedCost += c0;
-      const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
-      const int isLast = (scanPos == lastScanPos);
-      int ctxSig = 0, sigBits = 0;
       uint32_t level = 0;
-      double cCoeff;
-      if (!isLast) ctxSig = sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
-      e->rqState[scanPos] = (uint32_t)ctxSig | ((uint32_t)ctxOne << 8) | ((uint32_t)ctxSet << 13) | ((uint32_t)goRice << 16) | ((uint32_t)c1Idx << 19) | ((uint32_t)c2Idx << 24) | ((uint32_t)isLast << 29);
-      { // xGetCodedLevel, TComTrQuant.cpp:2660-2715
-        int currSigBits = 0; int done = 0;
-        if (!isLast && maxAbsLevel < 3) {
-          sigBits = estB[ctxSig * 2];
-          cCoeff = c0 + lambda * (double)sigBits;
-          if (maxAbsLevel == 0) done = 1;
-        } else cCoeff = HM_MAX_DOUBLE;
-        if (!done) {
+      double cCoeff, cSig;
+      if (maxAbsLevel == 0) { cCoeff = e->cgCoef[posInCG]; cSig = e->cgSigC[posInCG]; }
+      else {
+        const int32_t levelDouble = e->rqLvl[scanPos];
+        const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
+        const int isLast = (scanPos == lastScanPos);
+        const int ctxSig = e->rqCtxSig[scanPos];
+        int sigBits = 0;
+        { // xGetCodedLevel, TComTrQuant.cpp:2660-2715
+          int currSigBits = 0;
+          if (!isLast && maxAbsLevel < 3) { sigBits = estB[ctxSig * 2]; cCoeff = c0 + lambda * (double)sigBits; }
+          else cCoeff = HM_MAX_DOUBLE;
           double currCostSig = 0;
           if (!isLast) { currSigBits = estB[ctxSig * 2 + 1]; currCostSig = lambda * (double)currSigBits; }
           const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
@@ -786,19 +800,19 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
             if (cc < cCoeff) { level = (uint32_t)al; cCoeff = cc; sigBits = currSigBits; }
           }
         }
+        cSig = lambda * (double)sigBits;
+        e->rqSigBits[scanPos] = sigBits; e->rqDec[scanPos] = (uint16_t)level; e->rqCur[scanPos] = (int16_t)level;
+        const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
+        if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
+        if (level >= 1) c1Idx++;
+        if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
+        else if (c1 < 3 && c1 > 0 && level) c1++;
       }
-      const double cSig = lambda * (double)sigBits;
       baseCost += cCoeff;
-      const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
-      if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
-      if (level >= 1) c1Idx++;
-      if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
-      else if (c1 < 3 && c1 > 0 && level) c1++;
-      if ((scanPos % 16 == 0) && scanPos > 0) {
+      if (posInCG == 0 && scanPos > 0) {
         ctxSet = ctx_set_index(chroma, (scanPos - 1) >> 4, c1 == 0);
         c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
       }
-      e->rqSigBits[scanPos] = sigBits; e->rqDec[scanPos] = (uint16_t)level; e->rqCur[scanPos] = (int16_t)level;
       sigCost += cSig;
       if (posInCG == 0) sigCost0 = cSig;
       if (level) {
@@ -827,13 +841,11 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
         if (costZeroCG < baseCost) {
           cgFlag[cgBlkPos] = 0; baseCost = costZeroCG;
           costCGSig[cgScanPos] = r0;
-          for (int posInCG = 15; posInCG >= 0; posInCG--) {
-            const int scanPos = cgScanPos * 16 + posInCG;
-            if (e->rqCur[scanPos]) { e->rqCur[scanPos] = 0; e->rqSigBits[scanPos] = 0; }
-          }
+          HM_PAR_FOR(k, 16) { const int scanPos = cgScanPos * 16 + k; if (e->rqCur[scanPos]) { e->rqCur[scanPos] = 0; e->rqSigBits[scanPos] = 0; } }
         }
       }
     } else cgFlag[cgBlkPos] = 1;
+    HM_SYNC();
   }
   double bestCost = blockUncodedCost + lambda * (double)estB[(C_QT_CBF + cbfCtx) * 2];   // TComTrQuant.cpp:2310-2316
   baseCost += lambda * (double)estB[(C_QT_CBF + cbfCtx) * 2 + 1];
@@ -898,13 +910,22 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
         if (signbit != (uint32_t)(sum & 1)) {
           const int64_t I64MAX = 0x7fffffffffffffffLL;
           int64_t minCostInc = I64MAX, curCost = I64MAX; int minSp = -1, finalChange = 0, curChange = 0;
-          for (k = (lastCG == 1 ? lastNZ : 15); k >= 0; --k) {
+          // re-walk the group's decision-time state (contexts, Rice parameter, flag counters)
+          int wC1 = 1, wC1Idx = 0, wC2Idx = 0, wGoR = 0; const int wSet = e->cgCtxSet[subSet];
+          const int kStart = (lastCG == 1 ? lastNZ : 15);
+          for (k = top; k >= 0; --k) {
             const int sp = k + subPos;
-            // rate deltas of this position from its decision-time state
-            const uint32_t stt = e->rqState[sp];
-            const int ctxSig = (int)(stt & 0xff), ctxOne = (int)((stt >> 8) & 31), ctxSetD = (int)((stt >> 13) & 7), goR = (int)((stt >> 16) & 7);
-            const int c1I = (int)((stt >> 19) & 31), c2I = (int)((stt >> 24) & 31), wasLast = (int)((stt >> 29) & 1);
             const uint32_t dec = e->rqDec[sp];
+            const int ctxOne = 4 * wSet + wC1, ctxSetD = wSet, goR = wGoR, c1I = wC1Idx, c2I = wC2Idx;
+            { // advance the walk past this position (same updates as the decision chain)
+              const uint32_t baseLevel = (wC1Idx < 8) ? (2 + (wC2Idx < 1)) : 1;
+              if (dec >= baseLevel && dec > (3u << wGoR)) wGoR = wGoR + 1 < 4 ? wGoR + 1 : 4;
+              if (dec >= 1) wC1Idx++;
+              if (dec > 1) { wC1 = 0; wC2Idx++; }
+              else if (wC1 < 3 && wC1 > 0 && dec) wC1++;
+            }
+            if (k > kStart) continue;
+            const int ctxSig = e->rqCtxSig[sp], wasLast = (sp == lastScanPos);
             const int32_t lvlD = e->rqLvl[sp];
             const int32_t deltaU = (int32_t)((lvlD - (int32_t)(dec << qBits)) >> (qBits - 8));
             const int sigRateDelta = wasLast ? 0 : (estB[ctxSig * 2 + 1] - estB[ctxSig * 2]);
@@ -945,21 +966,28 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
 // syntax element coding on the estimator (TEncSbac.cpp)
 // ------------------------------------------------------------------------------------------------
 // TEncSbac::codeCoeffNxN, TEncSbac.cpp:1172-1525 (+codeLastSignificantXY :1106, xWriteCoefRemainExGolomb :337)
+// Wavefront form: the coefficients are staged into LDS in scan order lane-parallel (with the last
+// significant position by wave-max and the coefficient-group flags), the bins are then coded by the
+// serial context chain on LDS data with the bit accumulator kept in registers.
+#define HM_BIN(ctx, bin) do { const int st_ = c->s[ctx]; fr += (uint64_t)e->entBits[st_ ^ (bin)]; c->s[ctx] = e->nextSt[st_ * 2 + (bin)]; } while (0)
 HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
 {
   const int chroma = comp != 0, log2n = hm_log2(n), wg = n >> 2;
-  if (n == 4) enc_bin(e, c, C_TSKIP + chroma, tskipFlag);           // codeTransformSkipFlags, TEncSbac.cpp:988
+  uint64_t fr = 0;
+  if (n == 4) HM_BIN(C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
-  int cnt = 0;
-  HM_PAR_FOR(i, n * n) cnt += coef[i] != 0;
-  int numSig = hm_wave_sum_i(cnt);
-  uint8_t cgFlag[64];
-  for (int i = 0; i < 64; i++) cgFlag[i] = 0;
-  int scanPosLast = -1, posLast;
-  do {
-    posLast = scan[++scanPosLast];
-    if (coef[posLast] != 0) { const int py = posLast >> log2n, px = posLast - (py << log2n); cgFlag[wg * (py >> 2) + (px >> 2)] = 1; numSig--; }
-  } while (numSig > 0);
+  int16_t *lv = e->rqCur; uint8_t *cgFlag = e->cgFlag;
+  HM_PAR_FOR(i, 64) cgFlag[i] = 0;
+  HM_SYNC();
+  int lastLocal = -1;
+  HM_PAR_FOR(sp, n * n) {
+    const int blkPos = scan[sp]; const TCoeff v = coef[blkPos];
+    lv[sp] = (int16_t)v;
+    if (v != 0) { if (sp > lastLocal) lastLocal = sp; const int py = blkPos >> log2n, px = blkPos - (py << log2n); cgFlag[wg * (py >> 2) + (px >> 2)] = 1; }
+  }
+  const int scanPosLast = hm_wave_max_i(lastLocal);
+  HM_SYNC();
+  const int posLast = scan[scanPosLast];
   {
     int py = posLast >> log2n, px = posLast - (py << log2n);
     if (scanType == SCAN_VER) { const int t = px; px = py; py = t; }
@@ -967,12 +995,12 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
     int off, shift; last_ctx_params(chroma, n, &off, &shift);
     const int bxc = C_LASTX + (chroma ? 15 : 0) + off, byc = C_LASTY + (chroma ? 15 : 0) + off;
     int k;
-    for (k = 0; k < gx; k++) enc_bin(e, c, bxc + (k >> shift), 1);
-    if (gx < gmax) enc_bin(e, c, bxc + (k >> shift), 0);
-    for (k = 0; k < gy; k++) enc_bin(e, c, byc + (k >> shift), 1);
-    if (gy < gmax) enc_bin(e, c, byc + (k >> shift), 0);
-    if (gx > 3) enc_ep(c, (gx - 2) >> 1);
-    if (gy > 3) enc_ep(c, (gy - 2) >> 1);
+    for (k = 0; k < gx; k++) HM_BIN(bxc + (k >> shift), 1);
+    if (gx < gmax) HM_BIN(bxc + (k >> shift), 0);
+    for (k = 0; k < gy; k++) HM_BIN(byc + (k >> shift), 1);
+    if (gy < gmax) HM_BIN(byc + (k >> shift), 0);
+    if (gx > 3) fr += (uint64_t)32768 * (uint64_t)((gx - 2) >> 1);
+    if (gy > 3) fr += (uint64_t)32768 * (uint64_t)((gy - 2) >> 1);
   }
   const int firstCtx = first_sig_ctx(n, scanType, chroma), sigOff = C_SIG + (chroma ? 28 : 0);
   const int lastScanSet = scanPosLast >> 4;
@@ -980,16 +1008,16 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
   for (int subSet = lastScanSet; subSet >= 0; subSet--) {
     int numNonZero = 0; const int subPos = subSet << 4; uint32_t goRice = 0;
     int absCoeff[16]; int lastNZ = -1, firstNZ = 16; int escape = 0;
-    if (scanPosSig == scanPosLast) { absCoeff[0] = hm_abs(coef[posLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
+    if (scanPosSig == scanPosLast) { absCoeff[0] = hm_abs(lv[scanPosLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
     const int cgBlkPos = scanCG[subSet], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
     if (subSet == lastScanSet || subSet == 0) cgFlag[cgBlkPos] = 1;
-    else enc_bin(e, c, C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg), cgFlag[cgBlkPos] != 0);
+    else HM_BIN(C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg), cgFlag[cgBlkPos] != 0);
     if (cgFlag[cgBlkPos]) {
       const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
       for (; scanPosSig >= subPos; scanPosSig--) {
-        const int blkPos = scan[scanPosSig]; const TCoeff cv = coef[blkPos]; const int sig = cv != 0;
+        const int cv = lv[scanPosSig]; const int sig = cv != 0;
         if (scanPosSig > subPos || subSet == 0 || numNonZero)
-          enc_bin(e, c, sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma), sig);
+          HM_BIN(sigOff + sig_ctx_inc(pattern, firstCtx, scan[scanPosSig], log2n, chroma), sig);
         if (sig) { absCoeff[numNonZero] = hm_abs(cv); numNonZero++; if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
     } else scanPosSig = subPos - 1;
@@ -1000,28 +1028,31 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
       const int numC1 = numNonZero < 8 ? numNonZero : 8; int firstC2 = -1;
       for (int idx = 0; idx < numC1; idx++) {
         const int sym = absCoeff[idx] > 1;
-        enc_bin(e, c, C_ONE + 4 * ctxSet + (int)c1, sym);
+        HM_BIN(C_ONE + 4 * ctxSet + (int)c1, sym);
         if (sym) { c1 = 0; if (firstC2 == -1) firstC2 = idx; else escape = 1; }
         else if (c1 < 3 && c1 > 0) c1++;
       }
-      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; enc_bin(e, c, C_ABS + ctxSet, sym); if (sym) escape = 1; }
+      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; HM_BIN(C_ABS + ctxSet, sym); if (sym) escape = 1; }
       escape = escape || (numNonZero > 8);
-      enc_ep(c, signHidden ? numNonZero - 1 : numNonZero);
+      fr += (uint64_t)32768 * (uint64_t)(signHidden ? numNonZero - 1 : numNonZero);
       int firstCoeff2 = 1;
       if (escape)
         for (int idx = 0; idx < numNonZero; idx++) {
           const int baseLevel = (idx < 8) ? (2 + firstCoeff2) : 1;
           if (absCoeff[idx] >= baseLevel) {
             uint32_t sym = (uint32_t)(absCoeff[idx] - baseLevel);
-            if (sym < (3u << goRice)) enc_ep(c, (int)((sym >> goRice) + 1 + goRice));
-            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++)); enc_ep(c, (int)(3 + len + 1 - goRice + len)); }
+            if (sym < (3u << goRice)) fr += (uint64_t)32768 * (uint64_t)((sym >> goRice) + 1 + goRice);
+            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++)); fr += (uint64_t)32768 * (uint64_t)(3 + len + 1 - goRice + len); }
             if ((uint32_t)absCoeff[idx] > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
           }
           if (absCoeff[idx] >= 2) firstCoeff2 = 0;
         }
     }
   }
+  c->frac += fr;
+  HM_SYNC();
 }
+#undef HM_BIN
 
 // TEncSbac::codeIntraDirLumaAng, TEncSbac.cpp:636-690
 HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
