@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the hm355 CTU RD-search path (BASELINE.json metric: CTUs/sec (enc) at 4K main10).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path (the TEncSlice::compressSlice replacement) over one batch of
+independent all-intra pictures that are already resident in HBM: synthetic 3840x2160 10-bit frames,
+encoder_intra_main10 parameters, QP 32, WaveFrontSynchro=1 (BASELINE.json configs[3], the configuration
+the metric is quoted on; it fits one GPU).  Every rank owns one GPU and its own batch (weak scaling: the
+path shards by picture with no data-path collective); RCCL is used only for the barrier / max-time.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "hm-16.2_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+ALG_BYTES_PER_CTU = 54278          # org 12,288 + recon 12,288 + neighbour lines ~1,030 + coeff 24,576 + CU metadata 4,096
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+# encoder_intra_main10 parameters restated as a config for the reference binary
+REF_CFG = """MaxCUWidth : 64
+MaxCUHeight : 64
+MaxPartitionDepth : 4
+QuadtreeTULog2MaxSize : 5
+QuadtreeTULog2MinSize : 2
+QuadtreeTUMaxDepthInter : 3
+QuadtreeTUMaxDepthIntra : 3
+IntraPeriod : 1
+DecodingRefreshType : 0
+GOPSize : 1
+FastSearch : 1
+SearchRange : 64
+HadamardME : 1
+FEN : 1
+FDM : 1
+QP : 32
+MaxDeltaQP : 0
+MaxCuDQPDepth : 0
+DeltaQpRD : 0
+RDOQ : 1
+RDOQTS : 1
+SAO : 1
+AMP : 1
+TransformSkip : 1
+TransformSkipFast : 1
+InternalBitDepth : 10
+Profile : main10
+"""
+
+
+def cpu_baseline(width, bit_depth, qp, seed):
+    """The reference's own CPU path (oracle/_ref/hm_encoder, built from /root/reference in the dev container),
+    timed on a bounded sample of the same workload: the top 4 CTU rows (width x 256) of frame 0, 1 core
+    (HM is single threaded).  Falls back to the C restatement (oracle/) when the reference binary is absent."""
+    import synth
+    rows = 12
+    h = rows * 64
+    y, u, v = synth.frame(width, 2160 if width == 3840 else h, bit_depth, 0, seed)
+    y, u, v = y[:h], u[:h // 2], v[:h // 2]
+    n_ctus = ((width + 63) // 64) * rows
+    sample = f"top {rows} CTU rows ({width}x{h}, {n_ctus} CTUs) of frame 0, WaveFrontSynchro=1, QP {qp}"
+    enc = os.path.join(ROOT, "oracle", "_ref", "hm_encoder")
+    if os.path.exists(enc):
+        with tempfile.TemporaryDirectory() as td:
+            yuv = os.path.join(td, "in.yuv")
+            with open(yuv, "wb") as fh:
+                for p in (y, u, v):
+                    fh.write(np.ascontiguousarray(p).astype("<u2").tobytes())
+            cfg = os.path.join(td, "intra_main10.cfg")
+            open(cfg, "w").write(REF_CFG)
+            cmd = [enc, "-c", cfg, "-i", yuv, "-wdt", str(width), "-hgt", str(h), "-fr", "50", "-f", "1",
+                   f"--InputBitDepth={bit_depth}", "-q", str(qp), "--WaveFrontSynchro=1", "-b", os.path.join(td, "o.bin"),
+                   "-o", os.path.join(td, "r.yuv")]
+            t0 = time.time()
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+            dt = time.time() - t0
+            for line in out.splitlines():
+                if "Total Time" in line:      # HM's own clock (encmain.cpp:95-102): whole encoder incl. deblock/SAO/entropy (<5 %)
+                    dt = float(line.split()[2])
+        return {"value": n_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "reference", "sample": sample + "; HM 'Total Time'"}
+    import oracle
+    t0 = time.time()
+    oracle.compress((y, u, v), bit_depth, qp, 1)
+    dt = time.time() - t0
+    return {"value": n_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=40, help="independent pictures per GPU per step")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: hm355 has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import hm355
+    import synth
+    bd, seed = 10, 1234
+    enc = hm355.Encoder(args.width, args.height, bd, 1, args.frames)
+    # synthetic clip: a few distinct frames, cycled over the batch slots; resident in HBM before timing
+    distinct = [synth.frame(args.width, args.height, bd, f + 16 * rank, seed) for f in range(min(4, args.frames))]
+    for i in range(args.frames):
+        enc.upload(i, distinct[i % len(distinct)])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        enc.run(args.frames, args.qp)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, launches = 0.0, 0
+    for _ in range(args.steps):
+        ms, l = enc.run(args.frames, args.qp)   # blocking: returns after the last kernel of the step finished
+        kernel_ms += ms
+        launches += l
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ctus_per_rank = enc.num_ctus * args.frames * args.steps
+    total_ctus = ctus_per_rank * world
+    if rank == 0:
+        ach = ALG_BYTES_PER_CTU * ctus_per_rank / (kernel_ms * 1e-3) / 1e9    # GB/s of the CTU-search kernel on this rank
+        line = {
+            "metric": "CTUs/sec (enc) at 4K main10; bit-exact CU partition vs HM",
+            "value": total_ctus / dt, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32+f64", "data": "synthetic",
+            "config": {"workload": f"encoder_intra_main10, synthetic {args.width}x{args.height} 10-bit, QP {args.qp}, WaveFrontSynchro=1, "
+                                   f"{args.frames} independent I pictures per GPU per step, inputs resident in HBM",
+                       "frames_per_gpu": args.frames, "ctus_per_step": enc.num_ctus * args.frames * world,
+                       "parallelism": f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture"},
+            "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches,
+                         "note": "algorithmic bytes 54,278 B/CTU (SURVEY 8d) x CTUs / HIP-event kernel time; the path is "
+                                 "dependency/latency bound, not HBM bound"},
+        }
+        if not args.no_cpu_baseline and world >= 1:
+            line["cpu_baseline"] = cpu_baseline(args.width, bd, args.qp, seed)
+            line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    enc.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
