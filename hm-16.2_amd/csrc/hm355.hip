@@ -19,7 +19,7 @@
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64) hm355_ctu_kernel(const Params *P, const WorkItem *items, int count)
+extern "C" __global__ void __launch_bounds__(64, 2) hm355_ctu_kernel(const Params *P, const WorkItem *items, int count)
 {
   __shared__ Shared sh;
   const int b = (int)blockIdx.x;

@@ -141,30 +141,39 @@ HM_CONST int16_t HM_INV_ANG_TABLE[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 
 // LDS-resident state of one CTU search
 // ------------------------------------------------------------------------------------------------
 #define HM_TSTRIDE 33
+#define HM_RQ_LDS 256                  // RDOQ per-position arrays live in LDS up to 16x16, in HBM scratch for 32x32
+struct RqLds {                         // indexed by scan position
+  int32_t lvl[HM_RQ_LDS];              // |coef| * quant scale (lLevelDouble)
+  uint16_t pos[HM_RQ_LDS];             // raster position | sign << 15
+  uint16_t dec[HM_RQ_LDS];             // level at decision time
+  int16_t cur[HM_RQ_LDS];              // working / final level
+  uint8_t ctxSig[HM_RQ_LDS];           // significance context
+  uint8_t code[HM_RQ_LDS];             // significance cost of the position: 0 none, 1 bits(ctx,0), 2 bits(ctx,1)
+};
+struct RefLds {
+  Pel refTop[2][132], refLeft[2][132]; // [filtered][0 = corner, 1..2N]
+  Pel refMain[200], refSide[200];      // angular: extended main / side reference, origin at +64
+  Pel line[272];
+};
 struct Shared {
-  Cabac cur;                         // m_pcRDGoOnSbacCoder
-  Cabac slot[5][CI_NUM];             // m_pppcRDSbacCoder[depth][CI_*]
-  int32_t tmat[32 * HM_TSTRIDE];     // 32-point transform matrix, padded rows
-  int32_t bufA[32 * HM_TSTRIDE], bufB[32 * HM_TSTRIDE];
-  Pel refTop[2][132], refLeft[2][132];        // [filtered][0 = corner, 1..2N]
-  Pel refMain[200], refSide[200];             // angular: extended main / side reference, origin at +64
-  Pel tsPred[3][16], tsRec[3][16];            // transform-skip trial of a 4x4 block
+  Cabac cur;                           // m_pcRDGoOnSbacCoder
+  Cabac slot[5][CI_NUM];               // m_pppcRDSbacCoder[depth][CI_*]
+  int8_t tmat[32 * HM_TSTRIDE];        // 32-point transform matrix, padded rows
+  int32_t bufA[32 * HM_TSTRIDE];
+  union {                              // phase-exclusive LDS: transform temp | RDOQ state | intra reference samples
+    int32_t bufB[32 * HM_TSTRIDE];
+    RqLds rq;
+    RefLds ref;
+  } u;
+  Pel tsPred[3][16], tsRec[3][16];     // transform-skip trial of a 4x4 block
   TCoeff tsCoef[3][16];
   uint8_t flags[72];
-  Pel line[272];
-  int32_t entBits[128];              // ContextModel::m_entropyBits staged in LDS
-  uint8_t nextSt[256];               // [state*2 + bin] -> next state
-  // RDOQ per-call state, indexed by scan position
-  int32_t estB[HM_NUM_CTX * 2 + 2];  // bit cost of (context, bin) for the current estimator state
-  int32_t rqLvl[1024];               // |coef| * quant scale (lLevelDouble)
-  int32_t rqSigBits[1024];           // chosen significance bits (cost = lambda * bits)
-  uint8_t rqCtxSig[1024];            // significance context of each scan position
-  uint8_t cgCtxSet[64];              // context set each coefficient group started with
+  int32_t entBits[128];                // ContextModel::m_entropyBits staged in LDS
+  uint8_t nextSt[256];                 // [state*2 + bin] -> next state
+  int32_t estB[HM_NUM_CTX * 2 + 2];    // bit cost of (context, bin) for the current estimator state
+  uint8_t cgCtxSet[64];                // context set each coefficient group started with
   double cgC0[16], cgCoef[16], cgSigC[16];   // per-position costs of the current group (zero-level hypothesis)
   uint16_t cgMax[16];
-  uint16_t rqPos[1024];              // raster position | sign << 15
-  uint16_t rqDec[1024];              // level at decision time
-  int16_t rqCur[1024];               // working / final level
   double costCGSig[64];
   uint8_t cgFlag[64];
   // uniform per-CTU context
@@ -318,7 +327,7 @@ HM_DEV inline void load_tmat(Shared *e)
     const int k = i >> 5, n = i & 31, m = (k * (2 * n + 1)) & 127;
     int v;
     if (m <= 32) v = HM_DCT_C[m]; else if (m <= 64) v = -HM_DCT_C[64 - m]; else if (m <= 96) v = -HM_DCT_C[m - 64]; else v = HM_DCT_C[128 - m];
-    e->tmat[k * HM_TSTRIDE + n] = v;
+    e->tmat[k * HM_TSTRIDE + n] = (int8_t)v;
   }
   HM_SYNC();
 }
@@ -329,7 +338,7 @@ HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth
 {
   const int l2 = hm_log2(n), s1 = l2 + bitDepth + 6 - 15, s2 = l2 + 6;
   const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
-  int32_t *A = e->bufA, *B = e->bufB;
+  int32_t *A = e->bufA, *B = e->u.bufB;
   HM_PAR_FOR(o, n * n) { // o = j*n + k with k fastest: lanes of one row share the source row (LDS broadcast)
     const int j = o >> l2, k = o & (n - 1);
     int32_t acc = 0;
@@ -349,7 +358,7 @@ HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth
 HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth)
 {
   const int l2 = hm_log2(n), s1 = 7, s2 = 20 - bitDepth;
-  int32_t *A = e->bufA, *B = e->bufB;
+  int32_t *A = e->bufA, *B = e->u.bufB;
   HM_PAR_FOR(o, n * n) {
     const int j = o >> l2, i = o & (n - 1);
     int32_t acc = 0;
@@ -462,7 +471,7 @@ HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
 
 // TComPrediction::initAdiPatternChType + fillReferenceSamples + smoothing (TComPattern.cpp:107-500).
 // (px,py): block position in the component plane; n: block size; (x4,y4): top-left luma 4x4 unit;
-// units: block size in 4x4-luma units.  Result in e->refTop/refLeft[0] (and [1] when filter != 0).
+// units: block size in 4x4-luma units.  Result in e->u.ref.refTop/refLeft[0] (and [1] when filter != 0).
 HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, int n, int x4, int y4, int units, int filter)
 {
   const int uw = comp ? 2 : 4, total = 4 * units + 1, L = 2 * units, n2 = 2 * n;
@@ -483,14 +492,14 @@ HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, in
   HM_SYNC();
   const Pel *rec = e->fb.rec[comp]; const int st = e->P->stride[comp];
   const int dc = 1 << (bitDepth - 1);
-  Pel *top = e->refTop[0], *left = e->refLeft[0];
+  Pel *top = e->u.ref.refTop[0], *left = e->u.ref.refLeft[0];
   if (num == 0) {
     HM_PAR_FOR(i, n2 + 1) { top[i] = (Pel)dc; left[i] = (Pel)dc; }
   } else if (num == total) {
     HM_PAR_FOR(i, n2 + 1) { top[i] = rec[(py - 1) * st + px - 1 + i]; left[i] = rec[(py - 1 + i) * st + px - 1]; }
   } else {
     // line[]: 2n left samples bottom-to-top, uw copies of the corner, 2n above samples
-    Pel *line = e->line; const int nl = n2 + uw + n2;
+    Pel *line = e->u.ref.line; const int nl = n2 + uw + n2;
     HM_PAR_FOR(i, nl) {
       int v = dc;
       if (i < n2) { const int j = (n2 - 1 - i); if (flags[L - 1 - j / uw]) v = rec[(py + j) * st + px - 1]; }
@@ -514,7 +523,7 @@ HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, in
   HM_SYNC();
   if (!filter) return;
   // smoothing, TComPattern.cpp:180-283
-  Pel *ft = e->refTop[1], *fl = e->refLeft[1];
+  Pel *ft = e->u.ref.refTop[1], *fl = e->u.ref.refLeft[1];
   int strong = (comp == 0);
   const int bl = left[n2], tl = top[0], tr = top[n2];
   if (strong) {
@@ -551,7 +560,7 @@ HM_DEV inline int use_filtered_refs(int comp, int mode, int n)
 // One lane per sample.
 HM_DEV HM_NOINLINE void pred_intra(Shared *e, int comp, int mode, int n, int filtered, Pel *dst, int ds)
 {
-  const Pel *top = e->refTop[filtered], *left = e->refLeft[filtered];
+  const Pel *top = e->u.ref.refTop[filtered], *left = e->u.ref.refLeft[filtered];
   const int bitDepth = e->P->bitDepth, l2 = hm_log2(n);
   if (mode == PLANAR_IDX) {
     const int bottomLeft = left[n + 1], topRight = top[n + 1];
@@ -587,7 +596,7 @@ HM_DEV HM_NOINLINE void pred_intra(Shared *e, int comp, int mode, int n, int fil
   const int angMode = isVer ? mode - VER_IDX : -(mode - HOR_IDX);
   const int absAng = HM_ANG_TABLE[hm_abs(angMode)], invAngle = HM_INV_ANG_TABLE[hm_abs(angMode)];
   const int angle = angMode < 0 ? -absAng : absAng;
-  Pel *refMain = e->refMain + 64, *refSide = e->refSide + 64;
+  Pel *refMain = e->u.ref.refMain + 64, *refSide = e->u.ref.refSide + 64;
   if (angle < 0) {
     HM_PAR_FOR(i, n + 1) { refMain[i] = isVer ? top[i] : left[i]; refSide[i] = isVer ? left[i] : top[i]; }
     HM_SYNC();
@@ -721,6 +730,11 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   const int32_t *src = e->bufA;
   const int32_t *estB = e->estB;
   double *costCoeff = e->ws->costCoeff;
+  WorkSpace *ws = e->ws;
+  int32_t *rqLvl = (n == 32) ? ws->rqLvl : e->u.rq.lvl;
+  uint16_t *rqPos = (n == 32) ? ws->rqPos : e->u.rq.pos, *rqDec = (n == 32) ? ws->rqDec : e->u.rq.dec;
+  int16_t *rqCur = (n == 32) ? ws->rqCur : e->u.rq.cur;
+  uint8_t *rqCtxSig = (n == 32) ? ws->rqCtxSig : e->u.rq.ctxSig, *rqCode = (n == 32) ? ws->rqCode : e->u.rq.code;
   // ---- 1. pre-pass
   int lastLocal = -1;
   {
@@ -730,8 +744,8 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       const int32_t sc = src[(blkPos >> log2n) * HM_TSTRIDE + (blkPos & (n - 1))];
       const int64_t tmpLevel = (int64_t)hm_abs(sc) * quantCoef;
       const int32_t lvl = (int32_t)(tmpLevel < cap ? tmpLevel : cap);
-      e->rqLvl[sp] = lvl;
-      e->rqPos[sp] = (uint16_t)(blkPos | (sc < 0 ? 0x8000 : 0));
+      rqLvl[sp] = lvl;
+      rqPos[sp] = (uint16_t)(blkPos | (sc < 0 ? 0x8000 : 0));
       if (((lvl + (1 << (qBits - 1))) >> qBits) > 0 && sp > lastLocal) lastLocal = sp;
       dst[sp] = 0;
     }
@@ -748,7 +762,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   //         zero-level hypothesis (state independent); the serial part only decides the positions whose
   //         quantised magnitude is non-zero and adds the costs up in the reference's order.
   double blockUncodedCost = 0;
-  for (int sp = numCoef - 1; sp > lastScanPos; sp--) { const double err = (double)e->rqLvl[sp]; blockUncodedCost += err * err * errScale; }
+  for (int sp = numCoef - 1; sp > lastScanPos; sp--) { const double err = (double)rqLvl[sp]; blockUncodedCost += err * err * errScale; }
   double baseCost = blockUncodedCost;
   const int cgLastScanPos = lastScanPos >> 4;
   int ctxSet = ctx_set_index(chroma, lastScanPos >> 4, 0), c1 = 1, c2 = 0, c1Idx = 0, c2Idx = 0, goRice = 0;
@@ -759,15 +773,15 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     const int startPos = (cgScanPos == cgLastScanPos ? (lastScanPos & 15) : 15);
     e->cgCtxSet[cgScanPos] = (uint8_t)ctxSet;
     HM_PAR_FOR(k, 16) {
-      const int scanPos = cgScanPos * 16 + k, blkPos = e->rqPos[scanPos] & 0x3ff;
-      const int32_t lvl = e->rqLvl[scanPos];
+      const int scanPos = cgScanPos * 16 + k, blkPos = rqPos[scanPos] & 0x3ff;
+      const int32_t lvl = rqLvl[scanPos];
       uint32_t mx = (uint32_t)((lvl + (1 << (qBits - 1))) >> qBits); if (mx > 32767u) mx = 32767u;
       const double err = (double)lvl, c0 = err * err * errScale;
       const int ctxSig = (scanPos == lastScanPos) ? 0 : sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
       const int b0 = estB[ctxSig * 2];
       const double s0 = lambda * (double)b0;
       e->cgMax[k] = (uint16_t)mx; e->cgC0[k] = c0; e->cgSigC[k] = s0; e->cgCoef[k] = c0 + s0;
-      e->rqCtxSig[scanPos] = (uint8_t)ctxSig; e->rqSigBits[scanPos] = b0; e->rqDec[scanPos] = 0; e->rqCur[scanPos] = 0;
+      rqCtxSig[scanPos] = (uint8_t)ctxSig; rqCode[scanPos] = 1; rqDec[scanPos] = 0; rqCur[scanPos] = 0;
     }
     HM_SYNC();
     for (int posInCG = startPos; posInCG >= 0; posInCG--) {
@@ -779,14 +793,14 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       double cCoeff, cSig;
       if (maxAbsLevel == 0) { cCoeff = e->cgCoef[posInCG]; cSig = e->cgSigC[posInCG]; }
       else {
-        const int32_t levelDouble = e->rqLvl[scanPos];
+        const int32_t levelDouble = rqLvl[scanPos];
         const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
         const int isLast = (scanPos == lastScanPos);
-        const int ctxSig = e->rqCtxSig[scanPos];
-        int sigBits = 0;
+        const int ctxSig = rqCtxSig[scanPos];
+        int sigBits = 0, sigCode = 0;
         { // xGetCodedLevel, TComTrQuant.cpp:2660-2715
           int currSigBits = 0;
-          if (!isLast && maxAbsLevel < 3) { sigBits = estB[ctxSig * 2]; cCoeff = c0 + lambda * (double)sigBits; }
+          if (!isLast && maxAbsLevel < 3) { sigBits = estB[ctxSig * 2]; sigCode = 1; cCoeff = c0 + lambda * (double)sigBits; }
           else cCoeff = HM_MAX_DOUBLE;
           double currCostSig = 0;
           if (!isLast) { currSigBits = estB[ctxSig * 2 + 1]; currCostSig = lambda * (double)currSigBits; }
@@ -797,11 +811,11 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
             const double rc = lambda * (double)ic_rate(estB, (uint32_t)al, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
             double cc = dist + rc;
             cc += currCostSig;
-            if (cc < cCoeff) { level = (uint32_t)al; cCoeff = cc; sigBits = currSigBits; }
+            if (cc < cCoeff) { level = (uint32_t)al; cCoeff = cc; sigBits = currSigBits; sigCode = isLast ? 0 : 2; }
           }
         }
         cSig = lambda * (double)sigBits;
-        e->rqSigBits[scanPos] = sigBits; e->rqDec[scanPos] = (uint16_t)level; e->rqCur[scanPos] = (int16_t)level;
+        rqCode[scanPos] = (uint8_t)sigCode; rqDec[scanPos] = (uint16_t)level; rqCur[scanPos] = (int16_t)level;
         const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
         if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
         if (level >= 1) c1Idx++;
@@ -841,7 +855,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
         if (costZeroCG < baseCost) {
           cgFlag[cgBlkPos] = 0; baseCost = costZeroCG;
           costCGSig[cgScanPos] = r0;
-          HM_PAR_FOR(k, 16) { const int scanPos = cgScanPos * 16 + k; if (e->rqCur[scanPos]) { e->rqCur[scanPos] = 0; e->rqSigBits[scanPos] = 0; } }
+          HM_PAR_FOR(k, 16) { const int scanPos = cgScanPos * 16 + k; if (rqCur[scanPos]) { rqCur[scanPos] = 0; rqCode[scanPos] = 0; } }
         }
       }
     } else cgFlag[cgBlkPos] = 1;
@@ -859,10 +873,11 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG;
       if (scanPos > lastScanPos) continue;
-      const int cur = e->rqCur[scanPos];
-      const double cSig = lambda * (double)e->rqSigBits[scanPos];
+      const int cur = rqCur[scanPos];
+      const int code = rqCode[scanPos];
+      const double cSig = lambda * (double)(code ? estB[rqCtxSig[scanPos] * 2 + code - 1] : 0);
       if (cur) {
-        const int blkPos = e->rqPos[scanPos] & 0x3ff;
+        const int blkPos = rqPos[scanPos] & 0x3ff;
         int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
         if (scanType == SCAN_VER) { const int t = posX; posX = posY; posY = t; }
         // xGetRateLast, TComTrQuant.cpp:2815-2832 over estLastSignificantPositionBit, TEncSbac.cpp:1846-1892
@@ -880,7 +895,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
         const double totalCost = t1 - cSig;
         if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
         if (cur > 1) { foundLast = 1; break; }
-        const double err = (double)e->rqLvl[scanPos];
+        const double err = (double)rqLvl[scanPos];
         baseCost -= costCoeff[scanPos]; baseCost += err * err * errScale;
       } else baseCost -= cSig;
     }
@@ -888,9 +903,9 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   // ---- levels with signs, truncated at the chosen last position (lane-parallel)
   int absPart = 0;
   HM_PAR_FOR(sp, lastScanPos + 1) {
-    int lv = sp < bestLastIdxP1 ? e->rqCur[sp] : 0;
+    int lv = sp < bestLastIdxP1 ? rqCur[sp] : 0;
     absPart += lv;
-    e->rqCur[sp] = (int16_t)((e->rqPos[sp] & 0x8000) ? -lv : lv);
+    rqCur[sp] = (int16_t)((rqPos[sp] & 0x8000) ? -lv : lv);
   }
   const int absSum = hm_wave_sum_i(absPart);
   HM_SYNC();
@@ -901,12 +916,12 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     for (int subSet = cgLastScanPos; subSet >= 0; subSet--) {
       const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, k;
       const int top = (subPos + 15 <= lastScanPos) ? 15 : (lastScanPos - subPos);
-      for (k = top; k >= 0; --k) if (e->rqCur[k + subPos]) { lastNZ = k; break; }
-      for (k = 0; k <= top; k++) if (e->rqCur[k + subPos]) { firstNZ = k; break; }
-      for (k = firstNZ; k <= lastNZ; k++) sum += e->rqCur[k + subPos];
+      for (k = top; k >= 0; --k) if (rqCur[k + subPos]) { lastNZ = k; break; }
+      for (k = 0; k <= top; k++) if (rqCur[k + subPos]) { firstNZ = k; break; }
+      for (k = firstNZ; k <= lastNZ; k++) sum += rqCur[k + subPos];
       if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
       if (lastNZ - firstNZ >= 4) {
-        const uint32_t signbit = e->rqCur[subPos + firstNZ] > 0 ? 0 : 1;
+        const uint32_t signbit = rqCur[subPos + firstNZ] > 0 ? 0 : 1;
         if (signbit != (uint32_t)(sum & 1)) {
           const int64_t I64MAX = 0x7fffffffffffffffLL;
           int64_t minCostInc = I64MAX, curCost = I64MAX; int minSp = -1, finalChange = 0, curChange = 0;
@@ -915,7 +930,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
           const int kStart = (lastCG == 1 ? lastNZ : 15);
           for (k = top; k >= 0; --k) {
             const int sp = k + subPos;
-            const uint32_t dec = e->rqDec[sp];
+            const uint32_t dec = rqDec[sp];
             const int ctxOne = 4 * wSet + wC1, ctxSetD = wSet, goR = wGoR, c1I = wC1Idx, c2I = wC2Idx;
             { // advance the walk past this position (same updates as the decision chain)
               const uint32_t baseLevel = (wC1Idx < 8) ? (2 + (wC2Idx < 1)) : 1;
@@ -925,8 +940,8 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
               else if (wC1 < 3 && wC1 > 0 && dec) wC1++;
             }
             if (k > kStart) continue;
-            const int ctxSig = e->rqCtxSig[sp], wasLast = (sp == lastScanPos);
-            const int32_t lvlD = e->rqLvl[sp];
+            const int ctxSig = rqCtxSig[sp], wasLast = (sp == lastScanPos);
+            const int32_t lvlD = rqLvl[sp];
             const int32_t deltaU = (int32_t)((lvlD - (int32_t)(dec << qBits)) >> (qBits - 8));
             const int sigRateDelta = wasLast ? 0 : (estB[ctxSig * 2 + 1] - estB[ctxSig * 2]);
             int rateIncUp, rateIncDown = 0;
@@ -935,7 +950,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
               rateIncUp = ic_rate(estB, dec + 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
               rateIncDown = ic_rate(estB, dec - 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
             } else rateIncUp = estB[(C_ONE + ctxOne) * 2];
-            const int dv = e->rqCur[sp];
+            const int dv = rqCur[sp];
             if (dv != 0) {
               const int64_t costUp = rdFactor * (-deltaU) + rateIncUp;
               int64_t costDown = rdFactor * (deltaU) + rateIncDown - ((hm_abs(dv) == 1) ? sigRateDelta : 0);
@@ -945,19 +960,19 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
             } else {
               curCost = rdFactor * (-(hm_abs(deltaU))) + (1 << 15) + rateIncUp + sigRateDelta;
               curChange = 1;
-              if (k < firstNZ) { const uint32_t thissign = (e->rqPos[sp] & 0x8000) ? 1 : 0; if (thissign != signbit) curCost = I64MAX; }
+              if (k < firstNZ) { const uint32_t thissign = (rqPos[sp] & 0x8000) ? 1 : 0; if (thissign != signbit) curCost = I64MAX; }
             }
             if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minSp = sp; }
           }
-          if (e->rqCur[minSp] == 32767 || e->rqCur[minSp] == -32768) finalChange = -1;
-          if (!(e->rqPos[minSp] & 0x8000)) e->rqCur[minSp] = (int16_t)(e->rqCur[minSp] + finalChange); else e->rqCur[minSp] = (int16_t)(e->rqCur[minSp] - finalChange);
+          if (rqCur[minSp] == 32767 || rqCur[minSp] == -32768) finalChange = -1;
+          if (!(rqPos[minSp] & 0x8000)) rqCur[minSp] = (int16_t)(rqCur[minSp] + finalChange); else rqCur[minSp] = (int16_t)(rqCur[minSp] - finalChange);
         }
       }
       if (lastCG == 1) lastCG = 0;
     }
   }
   HM_SYNC();
-  HM_PAR_FOR(sp, lastScanPos + 1) dst[e->rqPos[sp] & 0x3ff] = e->rqCur[sp];
+  HM_PAR_FOR(sp, lastScanPos + 1) dst[rqPos[sp] & 0x3ff] = rqCur[sp];
   HM_SYNC();
   return absSum;
 }
@@ -976,7 +991,7 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
   uint64_t fr = 0;
   if (n == 4) HM_BIN(C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
-  int16_t *lv = e->rqCur; uint8_t *cgFlag = e->cgFlag;
+  int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->cgFlag;
   HM_PAR_FOR(i, 64) cgFlag[i] = 0;
   HM_SYNC();
   int lastLocal = -1;

@@ -43,8 +43,9 @@ struct WorkSpace {
   Pel pred[HM_COEF_CTU], resi[HM_COEF_CTU], reco[HM_COEF_CTU];
   Pel qtRec[4][HM_COEF_CTU];         // m_pcQTTempTComYuv[layer]
   TCoeff qtCoef[4][HM_COEF_CTU];     // m_ppcQTTempCoeff[comp][layer]
-  double costCoeff[1024], costSig[1024], costCoeff0[1024];          // RDOQ per-coefficient state
-  int32_t rateIncUp[1024], rateIncDown[1024], sigRateDelta[1024], deltaU[1024];
+  double costCoeff[1024];            // RDOQ: cost of the positions that keep a non-zero level
+  int32_t rqLvl[1024];               // RDOQ per-position state of 32x32 blocks (smaller blocks keep it in LDS)
+  uint16_t rqPos[1024], rqDec[1024]; int16_t rqCur[1024]; uint8_t rqCtxSig[1024], rqCode[1024];
   uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
 };
 
