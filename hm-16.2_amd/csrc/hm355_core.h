@@ -44,7 +44,9 @@ static inline int hm_wave_max_i(int v) { return v; }
 #define HM_CONST __device__ const
 #define HM_NT 64
 __device__ __forceinline__ int hm_lane() { return (int)threadIdx.x; }
-#define HM_SYNC() __syncthreads()
+// one wavefront per CTU: lanes run in lockstep, so a phase boundary only has to order this wave's own LDS /
+// global accesses (wavefront-scope fence) -- no s_barrier and no drain of outstanding stores
+#define HM_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 __device__ __forceinline__ uint32_t hm_wave_sum(uint32_t v)
 {
 #pragma unroll
