@@ -1,0 +1,112 @@
+// Host-side C++ mirror of the reference's encoder object graph for the hot path:
+//   TEncTop  (source/Lib/TLibEncoder/TEncTop.h:70-176)   create / init / encode / destroy
+//   TEncGOP  (TEncGOP.h; compressGOP TEncGOP.cpp:527)    per-picture driver
+//   TEncSlice(TEncSlice.h:60-127)                        initEncSlice / setUpLambda / compressSlice
+// Same class and method names, argument meaning and call order as the reference; the bodies are ours and
+// TEncSlice::compressSlice forwards to the C ABI (include/hm355.h) instead of running the CPU search.
+// Everything the reference does outside the hot path (RPS, SEI, NAL, deblocking, SAO, entropy pass, rate
+// control) is out of scope and absent here.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <list>
+#include <vector>
+#include "../../include/hm355.h"
+
+typedef void Void; typedef bool Bool; typedef int Int; typedef unsigned int UInt; typedef double Double;
+typedef short Pel;
+enum SliceType { B_SLICE = 0, P_SLICE = 1, I_SLICE = 2 };
+enum ComponentID { COMPONENT_Y = 0, COMPONENT_Cb = 1, COMPONENT_Cr = 2, MAX_NUM_COMPONENT = 3 };
+
+// picture planes (TComPicYuv.h): tightly packed 16-bit samples, 4:2:0
+class TComPicYuv {
+public:
+  Void create(Int w, Int h) { m_w = w; m_h = h; for (Int c = 0; c < 3; c++) m_buf[c].assign((size_t)(w >> (c ? 1 : 0)) * (h >> (c ? 1 : 0)), 0); }
+  Void destroy() { for (Int c = 0; c < 3; c++) m_buf[c].clear(); }
+  uint16_t *getAddr(ComponentID c) { return m_buf[c].data(); }
+  Int getWidth(ComponentID c) const { return m_w >> (c ? 1 : 0); }
+  Int getHeight(ComponentID c) const { return m_h >> (c ? 1 : 0); }
+private:
+  Int m_w = 0, m_h = 0; std::vector<uint16_t> m_buf[3];
+};
+
+// slice header fields compressSlice reads (TComSlice.h)
+class TComSlice {
+public:
+  Void setSliceType(SliceType t) { m_type = t; } SliceType getSliceType() const { return m_type; }
+  Void setSliceQp(Int qp) { m_qp = qp; } Int getSliceQp() const { return m_qp; }
+  Void setPOC(Int p) { m_poc = p; } Int getPOC() const { return m_poc; }
+  Void setSliceBits(UInt b) { m_bits = b; } UInt getSliceBits() const { return m_bits; }
+private:
+  SliceType m_type = I_SLICE; Int m_qp = 32, m_poc = 0; UInt m_bits = 0;
+};
+
+// picture = original + reconstruction + per-CTU decision data (TComPic.h / TComPicSym.h / TComDataCU.h)
+class TComPic {
+public:
+  Void create(Int w, Int h);
+  TComPicYuv *getPicYuvOrg() { return &m_org; }
+  TComPicYuv *getPicYuvRec() { return &m_rec; }
+  TComSlice *getSlice(Int) { return &m_slice; }
+  hm355_ctu_out *getCtu(UInt ctuRsAddr) { return &m_ctus[ctuRsAddr]; }     // the arrays of TComDataCU
+  UInt getNumberOfCtusInFrame() const { return (UInt)m_ctus.size(); }
+  Int getPOC() { return m_slice.getPOC(); }
+private:
+  TComPicYuv m_org, m_rec; TComSlice m_slice; std::vector<hm355_ctu_out> m_ctus;
+};
+
+// configuration holder (TEncCfg.h): the subset the hot path reads; unsupported values are rejected by create()
+class TEncCfg {
+public:
+  Void setSourceWidth(Int v) { m_iSourceWidth = v; } Void setSourceHeight(Int v) { m_iSourceHeight = v; }
+  Void setInternalBitDepth(Int v) { m_bitDepth = v; } Void setQP(Int v) { m_iQP = v; }
+  Void setIntraPeriod(Int v) { m_uiIntraPeriod = v; } Void setGOPSize(Int v) { m_iGOPSize = v; }
+  Void setWaveFrontSynchro(Int v) { m_iWaveFrontSynchro = v; } Void setFramesToBeEncoded(Int v) { m_framesToBeEncoded = v; }
+  Int getSourceWidth() const { return m_iSourceWidth; } Int getSourceHeight() const { return m_iSourceHeight; }
+  Int getQP() const { return m_iQP; } Int getGOPSize() const { return m_iGOPSize; } Int getIntraPeriod() const { return m_uiIntraPeriod; }
+  Int getWaveFrontsynchro() const { return m_iWaveFrontSynchro; } Int getInternalBitDepth() const { return m_bitDepth; }
+protected:
+  Int m_iSourceWidth = 0, m_iSourceHeight = 0, m_bitDepth = 8, m_iQP = 32, m_uiIntraPeriod = 1, m_iGOPSize = 1, m_iWaveFrontSynchro = 0, m_framesToBeEncoded = 0;
+};
+
+class TEncTop;
+
+class TEncSlice {
+public:
+  Void init(TEncTop *pcEncTop);
+  // TEncSlice::initEncSlice (TEncSlice.cpp:180-481): slice type, QP and lambda of the picture
+  Void initEncSlice(TComPic *pcPic, Int pocLast, Int pocCurr, Int iNumPicRcvd, Int iGOPid, TComSlice *&rpcSlice);
+  Void setUpLambda(TComSlice *slice, const Double dLambda, Int iQP);                 // TEncSlice.cpp:132-159
+  Void precompressSlice(TComPic *) {}                                                // DeltaQpRD = 0 in every config: no-op
+  Void compressSlice(TComPic *pcPic);                                                // TEncSlice.cpp:640 -> hm355_compress_slice
+  uint64_t getTotalBits() const { return m_uiPicTotalBits; }
+  Double getPicRdCost() const { return m_dPicRdCost; }
+  uint64_t getPicDist() const { return m_uiPicDist; }
+private:
+  TEncTop *m_pcEncTop = nullptr;
+  Double m_dLambda = 0, m_dChromaWeight = 1;
+  uint64_t m_uiPicTotalBits = 0, m_uiPicDist = 0; Double m_dPicRdCost = 0;
+};
+
+class TEncGOP {
+public:
+  Void init(TEncTop *pcTEncTop);
+  // TEncGOP::compressGOP (TEncGOP.cpp:527): one picture per call for the all-intra GOP (GOPSize 1)
+  Void compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &rcListPic);
+private:
+  TEncTop *m_pcEncTop = nullptr; TEncSlice *m_pcSliceEncoder = nullptr;
+};
+
+class TEncTop : public TEncCfg {
+public:
+  Void create();                     // TEncTop.cpp:87: allocates the device context
+  Void destroy();
+  Void init();                       // TEncTop.cpp:187
+  // TEncTop::encode (TEncTop.cpp:259): takes one original picture, encodes when a GOP is complete
+  Void encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &rcListPicOut, Int &iNumEncoded);
+  TEncSlice *getSliceEncoder() { return &m_cSliceEncoder; }
+  hm355_ctx *getDeviceContext() { return m_ctx; }
+private:
+  hm355_ctx *m_ctx = nullptr; TEncGOP m_cGOPEncoder; TEncSlice m_cSliceEncoder;
+  std::list<TComPic *> m_cListPic; Int m_iPOCLast = -1, m_iNumPicRcvd = 0;
+};
