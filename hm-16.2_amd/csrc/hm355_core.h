@@ -33,6 +33,8 @@ static inline int hm_lane() { return 0; }
 static inline uint32_t hm_wave_sum(uint32_t v) { return v; }
 static inline int hm_wave_sum_i(int v) { return v; }
 static inline int hm_wave_max_i(int v) { return v; }
+#define HM_UNI(x) (x)
+#define HM_LDS_ADD(p, v) (*(p) += (v))
 #ifdef HM355_HOSTSIM_REVERSE   /* run every lane-parallel loop backwards: catches order dependence */
 #define HM_PAR_FOR(i, n) for (int i = (n) - 1; i >= 0; i--)
 #else
@@ -65,6 +67,9 @@ __device__ __forceinline__ int hm_wave_max_i(int v)
   for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
   return v;
 }
+#define HM_LDS_ADD(p, v) atomicAdd((p), (v))
+// wave-uniform value loaded through the vector path -> SGPR, so that the dependent control code runs on the scalar unit
+#define HM_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 #define HM_PAR_FOR(i, n) for (int i = hm_lane(); i < (n); i += HM_NT)
 #endif
 
@@ -142,6 +147,18 @@ HM_CONST int16_t HM_INV_ANG_TABLE[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 
 // ------------------------------------------------------------------------------------------------
 // LDS-resident state of one CTU search
 // ------------------------------------------------------------------------------------------------
+// TU descriptor: the subset of TComTU (TComTU.h/.cpp) that 4:2:0 intra coding needs
+struct TU {
+  int16_t cuZ, cuDepth, cuParts, relZ, trDepth, log2, parts, section, x, y;
+  int16_t cW, cCodeAll, cTrDepth, cRelZ, cParts, cOff, cx, cy;
+};
+// explicit stacks of the tree walks (kept in LDS: no private-memory traffic, no device recursion)
+struct TuWalk { TU node[5]; int8_t next[5]; int sp; };
+struct RqtFrame {
+  TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf; double singleCost, splitCost;
+};
+struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
+
 #define HM_TSTRIDE 33
 #define HM_RQ_LDS 256                  // RDOQ per-position arrays live in LDS up to 16x16, in HBM scratch for 32x32
 struct RqLds {                         // indexed by scan position
@@ -178,7 +195,19 @@ struct Shared {
   uint16_t cgMax[16];
   double costCGSig[64];
   uint8_t cgFlag[64];
+  uint8_t z2r[256], r2z[256];          // z-scan <-> raster of the 4x4 partitions
+  TuWalk walkOuter, walkInner;         // tree-walk stacks
+  RqtFrame rqt[4]; uint32_t rqtRetDist[5]; double rqtRetCost[5];
+  CuFrame cuf[4];
+  int32_t absCoeff[16];
+  int32_t rdModeList[12]; double candCost[12];
+  uint8_t splitCbf[5][2];
+  // results handed back by the big non-inlined stages (instead of pointers to private memory)
+  double outCost; uint32_t outBits, outDist; double outRdCost; uint32_t outDistY;
+  uint32_t satd[36];                   // SATD of the 35 intra modes of the PU under test
+  int32_t mpmZ, mpmNum, mpmPreds[3];   // most-probable-mode list of the PU under test (same for all its candidates)
   // uniform per-CTU context
+  int32_t width, height, bitDepth, wCtu, stride[3];
   const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
   CtuMeta *cm; TCoeff *cc;
   int32_t ctuX, ctuY, ctuAddr;
@@ -380,16 +409,12 @@ HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth
 // ------------------------------------------------------------------------------------------------
 // TU descriptor: the subset of TComTU (TComTU.h/.cpp) that 4:2:0 intra coding needs
 // ------------------------------------------------------------------------------------------------
-struct TU {
-  int16_t cuZ, cuDepth, cuParts, relZ, trDepth, log2, parts, section, x, y;
-  int16_t cW, cCodeAll, cTrDepth, cRelZ, cParts, cOff, cx, cy;
-};
 HM_DEV inline TU tu_root(const Shared *e, int cuZ, int cuDepth)
 { // TComTU::TComTU(pcCU, absPartIdxCU, cuDepth, 0), TComTU.cpp:48
   TU t;
   t.cuZ = (int16_t)cuZ; t.cuDepth = (int16_t)cuDepth; t.cuParts = (int16_t)(256 >> (2 * cuDepth));
   t.relZ = 0; t.trDepth = 0; t.log2 = (int16_t)(6 - cuDepth); t.parts = t.cuParts; t.section = 0;
-  const int r = e->tab->z2r[cuZ];
+  const int r = e->z2r[cuZ];
   t.x = (int16_t)((r & 15) * 4); t.y = (int16_t)((r >> 4) * 4);
   t.cW = (int16_t)(1 << (t.log2 - 1)); t.cCodeAll = 1; t.cTrDepth = 0; t.cRelZ = 0; t.cParts = t.parts; t.cOff = (int16_t)(cuZ * 4);
   t.cx = t.x >> 1; t.cy = t.y >> 1;
@@ -416,12 +441,12 @@ HM_DEV inline TU tu_child(const TU *p, int section, int processLast)
 // neighbour helpers
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline const CtuMeta *meta_at(const Shared *e, int x4, int y4, int *z)
-{ *z = e->tab->r2z[((y4 & 15) << 4) | (x4 & 15)]; return e->fb.meta + ((y4 >> 4) * e->P->wCtu + (x4 >> 4)); }
+{ *z = e->r2z[((y4 & 15) << 4) | (x4 & 15)]; return e->fb.meta + ((y4 >> 4) * e->wCtu + (x4 >> 4)); }
 
 // TComDataCU::getIntraDirPredictor, TComDataCU.cpp:1513-1586 (luma)
 HM_DEV inline int intra_dir_predictor(const Shared *e, int z, int preds[3])
 {
-  const int r = e->tab->z2r[z];
+  const int r = e->z2r[z];
   const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4);
   int left = DC_IDX, above = DC_IDX, zz;
   if (x4 > 0) { const CtuMeta *m = meta_at(e, x4 - 1, y4, &zz); left = (m->pred[zz] == MODE_INTRA) ? m->dirL[zz] : DC_IDX; }
@@ -438,7 +463,7 @@ HM_DEV inline int intra_dir_predictor(const Shared *e, int z, int preds[3])
 // TComDataCU::getCtxSplitFlag, TComDataCU.cpp:1587-1601
 HM_DEV inline int ctx_split_flag(const Shared *e, int z, int depth)
 {
-  const int r = e->tab->z2r[z];
+  const int r = e->z2r[z];
   const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4);
   int ctx = 0, zz;
   if (x4 > 0) { const CtuMeta *m = meta_at(e, x4 - 1, y4, &zz); ctx += m->depth[zz] > depth; }
@@ -451,21 +476,21 @@ HM_DEV inline int ctx_split_flag(const Shared *e, int z, int depth)
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline int avail_above_right(const Shared *e, int rtx4, int rty4, int k)
 { // TComDataCU::getPUAboveRightAdi, TComDataCU.cpp:1302-1360
-  if ((rtx4 + k) * 4 >= e->P->width) return 0;
+  if ((rtx4 + k) * 4 >= e->width) return 0;
   const int cx = rtx4 & 15, cy = rty4 & 15;
   if (cx + k <= 15) {
-    if (cy != 0) return e->tab->r2z[(cy << 4) | cx] > e->tab->r2z[((cy - 1) << 4) | (cx + k)];
+    if (cy != 0) return e->r2z[(cy << 4) | cx] > e->r2z[((cy - 1) << 4) | (cx + k)];
     return rty4 > 0;
   }
   if (cy != 0) return 0;
-  return rty4 > 0 && (rtx4 >> 4) < e->P->wCtu - 1;
+  return rty4 > 0 && (rtx4 >> 4) < e->wCtu - 1;
 }
 HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
 { // TComDataCU::getPUBelowLeftAdi, TComDataCU.cpp:1244-1300
-  if ((lby4 + k) * 4 >= e->P->height) return 0;
+  if ((lby4 + k) * 4 >= e->height) return 0;
   const int cx = lbx4 & 15, cy = lby4 & 15;
   if (cy + k <= 15) {
-    if (cx != 0) return e->tab->r2z[(cy << 4) | cx] > e->tab->r2z[((cy + k) << 4) | (cx - 1)];
+    if (cx != 0) return e->r2z[(cy << 4) | cx] > e->r2z[((cy + k) << 4) | (cx - 1)];
     return lbx4 > 0;
   }
   return 0;
@@ -477,7 +502,7 @@ HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
 HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, int n, int x4, int y4, int units, int filter)
 {
   const int uw = comp ? 2 : 4, total = 4 * units + 1, L = 2 * units, n2 = 2 * n;
-  const int bitDepth = e->P->bitDepth;
+  const int bitDepth = e->bitDepth;
   uint8_t *flags = e->flags;
   // availability flag of every unit: one lane per unit, then a wave reduction for the count
   int cnt = 0;
@@ -492,7 +517,7 @@ HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, in
   }
   const int num = hm_wave_sum_i(cnt);
   HM_SYNC();
-  const Pel *rec = e->fb.rec[comp]; const int st = e->P->stride[comp];
+  const Pel *rec = e->fb.rec[comp]; const int st = e->stride[comp];
   const int dc = 1 << (bitDepth - 1);
   Pel *top = e->u.ref.refTop[0], *left = e->u.ref.refLeft[0];
   if (num == 0) {
@@ -563,7 +588,7 @@ HM_DEV inline int use_filtered_refs(int comp, int mode, int n)
 HM_DEV HM_NOINLINE void pred_intra(Shared *e, int comp, int mode, int n, int filtered, Pel *dst, int ds)
 {
   const Pel *top = e->u.ref.refTop[filtered], *left = e->u.ref.refLeft[filtered];
-  const int bitDepth = e->P->bitDepth, l2 = hm_log2(n);
+  const int bitDepth = e->bitDepth, l2 = hm_log2(n);
   if (mode == PLANAR_IDX) {
     const int bottomLeft = left[n + 1], topRight = top[n + 1];
     HM_PAR_FOR(i, n * n) {
@@ -621,6 +646,109 @@ HM_DEV HM_NOINLINE void pred_intra(Shared *e, int comp, int mode, int n, int fil
       else v = refMain[x + di + 1];
     }
     if (isVer) dst[y * ds + x] = (Pel)v; else dst[x * ds + y] = (Pel)v;
+  }
+  HM_SYNC();
+}
+
+// One predicted sample of `mode` at (x,y), straight from the reference lines in LDS: the same arithmetic as
+// pred_intra above, evaluated per sample so that a lane can own a whole (mode, 8x8 block) SATD task.
+HM_DEV inline int pred_sample(const Shared *e, int mode, int n, int l2, int x, int y, int dcVal, int bitDepth)
+{
+  const int filt = use_filtered_refs(0, mode, n);
+  const Pel *top = e->u.ref.refTop[filt], *left = e->u.ref.refLeft[filt];
+  if (mode == PLANAR_IDX) {
+    const int hor = (left[y + 1] << l2) + n + (x + 1) * (top[n + 1] - left[y + 1]);
+    const int ver = (top[x + 1] << l2) + (y + 1) * (left[n + 1] - top[x + 1]);
+    return (hor + ver) >> (l2 + 1);
+  }
+  if (mode == DC_IDX) {
+    if (n <= 16) {
+      if (x == 0 && y == 0) return (top[1] + left[1] + 2 * dcVal + 2) >> 2;
+      if (y == 0) return (top[x + 1] + 3 * dcVal + 2) >> 2;
+      if (x == 0) return (left[y + 1] + 3 * dcVal + 2) >> 2;
+    }
+    return dcVal;
+  }
+  const int isVer = mode >= 18;
+  const int angMode = isVer ? mode - VER_IDX : -(mode - HOR_IDX);
+  const int absAng = HM_ANG_TABLE[hm_abs(angMode)], invAngle = HM_INV_ANG_TABLE[hm_abs(angMode)];
+  const int angle = angMode < 0 ? -absAng : absAng;
+  const Pel *mainR = isVer ? top : left, *sideR = isVer ? left : top;
+  const int xx = isVer ? x : y, yy = isVer ? y : x;
+  if (angle == 0) {
+    int v = mainR[xx + 1];
+    if (n <= 16 && xx == 0) v = hm_clip3(0, (1 << bitDepth) - 1, v + ((sideR[yy + 1] - sideR[0]) >> 1));
+    return v;
+  }
+  const int deltaPos = (yy + 1) * angle, di = deltaPos >> 5, df = deltaPos & 31;
+  const int i0 = xx + di + 1;
+  const int a = i0 >= 0 ? mainR[i0] : sideR[(128 - i0 * invAngle) >> 8];
+  if (!df) return a;
+  const int i1 = i0 + 1;
+  const int b = i1 >= 0 ? mainR[i1] : sideR[(128 - i1 * invAngle) >> 8];
+  return ((32 - df) * a + df * b + 16) >> 5;
+}
+
+// SATD of all 35 modes of an n x n luma PU (n <= 16): lanes own (mode, 8x8 block) tasks and predict their
+// samples on the fly, so the whole first-pass mode estimation of a small PU is one or a few wave passes.
+HM_DEV HM_NOINLINE void satd_all_modes_small(Shared *e, const Pel *org, int so, int n)
+{
+  const int l2 = hm_log2(n), bitDepth = e->bitDepth;
+  int s = 0;
+  HM_PAR_FOR(i, n) s += e->u.ref.refTop[0][i + 1] + e->u.ref.refLeft[0][i + 1];
+  const int dcVal = (hm_wave_sum_i(s) + n) / (n + n);
+  HM_PAR_FOR(i, 36) e->satd[i] = 0;
+  HM_SYNC();
+  if (n == 4) {
+    HM_PAR_FOR(mode, 35) {
+      int d[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) d[i] = org[(i >> 2) * so + (i & 3)] - pred_sample(e, mode, 4, 2, i & 3, i >> 2, dcVal, bitDepth);
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+        const int a = d[y * 4] + d[y * 4 + 1], b = d[y * 4] - d[y * 4 + 1], c = d[y * 4 + 2] + d[y * 4 + 3], f = d[y * 4 + 2] - d[y * 4 + 3];
+        d[y * 4] = a + c; d[y * 4 + 1] = b + f; d[y * 4 + 2] = a - c; d[y * 4 + 3] = b - f;
+      }
+      uint32_t t = 0;
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const int a = d[x] + d[4 + x], b = d[x] - d[4 + x], c = d[8 + x] + d[12 + x], f = d[8 + x] - d[12 + x];
+        t += (uint32_t)(hm_abs(a + c) + hm_abs(b + f) + hm_abs(a - c) + hm_abs(b - f));
+      }
+      e->satd[mode] = ((t + 1) >> 1) >> (bitDepth - 8);
+    }
+  } else {
+    const int nb = n >> 3;
+    HM_PAR_FOR(task, 35 * nb * nb) {
+      const int mode = task / (nb * nb), b = task - mode * nb * nb, by = (b / nb) * 8, bx = (b % nb) * 8;
+      int d[64];
+#pragma unroll
+      for (int i = 0; i < 64; i++) d[i] = org[(by + (i >> 3)) * so + bx + (i & 7)] - pred_sample(e, mode, n, l2, bx + (i & 7), by + (i >> 3), dcVal, bitDepth);
+#pragma unroll
+      for (int y = 0; y < 8; y++) {
+#pragma unroll
+        for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+          for (int bb = 0; bb < 8; bb += len << 1)
+#pragma unroll
+            for (int k = 0; k < len; k++) { const int a0 = d[y * 8 + bb + k], a1 = d[y * 8 + bb + k + len]; d[y * 8 + bb + k] = a0 + a1; d[y * 8 + bb + k + len] = a0 - a1; }
+      }
+      uint32_t t = 0;
+#pragma unroll
+      for (int x = 0; x < 8; x++) {
+#pragma unroll
+        for (int len = 1; len < 8; len <<= 1)
+#pragma unroll
+          for (int bb = 0; bb < 8; bb += len << 1)
+#pragma unroll
+            for (int k = 0; k < len; k++) { const int a0 = d[(bb + k) * 8 + x], a1 = d[(bb + k + len) * 8 + x]; d[(bb + k) * 8 + x] = a0 + a1; d[(bb + k + len) * 8 + x] = a0 - a1; }
+#pragma unroll
+        for (int y = 0; y < 8; y++) t += (uint32_t)hm_abs(d[y * 8 + x]);
+      }
+      HM_LDS_ADD(&e->satd[mode], (t + 2) >> 2);
+    }
+    HM_SYNC();
+    HM_PAR_FOR(mode, 35) e->satd[mode] >>= (bitDepth - 8);
   }
   HM_SYNC();
 }
@@ -719,7 +847,7 @@ HM_DEV inline int ic_rate(const int32_t *estB, uint32_t absLevel, int ctxOne, in
 HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanType, int cbfCtx)
 {
   const Cabac *cb = &e->cur;
-  const int chroma = comp != 0, log2n = hm_log2(n), bitDepth = e->P->bitDepth;
+  const int chroma = comp != 0, log2n = hm_log2(n), bitDepth = e->bitDepth;
   const double lambda = chroma ? e->fb.lambdaC : e->fb.lambda;
   const int transformShift = 15 - bitDepth - log2n;
   const int qBits = 14 + e->fb.qpPer[chroma] + transformShift;
@@ -994,17 +1122,18 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
   if (n == 4) HM_BIN(C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
   int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->cgFlag;
+  uint16_t *sposArr = (n == 32) ? e->ws->rqPos : e->u.rq.pos;
   HM_PAR_FOR(i, 64) cgFlag[i] = 0;
   HM_SYNC();
   int lastLocal = -1;
   HM_PAR_FOR(sp, n * n) {
     const int blkPos = scan[sp]; const TCoeff v = coef[blkPos];
-    lv[sp] = (int16_t)v;
+    lv[sp] = (int16_t)v; sposArr[sp] = (uint16_t)blkPos;
     if (v != 0) { if (sp > lastLocal) lastLocal = sp; const int py = blkPos >> log2n, px = blkPos - (py << log2n); cgFlag[wg * (py >> 2) + (px >> 2)] = 1; }
   }
   const int scanPosLast = hm_wave_max_i(lastLocal);
   HM_SYNC();
-  const int posLast = scan[scanPosLast];
+  const int posLast = sposArr[scanPosLast];
   {
     int py = posLast >> log2n, px = posLast - (py << log2n);
     if (scanType == SCAN_VER) { const int t = px; px = py; py = t; }
@@ -1024,7 +1153,7 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
   uint32_t c1 = 1; int scanPosSig = scanPosLast;
   for (int subSet = lastScanSet; subSet >= 0; subSet--) {
     int numNonZero = 0; const int subPos = subSet << 4; uint32_t goRice = 0;
-    int absCoeff[16]; int lastNZ = -1, firstNZ = 16; int escape = 0;
+    int32_t *absCoeff = e->absCoeff; int lastNZ = -1, firstNZ = 16; int escape = 0;
     if (scanPosSig == scanPosLast) { absCoeff[0] = hm_abs(lv[scanPosLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
     const int cgBlkPos = scanCG[subSet], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
     if (subSet == lastScanSet || subSet == 0) cgFlag[cgBlkPos] = 1;
@@ -1034,7 +1163,7 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
       for (; scanPosSig >= subPos; scanPosSig--) {
         const int cv = lv[scanPosSig]; const int sig = cv != 0;
         if (scanPosSig > subPos || subSet == 0 || numNonZero)
-          HM_BIN(sigOff + sig_ctx_inc(pattern, firstCtx, scan[scanPosSig], log2n, chroma), sig);
+          HM_BIN(sigOff + sig_ctx_inc(pattern, firstCtx, sposArr[scanPosSig], log2n, chroma), sig);
         if (sig) { absCoeff[numNonZero] = hm_abs(cv); numNonZero++; if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
       }
     } else scanPosSig = subPos - 1;
@@ -1081,7 +1210,8 @@ HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
   for (int j = 0; j < partNum; j++) {
     int preds[3];
     const int dir = m->dirL[z + partOffset * j];
-    intra_dir_predictor(e, z + partOffset * j, preds);
+    if (!multiple && z == e->mpmZ) { preds[0] = e->mpmPreds[0]; preds[1] = e->mpmPreds[1]; preds[2] = e->mpmPreds[2]; }
+    else intra_dir_predictor(e, z + partOffset * j, preds);
     for (int i = 0; i < 3; i++) if (dir == preds[i]) predIdx[j] = i;
     enc_bin(e, c, C_INTRA_LUMA, predIdx[j] != -1);
   }
@@ -1126,14 +1256,13 @@ HM_DEV inline int codes_subdiv_flag(const CtuMeta *m, const TU *t)
 
 // Pre-order walk of the residual quadtree with an explicit stack (no device recursion).
 // The callbacks of the reference's recursive functions become phases of one loop.
-struct TuWalk { TU node[5]; int8_t next[5]; int sp; };
 HM_DEV inline void walk_begin(TuWalk *w, const TU *root) { w->node[0] = *root; w->next[0] = -1; w->sp = 0; }
 
 // xEncSubdivCbfQT, TEncSearch.cpp:856-921
 HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int bChroma)
 {
   const CtuMeta *m = e->cm;
-  TuWalk w; walk_begin(&w, root);
+  TuWalk &w = e->walkInner; walk_begin(&w, root);
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
     const int z = t->cuZ + t->relZ;
@@ -1156,7 +1285,7 @@ HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int b
 HM_DEV inline void enc_coeff_qt(Shared *e, const TU *root, int comp)
 {
   const CtuMeta *m = e->cm;
-  TuWalk w; walk_begin(&w, root);
+  TuWalk &w = e->walkInner; walk_begin(&w, root);
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
     const int z = t->cuZ + t->relZ;
@@ -1189,8 +1318,9 @@ HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChro
   if (bChroma && relZ == 0) code_intra_dir_chroma(e, &e->cur, t->cuZ + relZ);
 }
 // xGetIntraBitsQT, TEncSearch.cpp:1038-1060
-HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU *t, int bLuma, int bChroma)
+HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU tv, int bLuma, int bChroma)
 {
+  const TU *t = &tv;
   HM_PROF_BEGIN(e, PR_BITS);
   reset_bits(&e->cur);
   enc_intra_header(e, t, bLuma, bChroma);
@@ -1204,8 +1334,9 @@ HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU *t, int bLuma, int
 // ------------------------------------------------------------------------------------------------
 // one TU: predict, transform, RDOQ, reconstruct (TEncSearch::xIntraCodingTUBlock :1074-1357)
 // ------------------------------------------------------------------------------------------------
-HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int comp, int save1load2)
+HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU tv, int comp, int save1load2)
 {
+  const TU *t = &tv;
   CtuMeta *m = e->cm; WorkSpace *ws = e->ws;
   if (comp && !t->cW) return 0;
   const int n = comp ? t->cW : (1 << t->log2), l2 = hm_log2(n);
@@ -1213,7 +1344,7 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int co
   const int bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
   const int st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp);
   const int layer = 5 - t->log2, parts = comp ? t->cParts : t->parts;
-  const int ps = e->P->stride[comp], bitDepth = e->P->bitDepth;
+  const int ps = e->stride[comp], bitDepth = e->bitDepth;
   const Pel *org = e->fb.org[comp] + (e->ctuY * st + by) * ps + e->ctuX * st + bx;
   Pel *recPic = e->fb.rec[comp] + (e->ctuY * st + by) * ps + e->ctuX * st + bx;
   Pel *pred = ws->pred + po + by * st + bx, *resi = ws->resi + po + by * st + bx;
@@ -1224,7 +1355,7 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int co
   if (comp && mode == DM_CHROMA_IDX) mode = m->dirL[z & ~3];
   if (save1load2 != 2) {
     const int filt = use_filtered_refs(comp, mode, n);
-    const int r = e->tab->z2r[z];
+    const int r = e->z2r[z];
     { HM_PROF_BEGIN(e, PR_ADI); init_adi_pattern(e, comp, e->ctuX * st + bx, e->ctuY * st + by, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), comp ? n / 2 : n / 4, filt); HM_PROF_END(e, PR_ADI); }
     { HM_PROF_BEGIN(e, PR_PRED); pred_intra(e, comp, mode, n, filt, pred, st); HM_PROF_END(e, PR_PRED); }
     if (save1load2 == 1) { HM_PAR_FOR(i, 16) e->tsPred[comp][i] = pred[(i >> 2) * st + (i & 3)]; HM_SYNC(); }
@@ -1244,6 +1375,9 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU *t, int co
   HM_PROF_BEGIN(e, PR_RDOQ);
   const int absSum = rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx);
   HM_PROF_END(e, PR_RDOQ);
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  { const int pid = l2 == 2 ? (absSum ? 13 : 7) : (l2 == 3 ? 14 : 15); e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }
+#endif
   par_set8(m->cbf[comp] + z, (absSum > 0 ? 1 : 0) << t->trDepth, parts);   // setCbfPartRange, TComTrQuant.cpp:1419
   HM_PROF_BEGIN(e, PR_INV);
   if (absSum > 0) { // invTransformNxN, TComTrQuant.cpp:1423-1545; xDeQuant (flat), :1276-1312
@@ -1298,7 +1432,7 @@ HM_DEV inline void store_intra_result_qt(Shared *e, const TU *t, int comp)
 }
 HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
 {
-  const int st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp), layer = 5 - t->log2, ps = e->P->stride[comp];
+  const int st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp), layer = 5 - t->log2, ps = e->stride[comp];
   const int bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
   TCoeff *coef = e->ws->qtCoef[layer] + po + (comp ? t->cOff : (t->cuZ + t->relZ) * 16);
   Pel *rq = e->ws->qtRec[layer] + po + by * st + bx;
@@ -1310,16 +1444,13 @@ HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
 // ------------------------------------------------------------------------------------------------
 // luma residual quadtree (TEncSearch::xRecurIntraCodingQT :1364-1733, bLumaOnly), explicit stack
 // ------------------------------------------------------------------------------------------------
-struct RqtFrame {
-  TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf; double singleCost, splitCost;
-};
 // returns distortion through *distY and adds the RD cost to *rdCost, exactly like the recursive reference
-HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU *root, uint32_t *distY, int checkFirst, double *rdCost)
+HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int checkFirst)
 {
   CtuMeta *m = e->cm;
-  RqtFrame fr[4]; int sp = 0;
-  uint32_t retDist[5]; double retCost[5];     // accumulators handed to each level by its parent
-  fr[0].t = *root; fr[0].phase = 0; retDist[0] = 0; retCost[0] = 0.0;
+  RqtFrame *fr = e->rqt; int sp = 0;
+  uint32_t *retDist = e->rqtRetDist; double *retCost = e->rqtRetCost;     // accumulators handed to each level by its parent
+  fr[0].t = rootv; fr[0].phase = 0; retDist[0] = 0; retCost[0] = 0.0;
   while (sp >= 0) {
     RqtFrame *f = &fr[sp]; const TU *t = &f->t;
     const int z = t->cuZ + t->relZ, fullDepth = t->cuDepth + t->trDepth, log2 = t->log2;
@@ -1336,10 +1467,10 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU *root, uint32_
           for (int modeId = 0; modeId < 2; modeId++) {
             double costTmp;
             par_set8(m->ts[0] + z, modeId, t->parts);
-            const uint32_t distTmp = intra_coding_tu_block(e, t, 0, modeId == 0 ? 1 : 2);
+            const uint32_t distTmp = intra_coding_tu_block(e, *t, 0, modeId == 0 ? 1 : 2);
             const uint32_t cbfTmp = (m->cbf[0][z] >> t->trDepth) & 1;
             if (modeId == 1 && cbfTmp == 0) costTmp = HM_MAX_DOUBLE;
-            else { const uint32_t bits = intra_bits_qt(e, t, 1, 0); costTmp = calc_rd_cost(e, bits, distTmp); }
+            else { const uint32_t bits = intra_bits_qt(e, *t, 1, 0); costTmp = calc_rd_cost(e, bits, distTmp); }
             if (costTmp < f->singleCost) {
               f->singleCost = costTmp; f->singleDist = distTmp; f->singleCbf = cbfTmp; f->bestModeId = (int8_t)modeId;
               if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->slot[fullDepth][CI_TEMP_BEST], &e->cur); }
@@ -1355,9 +1486,9 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU *root, uint32_
         } else {
           if (f->checkSplit) cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
           par_set8(m->ts[0] + z, 0, t->parts);
-          f->singleDist = intra_coding_tu_block(e, t, 0, 0);
+          f->singleDist = intra_coding_tu_block(e, *t, 0, 0);
           if (f->checkSplit) f->singleCbf = (m->cbf[0][z] >> t->trDepth) & 1;
-          const uint32_t bits = intra_bits_qt(e, t, 1, 0);
+          const uint32_t bits = intra_bits_qt(e, *t, 1, 0);
           f->singleCost = calc_rd_cost(e, bits, f->singleDist);
         }
       }
@@ -1379,7 +1510,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU *root, uint32_
       f->splitDist = retDist[sp + 1];
       if (f->splitCbf) { HM_PAR_FOR(o, t->parts) m->cbf[0][z + o] |= (uint8_t)(1 << t->trDepth); HM_SYNC(); }
       cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]);
-      const uint32_t splitBits = intra_bits_qt(e, t, 1, 0);
+      const uint32_t splitBits = intra_bits_qt(e, *t, 1, 0);
       f->splitCost = calc_rd_cost(e, splitBits, f->splitDist);
       if (f->splitCost < f->singleCost) { retDist[sp] += f->splitDist; retCost[sp] += f->splitCost; sp--; continue; }
       cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_TEST]);
@@ -1387,13 +1518,13 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU *root, uint32_
       par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
       par_set8(m->ts[0] + z, f->bestModeId, t->parts);
       { // reconstruction of the unsplit TU back into the picture for the following blocks
-        const int n = 1 << log2, layer = 5 - log2, ps = e->P->stride[0];
+        const int n = 1 << log2, layer = 5 - log2, ps = e->stride[0];
         par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + t->y) * ps + e->ctuX * 64 + t->x, ps, e->ws->qtRec[layer] + t->y * 64 + t->x, 64, n);
       }
       retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue;
     }
   }
-  *distY += retDist[0]; *rdCost += retCost[0];
+  e->outDistY = retDist[0]; e->outRdCost = retCost[0];
 }
 
 // leaves of the decided residual quadtree inside [relZ0, relZ0+parts0): visit in z order
@@ -1405,7 +1536,7 @@ HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
     const int z = root->cuZ + rel, trd = m->tr[z];
     const int log2 = 6 - root->cuDepth - trd, n = 1 << log2, layer = 5 - log2;
     const int parts = root->cuParts >> (2 * trd) > 0 ? root->cuParts >> (2 * trd) : 1;
-    const int r = e->tab->z2r[z], x = (r & 15) * 4, y = (r >> 4) * 4;
+    const int r = e->z2r[z], x = (r & 15) * 4, y = (r >> 4) * 4;
     par_copy32(e->cc + z * 16, e->ws->qtCoef[layer] + z * 16, n * n);
     par_copy_blk(e->ws->reco + y * 64 + x, 64, e->ws->qtRec[layer] + y * 64 + x, 64, n);
     rel += parts;
@@ -1422,29 +1553,35 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
   const int nxn = m->part[cuZ] == SIZE_NxN;
   const int numPU = nxn ? 4 : 1, puParts = cuParts / numPU;
   const int puLog2 = 6 - cuDepth - nxn, n = 1 << puLog2;
-  const int bitDepth = e->P->bitDepth, ps = e->P->stride[0];
+  const int bitDepth = e->bitDepth, ps = e->stride[0];
   uint32_t overallDistY = 0;
   const TU root = tu_root(e, cuZ, cuDepth);
   for (int pu = 0; pu < numPU; pu++) {
     const TU t = nxn ? tu_child(&root, pu, 0) : root;
     const int z = cuZ + t.relZ;
     int numModesForFullRD = HM_INTRA_MODE_NUM_FAST[puLog2 - 1];
-    int rdModeList[12]; double candCost[12];
+    int32_t *rdModeList = e->rdModeList; double *candCost = e->candCost;
     { // SATD pre-selection over the 35 modes, :2360-2410
-      const int r = e->tab->z2r[z];
+      const int r = e->z2r[z];
       init_adi_pattern(e, 0, e->ctuX * 64 + t.x, e->ctuY * 64 + t.y, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), n / 4, 1);
       for (int i = 0; i < numModesForFullRD; i++) candCost[i] = HM_MAX_DOUBLE;
       const Pel *org = e->fb.org[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x;
       Pel *pred = ws->pred + t.y * 64 + t.x;
       int preds[3];
       const int numMpm = intra_dir_predictor(e, z, preds);
+      e->mpmZ = z; e->mpmNum = numMpm; e->mpmPreds[0] = preds[0]; e->mpmPreds[1] = preds[1]; e->mpmPreds[2] = preds[2];
       // xModeBitsIntra (TEncSearch.cpp:5456-5478) depends only on whether the mode is an MPM and which
       const uint64_t frac0 = e->slot[cuDepth][CI_CURR_BEST].frac & 32767;
       const uint8_t st0 = e->slot[cuDepth][CI_CURR_BEST].s[C_INTRA_LUMA];
       HM_PROF_BEGIN(e, PR_SATD35);
+      if (n <= 16) satd_all_modes_small(e, org, ps, n);
       for (int mode = 0; mode < 35; mode++) {
-        pred_intra(e, 0, mode, n, use_filtered_refs(0, mode, n), pred, 64);
-        const uint32_t sad = dist_hads(org, ps, pred, 64, n, bitDepth);
+        uint32_t sad;
+        if (n <= 16) sad = e->satd[mode];
+        else {
+          pred_intra(e, 0, mode, n, use_filtered_refs(0, mode, n), pred, 64);
+          sad = dist_hads(org, ps, pred, 64, n, bitDepth);
+        }
         int predIdx = -1;
         for (int i = 0; i < 3; i++) if (mode == preds[i]) predIdx = i;
         uint64_t fb = frac0 + (uint64_t)HM_ENTROPY_BITS[st0 ^ (predIdx != -1)];
@@ -1472,8 +1609,8 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       const int orgMode = last ? bestPUMode : rdModeList[pass];
       par_set8(m->dirL + z, orgMode, puParts);
       cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
-      uint32_t puDistY = 0; double puCost = 0.0;
-      recur_intra_coding_qt(e, &t, &puDistY, !last, &puCost);
+      recur_intra_coding_qt(e, t, !last);
+      const uint32_t puDistY = e->outDistY; const double puCost = e->outRdCost;
       if (puCost < bestPUCost) {
         bestPUMode = orgMode; bestPUDistY = puDistY; bestPUCost = puCost;
         set_intra_result_qt(e, &t);
@@ -1487,6 +1624,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
     if (pu != numPU - 1) // reconstruction for the next PU, :2632-2660
       par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x, ps, ws->reco + t.y * 64 + t.x, 64, n);
   }
+  e->mpmZ = -1;
   if (numPU > 1) {
     uint8_t comb[3] = {0, 0, 0};
     for (int p = 0; p < 4; p++) for (int c = 0; c < 3; c++) comb[c] |= (m->cbf[c][cuZ + p * puParts] >> 1) & 1;
@@ -1516,7 +1654,7 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
       par_set8(m->ts[comp] + zc, tsMode, t->cParts);
       currModeId++;
       const int isOne = (total == 1), isLast = (currModeId == total);
-      const uint32_t distTmp = intra_coding_tu_block(e, t, comp, isOne ? 0 : (tsMode == 0 ? 1 : 2));
+      const uint32_t distTmp = intra_coding_tu_block(e, *t, comp, isOne ? 0 : (tsMode == 0 ? 1 : 2));
       const uint32_t cbfTmp = (m->cbf[comp][zc] >> t->trDepth) & 1;
       if (tsMode == 1 && cbfTmp == 0) costTmp = HM_MAX_DOUBLE;
       else if (!isOne) { reset_bits(&e->cur); enc_coeff_qt(e, t, comp); costTmp = calc_rd_cost(e, num_bits(&e->cur), distTmp); }   // xGetIntraBitsQTChroma
@@ -1536,12 +1674,13 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
   }
   return dist;
 }
-HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU *root)
+HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU rootv)
 {
+  const TU *root = &rootv;
   CtuMeta *m = e->cm;
   uint32_t dist = 0;
-  TuWalk w; walk_begin(&w, root);
-  uint8_t splitCbf[5][2];
+  TuWalk &w = e->walkOuter; walk_begin(&w, root);
+  uint8_t (*splitCbf)[2] = e->splitCbf;
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
     const int z = t->cuZ + t->relZ;
@@ -1565,7 +1704,7 @@ HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU *ro
 HM_DEV inline void set_intra_result_chroma_qt(Shared *e, const TU *root)
 {
   const CtuMeta *m = e->cm;
-  TuWalk w; walk_begin(&w, root);
+  TuWalk &w = e->walkOuter; walk_begin(&w, root);
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
     const int z = t->cuZ + t->relZ;
@@ -1595,9 +1734,9 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
   for (int mi = 0; mi < 5; mi++) {
     cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
     par_set8(m->dirC + cuZ, modeList[mi], cuParts);
-    const uint32_t dist = recur_intra_chroma_coding_qt(e, &t);
+    const uint32_t dist = recur_intra_chroma_coding_qt(e, t);
     cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
-    const uint32_t bits = intra_bits_qt(e, &t, 0, 1);
+    const uint32_t bits = intra_bits_qt(e, t, 0, 1);
     const double cost = calc_rd_cost(e, bits, dist);
     if (cost < bestCost) {
       bestCost = cost; bestDist = dist; bestMode = modeList[mi];
@@ -1622,7 +1761,7 @@ HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDep
   code_intra_dir_luma(e, c, cuZ, 1);
   code_intra_dir_chroma(e, c, cuZ);
   const TU root = tu_root(e, cuZ, cuDepth);
-  TuWalk w; walk_begin(&w, &root);
+  TuWalk &w = e->walkOuter; walk_begin(&w, &root);
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
     const int z = t->cuZ + t->relZ;
@@ -1683,7 +1822,7 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
   meta_copy_range(&b->m, e->cm, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) b->coef[cuZ * 16 + i] = e->cc[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { b->coef[4096 + cuZ * 4 + i] = e->cc[4096 + cuZ * 4 + i]; b->coef[5120 + cuZ * 4 + i] = e->cc[5120 + cuZ * 4 + i]; }
-  const int r = e->tab->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
+  const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
   HM_PAR_FOR(i, n * n) { const int yy = i >> l2, xx = i & (n - 1); b->reco[(y + yy) * 64 + x + xx] = e->ws->reco[(y + yy) * 64 + x + xx]; }
   HM_PAR_FOR(i, (n * n) >> 2) {
     const int yy = i >> (l2 - 1), xx = i & ((n >> 1) - 1), o = ((y >> 1) + yy) * 32 + (x >> 1) + xx;
@@ -1698,20 +1837,20 @@ HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
   meta_copy_range(e->cm, &b->m, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = b->coef[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = b->coef[4096 + cuZ * 4 + i]; e->cc[5120 + cuZ * 4 + i] = b->coef[5120 + cuZ * 4 + i]; }
-  const int r = e->tab->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
-  Pel *ry = e->fb.rec[0] + (e->ctuY * 64 + y) * e->P->stride[0] + e->ctuX * 64 + x;
-  HM_PAR_FOR(i, n * n) { const int yy = i >> l2, xx = i & (n - 1); ry[yy * e->P->stride[0] + xx] = b->reco[(y + yy) * 64 + x + xx]; }
-  Pel *ru = e->fb.rec[1] + (e->ctuY * 32 + (y >> 1)) * e->P->stride[1] + e->ctuX * 32 + (x >> 1);
-  Pel *rv = e->fb.rec[2] + (e->ctuY * 32 + (y >> 1)) * e->P->stride[2] + e->ctuX * 32 + (x >> 1);
+  const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
+  Pel *ry = e->fb.rec[0] + (e->ctuY * 64 + y) * e->stride[0] + e->ctuX * 64 + x;
+  HM_PAR_FOR(i, n * n) { const int yy = i >> l2, xx = i & (n - 1); ry[yy * e->stride[0] + xx] = b->reco[(y + yy) * 64 + x + xx]; }
+  Pel *ru = e->fb.rec[1] + (e->ctuY * 32 + (y >> 1)) * e->stride[1] + e->ctuX * 32 + (x >> 1);
+  Pel *rv = e->fb.rec[2] + (e->ctuY * 32 + (y >> 1)) * e->stride[2] + e->ctuX * 32 + (x >> 1);
   HM_PAR_FOR(i, (n * n) >> 2) {
     const int yy = i >> (l2 - 1), xx = i & ((n >> 1) - 1), o = ((y >> 1) + yy) * 32 + (x >> 1) + xx;
-    ru[yy * e->P->stride[1] + xx] = b->reco[4096 + o]; rv[yy * e->P->stride[2] + xx] = b->reco[5120 + o];
+    ru[yy * e->stride[1] + xx] = b->reco[4096 + o]; rv[yy * e->stride[2] + xx] = b->reco[5120 + o];
   }
   HM_SYNC();
 }
 
 // xCheckRDCostIntra, TEncCu.cpp:1574-1646; leaves the trial in place
-HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int partSize, double *cost, uint32_t *bits, uint32_t *dist)
+HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int partSize)
 {
   CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
   init_est_data(e, cuZ, cuDepth);
@@ -1721,40 +1860,40 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
   uint32_t d = est_intra_pred_qt(e, cuZ, cuDepth);
   HM_PROF_END(e, PR_LUMA);
   { // luma reconstruction of the CU into the picture, TEncCu.cpp:1608
-    const int r = e->tab->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, ps = e->P->stride[0];
+    const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, ps = e->stride[0];
     par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + y) * ps + e->ctuX * 64 + x, ps, e->ws->reco + y * 64 + x, 64, n);
   }
   { HM_PROF_BEGIN(e, PR_CHROMA); d += est_intra_pred_chroma_qt(e, cuZ, cuDepth); HM_PROF_END(e, PR_CHROMA); }
   reset_bits(&e->cur);
   { HM_PROF_BEGIN(e, PR_ENCCU); encode_cu_syntax(e, &e->cur, cuZ, cuDepth); HM_PROF_END(e, PR_ENCCU); }
   cabac_copy(&e->slot[cuDepth][CI_TEMP_BEST], &e->cur);
-  *bits = num_bits(&e->cur); *dist = d;
-  *cost = calc_rd_cost(e, *bits, *dist);
+  e->outBits = num_bits(&e->cur); e->outDist = d;
+  e->outCost = calc_rd_cost(e, e->outBits, e->outDist);
 }
 
-struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
 
 // TEncCu::compressCtu -> xCompressCU recursion as a 4-level state machine
-HM_DEV HM_NOINLINE void compress_ctu(Shared *e, double *outCost, uint32_t *outBits, uint32_t *outDist)
+HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 {
   CtuMeta *m = e->cm;
-  CuFrame fr[4]; int sp = 0;
+  CuFrame *fr = e->cuf; int sp = 0;
   fr[0].cuZ = 0; fr[0].phase = 0;
   double retCost = 0; uint32_t retBits = 0, retDist = 0;
   while (sp >= 0) {
     CuFrame *f = &fr[sp]; const int cuDepth = sp, cuZ = f->cuZ;
     const int size = 64 >> cuDepth, parts = 256 >> (2 * cuDepth), q = parts >> 2;
     if (f->phase == 0) {
-      const int r = e->tab->z2r[cuZ];
+      const int r = e->z2r[cuZ];
       const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
-      f->boundary = !((lx + size - 1 < e->P->width) && (ty + size - 1 < e->P->height));
+      f->boundary = !((lx + size - 1 < e->width) && (ty + size - 1 < e->height));
       f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
       if (!f->boundary) {
-        double c; uint32_t b, d;
-        check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N, &c, &b, &d);
+        check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N);
+        double c = e->outCost; uint32_t b = e->outBits, d = e->outDist;
         if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]); }
         if (cuDepth == 3) {
-          check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN, &c, &b, &d);
+          check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN);
+          c = e->outCost; b = e->outBits; d = e->outDist;
           if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]); }
         }
         // split flag of the unsplit candidate, TEncCu.cpp:859-863 (coded on the go-on coder as it stands)
@@ -1770,12 +1909,12 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e, double *outCost, uint32_t *outBi
     if (f->phase == 1) {
       if (f->sub < 4) {
         const int s = f->sub++;
-        const int subZ = cuZ + s * q, r = e->tab->z2r[subZ];
+        const int subZ = cuZ + s * q, r = e->z2r[subZ];
         const int sx = e->ctuX * 64 + (r & 15) * 4, sy = e->ctuY * 64 + (r >> 4) * 4;
         // TComDataCU::initSubCU, TComDataCU.cpp:555-640
         HM_PAR_FOR(i, q) { m->depth[subZ + i] = (uint8_t)(cuDepth + 1); m->part[subZ + i] = SIZE_NONE; m->pred[subZ + i] = MODE_NONE; }
         HM_SYNC();
-        if (sx < e->P->width && sy < e->P->height) {
+        if (sx < e->width && sy < e->height) {
           if (s == 0) cabac_copy(&e->slot[cuDepth + 1][CI_CURR_BEST], &e->slot[cuDepth][CI_CURR_BEST]);
           else cabac_copy(&e->slot[cuDepth + 1][CI_CURR_BEST], &e->slot[cuDepth + 1][CI_NEXT_BEST]);
           fr[sp + 1].cuZ = (int16_t)subZ; fr[sp + 1].phase = 0;
@@ -1800,7 +1939,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e, double *outCost, uint32_t *outBi
       f->splitBits += retBits; f->splitDist += retDist; f->phase = 1; continue;
     }
   }
-  *outCost = retCost; *outBits = retBits; *outDist = retDist;
+  e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
 }
 
 // TEncCu::xEncodeCU, TEncCu.cpp:1185-1295: re-encode the decided CTU to advance the contexts
@@ -1811,15 +1950,15 @@ HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
   stackZ[0] = 0; stackNext[0] = -1;
   while (sp >= 0) {
     const int depth = sp, z = stackZ[sp], size = 64 >> depth;
-    const int r = e->tab->z2r[z];
+    const int r = e->z2r[z];
     const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
-    const int inside = (lx + size - 1 < e->P->width) && (ty + size - 1 < e->P->height);
+    const int inside = (lx + size - 1 < e->width) && (ty + size - 1 < e->height);
     if (stackNext[sp] < 0) {
       if (inside && depth != 3) enc_bin(e, c, C_SPLIT + ctx_split_flag(e, z, depth), m->depth[z] > depth);
       if (!((depth < m->depth[z] && depth < 3) || !inside)) {
         encode_cu_syntax(e, c, z, depth);
         // finishCU, TEncCu.cpp:1130-1147
-        const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->P->width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->P->height);
+        const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->height);
         if (lastX && lastY && !lastCtuOfSlice) enc_trm(e, c, 0);
         sp--; continue;
       }
@@ -1827,9 +1966,9 @@ HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
     }
     if (stackNext[sp] == 4) { sp--; continue; }
     const int s = stackNext[sp]++;
-    const int q = (256 >> (2 * depth)) >> 2, sz = z + s * q, rr = e->tab->z2r[sz];
+    const int q = (256 >> (2 * depth)) >> 2, sz = z + s * q, rr = e->z2r[sz];
     const int sx = e->ctuX * 64 + (rr & 15) * 4, sy = e->ctuY * 64 + (rr >> 4) * 4;
-    if (sx < e->P->width && sy < e->P->height) { stackZ[sp + 1] = (int16_t)sz; stackNext[sp + 1] = -1; sp++; }
+    if (sx < e->width && sy < e->height) { stackZ[sp + 1] = (int16_t)sz; stackNext[sp + 1] = -1; sp++; }
   }
 }
 
@@ -1840,6 +1979,9 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
 {
   // uniform context (every lane writes the same values)
   e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab;
+  e->width = P->width; e->height = P->height; e->bitDepth = P->bitDepth; e->wCtu = P->wCtu; e->mpmZ = -1;
+  for (int c = 0; c < 3; c++) e->stride[c] = P->stride[c];
+  HM_PAR_FOR(i, 256) { e->z2r[i] = P->tab->z2r[i]; e->r2z[i] = P->tab->r2z[i]; }
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
   e->cm = e->fb.meta + e->ctuAddr; e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
   HM_SYNC();
@@ -1869,9 +2011,8 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     }
   } else cabac_copy(cb0, e->fb.endState + (a - 1));
   cabac_copy(&e->cur, cb0);
-  double cost; uint32_t bits, dist;
-  compress_ctu(e, &cost, &bits, &dist);
-  e->fb.stat[a].cost = cost; e->fb.stat[a].bits = bits; e->fb.stat[a].dist = dist;
+  compress_ctu(e);
+  e->fb.stat[a].cost = e->outCost; e->fb.stat[a].bits = e->outBits; e->fb.stat[a].dist = e->outDist;
   // TEncCu::encodeCtu on m_pppcRDSbacCoder[0][CI_CURR_BEST], TEncSlice.cpp:818-825
   reset_bits(cb0);
   encode_ctu(e, cb0, a == numCtus - 1);

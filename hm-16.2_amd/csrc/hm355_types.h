@@ -17,7 +17,7 @@ struct Cabac {
   uint8_t s[168];          // HM_NUM_CTX used, padded to 8-byte multiple
   uint64_t frac;           // TEncBinCABAC::m_fracBits
 };
-enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
+enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };   // TypeDef.h:477-486 minus the unused CI_CHROMA_INTRA
 
 // ---- per-CTU decision arrays, 256 4x4 partitions in z-scan order ----
 struct CtuMeta {

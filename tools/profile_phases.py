@@ -11,7 +11,7 @@ t = time.time(); ms, l = enc.run(F, 32); dt = time.time() - t
 out = (C.c_ulonglong * 32)()
 lib.hm355_read_profile.argtypes = [C.c_void_p, C.c_void_p]
 lib.hm355_read_profile(enc.h_, out)
-names = ["RDOQ", "BITS", "ADI", "PRED", "FWD", "INV", "SATD35", "TUBLK", "SAVE", "CHROMA", "LUMA", "ENCCU", "TOTAL"]
+names = ["RDOQ", "BITS", "ADI", "PRED", "FWD", "INV", "SATD35", "RDOQ4z", "SAVE", "CHROMA", "LUMA", "ENCCU", "TOTAL", "RDOQ4nz", "RDOQ8", "RDOQ16+"]
 tot = out[12]
 print(f"{w}x{h} F={F}: {dt:.2f}s, {enc.num_ctus*F/dt:.1f} CTU/s, per-step {ms/l:.1f} ms")
 for i, n in enumerate(names):
