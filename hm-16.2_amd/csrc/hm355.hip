@@ -19,12 +19,66 @@
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64, 2) hm355_ctu_kernel(const Params *P, const WorkItem *items, int count)
+// Persistent CTU scheduler.  The work list holds every CTU of every picture of the batch in a dependency-
+// respecting (topological) order; a workgroup (one wavefront) repeatedly takes the next ticket, waits until the
+// CTUs it depends on have published their results, searches its CTU and publishes.  Because tickets are taken
+// in topological order and a workgroup only takes a ticket while it is running, the oldest unfinished ticket
+// always has its dependencies satisfied: the grid drains for any grid size and any placement.
+//   dependencies of CTU (x,y):  left (x-1,y);  above-right (x+1,y-1) (above at the right picture edge)  [WPP]
+//                               previous CTU in raster order (CABAC chain)                               [no WPP]
+// Hand-off between workgroups follows the agent-scope release/acquire recipe: all stores of the wave, release
+// fence, s_waitcnt, relaxed flag store; consumer: relaxed poll by one lane, acquire fence, plain loads.
+#define HM_SPIN_TIMEOUT_TICKS (150ull * 100000000ull)   /* 150 s of the 100 MHz wall clock: bounds every spin */
+typedef __attribute__((address_space(1))) unsigned int gu32;   // global address space: never a flat access
+
+// lane 0 polls the flag of one dependency (relaxed, agent scope); returns non-zero when the run must be abandoned
+__device__ __attribute__((noinline)) int hm355_wait_flag(const unsigned int *flag, unsigned int *abortWord, unsigned int epoch)
+{
+  int bad = 0;
+  if (threadIdx.x == 0) {
+    const gu32 *f = (const gu32 *)flag; gu32 *ab = (gu32 *)abortWord;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      __builtin_amdgcn_s_sleep(32);
+      if (__hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > HM_SPIN_TIMEOUT_TICKS) {
+        __hip_atomic_store(ab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tell everybody to drain
+        bad = 1; break;
+      }
+    }
+  }
+  return __shfl(bad, 0, 64);
+}
+
+extern "C" __global__ void __launch_bounds__(64, 2) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
 {
   __shared__ Shared sh;
-  const int b = (int)blockIdx.x;
-  if (b >= count) return;
-  process_ctu(&sh, P, items + b, b);
+  __shared__ WorkItem curItem;
+  for (;;) {
+    int idx = 0;
+    if (threadIdx.x == 0) idx = (int)atomicAdd(&sched[0], 1u);
+    idx = __shfl(idx, 0, 64);
+    if (idx >= total) break;
+    if (threadIdx.x == 0) curItem = items[idx];
+    __syncthreads();
+    const int cx = curItem.ctuX, cy = curItem.ctuY, wCtu = P->wCtu;
+    const unsigned int *done = P->frames[curItem.frame].done;
+    const int a = cy * wCtu + cx;
+    int dep0 = -1, dep1 = -1;
+    if (P->wpp) {
+      if (cx > 0) dep0 = a - 1;
+      if (cy > 0) dep1 = (cy - 1) * wCtu + (cx + 1 < wCtu ? cx + 1 : cx);
+    } else if (a > 0) dep0 = a - 1;
+    int bad = 0;
+    if (dep0 >= 0) bad = hm355_wait_flag(done + dep0, sched + 1, epoch);
+    if (!bad && dep1 >= 0) bad = hm355_wait_flag(done + dep1, sched + 1, epoch);
+    if (bad) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    process_ctu(&sh, P, &curItem, (int)blockIdx.x);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
 }
 
 // batched distortion primitives: one wavefront per n x n block pair
@@ -70,6 +124,7 @@ struct hm355_ctx {
   FrameBuf *dFrames;
   WorkSpace *dWs; size_t wsCount;
   WorkItem *dItems; size_t itemsCap;
+  unsigned int *dSched; unsigned int epoch;
   std::vector<Slot> slots;
   std::vector<WorkItem> items; std::vector<int> stepStart; int schedFrames;
   hipStream_t stream; hipEvent_t ev0, ev1;
@@ -105,7 +160,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
   c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0;
-  c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0;
+  c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
   P.wCtu = (cfg->width + 63) / 64; P.hCtu = (cfg->height + 63) / 64;
@@ -119,7 +174,9 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   if (e == hipSuccess) e = hipMemcpy(c->dTab, ht, sizeof(Tables), hipMemcpyHostToDevice);
   delete ht;
   HM_CHECK(c, e);
-  c->wsCount = (size_t)maxItemsPerStep(P.wCtu, P.hCtu, P.wpp, cfg->max_batch);
+  // one scratch area per resident workgroup of the persistent grid: 256 CUs x 8 single-wave workgroups, or fewer when the batch is small
+  c->wsCount = (size_t)c->numCtus * (size_t)cfg->max_batch; if (c->wsCount > 2048) c->wsCount = 2048;
+  HM_CHECK(c, hipMalloc((void **)&c->dSched, 64)); HM_CHECK(c, hipMemset(c->dSched, 0, 64));
   HM_CHECK(c, hipMalloc((void **)&c->dWs, c->wsCount * sizeof(WorkSpace)));
   HM_CHECK(c, hipMalloc((void **)&c->dFrames, sizeof(FrameBuf) * cfg->max_batch));
   HM_CHECK(c, hipMalloc((void **)&c->dP, sizeof(Params)));
@@ -135,6 +192,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
     HM_CHECK(c, hipMalloc((void **)&fb.coef, sizeof(TCoeff) * (size_t)c->numCtus * HM_COEF_CTU));
     HM_CHECK(c, hipMalloc((void **)&fb.stat, sizeof(CtuStat) * c->numCtus));
     HM_CHECK(c, hipMalloc((void **)&fb.endState, sizeof(Cabac) * c->numCtus));
+    HM_CHECK(c, hipMalloc((void **)&fb.done, sizeof(uint32_t) * c->numCtus)); HM_CHECK(c, hipMemset(fb.done, 0, sizeof(uint32_t) * c->numCtus));
   }
   P.tab = c->dTab; P.ws = c->dWs; P.frames = c->dFrames; P.prof = NULL;
 #ifdef HM355_PROFILE
@@ -150,9 +208,9 @@ extern "C" void hm355_destroy(hm355_ctx *c)
   for (size_t s = 0; s < c->slots.size(); s++) {
     FrameBuf &fb = c->slots[s].fb;
     for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
-    if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState);
+    if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState); if (fb.done) hipFree(fb.done);
   }
-  if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems);
+  if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems); if (c->dSched) hipFree(c->dSched);
   if (c->staging) hipHostFree(c->staging);
   if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -194,21 +252,21 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
     HM_CHECK(c, hipMemcpyAsync(c->dItems, c->items.data(), sizeof(WorkItem) * c->items.size(), hipMemcpyHostToDevice, c->stream));
     c->schedFrames = n;
   }
+  c->epoch++; if (c->epoch == 0) c->epoch = 1;
+  HM_CHECK(c, hipMemsetAsync(c->dSched, 0, 64, c->stream));        // ticket = 0, abort = 0
   HM_CHECK(c, hipStreamSynchronize(c->stream));   // fbs / items must stay valid until copied
   HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
-  const int steps = (int)c->stepStart.size() - 1;
-  int launches = 0;
-  for (int s = 0; s < steps; s++) {
-    const int start = c->stepStart[s], count = c->stepStart[s + 1] - start;
-    if (count <= 0) continue;
-    if ((size_t)count > c->wsCount) return fail(c, HM355_ERR_DEVICE, "internal: step larger than workspace");
-    hipLaunchKernelGGL(hm355_ctu_kernel, dim3(count), dim3(64), 0, c->stream, (const Params *)c->dP, (const WorkItem *)(c->dItems + start), count);
-    launches++;
-  }
+  const int total = (int)c->items.size();
+  const int grid = total < (int)c->wsCount ? total : (int)c->wsCount;
+  int launches = 1;
+  hipLaunchKernelGGL(hm355_ctu_kernel, dim3(grid), dim3(64), 0, c->stream, (const Params *)c->dP, (const WorkItem *)c->dItems, total, c->dSched, c->epoch);
   HM_CHECK(c, hipGetLastError());
   HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
   HM_CHECK(c, hipStreamSynchronize(c->stream));
   float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  unsigned int sched[2] = {0, 0};
+  HM_CHECK(c, hipMemcpy(sched, c->dSched, sizeof(sched), hipMemcpyDeviceToHost));
+  if (sched[1] != 0) return fail(c, HM355_ERR_DEVICE, "scheduler aborted: a dependency wait timed out");
   c->lastKernelMs = ms; c->lastLaunches = launches;
   return HM355_OK;
 }

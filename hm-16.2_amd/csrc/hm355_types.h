@@ -63,6 +63,7 @@ struct FrameBuf {
   TCoeff *coef;                      // [numCtus][HM_COEF_CTU]
   CtuStat *stat;                     // [numCtus]
   Cabac *endState;                   // [numCtus] estimator state after encodeCtu of that CTU
+  uint32_t *done;                    // [numCtus] == run epoch once the CTU's results are published (persistent scheduler)
   // slice parameters (TEncSlice::setUpLambda, TEncSlice.cpp:132-159)
   double lambda, sqrtLambda, lambdaC, chromaWeight;
   double errScale[2][4];             // [luma/chroma][log2-2]  TComTrQuant::setErrScaleCoeff :2933
