@@ -166,6 +166,7 @@ struct RqLds {                         // indexed by scan position
   uint16_t pos[HM_RQ_LDS];             // raster position | sign << 15
   uint16_t dec[HM_RQ_LDS];             // level at decision time
   int16_t cur[HM_RQ_LDS];              // working / final level
+  double costCoeff[HM_RQ_LDS];         // cost of the positions that keep a non-zero level
   uint8_t ctxSig[HM_RQ_LDS];           // significance context
   uint8_t code[HM_RQ_LDS];             // significance cost of the position: 0 none, 1 bits(ctx,0), 2 bits(ctx,1)
 };
@@ -209,7 +210,8 @@ struct Shared {
   // uniform per-CTU context
   int32_t width, height, bitDepth, wCtu, stride[3];
   const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
-  CtuMeta *cm; TCoeff *cc;
+  CtuMeta meta;                        // decision arrays of the CTU under search (written back to HBM at the end)
+  TCoeff *cc;
   int32_t ctuX, ctuY, ctuAddr;
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   unsigned long long prof[HM_PROF_N]; unsigned long long profCnt[HM_PROF_N];
@@ -441,7 +443,7 @@ HM_DEV inline TU tu_child(const TU *p, int section, int processLast)
 // neighbour helpers
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline const CtuMeta *meta_at(const Shared *e, int x4, int y4, int *z)
-{ *z = e->r2z[((y4 & 15) << 4) | (x4 & 15)]; return e->fb.meta + ((y4 >> 4) * e->wCtu + (x4 >> 4)); }
+{ *z = e->r2z[((y4 & 15) << 4) | (x4 & 15)]; const int ca = (y4 >> 4) * e->wCtu + (x4 >> 4); return ca == e->ctuAddr ? &e->meta : e->fb.meta + ca; }
 
 // TComDataCU::getIntraDirPredictor, TComDataCU.cpp:1513-1586 (luma)
 HM_DEV inline int intra_dir_predictor(const Shared *e, int z, int preds[3])
@@ -859,8 +861,8 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   const int sigOff = C_SIG + (chroma ? 28 : 0);
   const int32_t *src = e->bufA;
   const int32_t *estB = e->estB;
-  double *costCoeff = e->ws->costCoeff;
   WorkSpace *ws = e->ws;
+  double *costCoeff = (n == 32) ? ws->costCoeff : e->u.rq.costCoeff;
   int32_t *rqLvl = (n == 32) ? ws->rqLvl : e->u.rq.lvl;
   uint16_t *rqPos = (n == 32) ? ws->rqPos : e->u.rq.pos, *rqDec = (n == 32) ? ws->rqDec : e->u.rq.dec;
   int16_t *rqCur = (n == 32) ? ws->rqCur : e->u.rq.cur;
@@ -1203,7 +1205,7 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
 // TEncSbac::codeIntraDirLumaAng, TEncSbac.cpp:636-690
 HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
 {
-  const CtuMeta *m = e->cm;
+  const CtuMeta *m = (&e->meta);
   const int partNum = multiple ? (m->part[z] == SIZE_NxN ? 4 : 1) : 1;
   const int partOffset = (256 >> (m->depth[z] << 1)) >> 2;
   int predIdx[4] = {-1, -1, -1, -1};
@@ -1223,7 +1225,7 @@ HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
 // TEncSbac::codeIntraDirChroma, TEncSbac.cpp:692-718
 HM_DEV inline void code_intra_dir_chroma(Shared *e, Cabac *c, int z)
 {
-  if (e->cm->dirC[z] == DM_CHROMA_IDX) enc_bin(e, c, C_CHROMA_PRED, 0);
+  if ((&e->meta)->dirC[z] == DM_CHROMA_IDX) enc_bin(e, c, C_CHROMA_PRED, 0);
   else { enc_bin(e, c, C_CHROMA_PRED, 1); enc_ep(c, 2); }
 }
 // TEncSbac::codeQtCbf, TEncSbac.cpp:911-960 (square TUs)
@@ -1234,7 +1236,7 @@ HM_DEV inline void code_qt_cbf(Shared *e, Cabac *c, const TU *t, int comp, int l
   const int width = comp ? (1 << (t->log2 - 1)) : (1 << t->log2);
   const int canQuadSplit = width >= 8;
   const int lowestTUDepth = t->trDepth + ((!lowestLevel && !canQuadSplit) ? 1 : 0);
-  enc_bin(e, c, C_QT_CBF + (comp ? 5 : 0) + ctx, (e->cm->cbf[comp][z] >> lowestTUDepth) & 1);
+  enc_bin(e, c, C_QT_CBF + (comp ? 5 : 0) + ctx, ((&e->meta)->cbf[comp][z] >> lowestTUDepth) & 1);
 }
 
 HM_DEV inline int tr_min_size_in_cu(int cuLog2, int nxn)
@@ -1261,7 +1263,7 @@ HM_DEV inline void walk_begin(TuWalk *w, const TU *root) { w->node[0] = *root; w
 // xEncSubdivCbfQT, TEncSearch.cpp:856-921
 HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int bChroma)
 {
-  const CtuMeta *m = e->cm;
+  const CtuMeta *m = (&e->meta);
   TuWalk &w = e->walkInner; walk_begin(&w, root);
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
@@ -1284,7 +1286,7 @@ HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int b
 // xEncCoeffQT, TEncSearch.cpp:926-960 (coefficients from the QT layer buffers)
 HM_DEV inline void enc_coeff_qt(Shared *e, const TU *root, int comp)
 {
-  const CtuMeta *m = e->cm;
+  const CtuMeta *m = (&e->meta);
   TuWalk &w = e->walkInner; walk_begin(&w, root);
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
@@ -1309,7 +1311,7 @@ HM_DEV inline void enc_coeff_qt(Shared *e, const TU *root, int comp)
 // xEncIntraHeader, TEncSearch.cpp:965-1032 (I slice, no PCM)
 HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChroma)
 {
-  const CtuMeta *m = e->cm; const int relZ = t->relZ;
+  const CtuMeta *m = (&e->meta); const int relZ = t->relZ;
   if (bLuma) {
     if (relZ == 0 && t->cuDepth == 3) enc_bin(e, &e->cur, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
     if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, &e->cur, t->cuZ, 0); }
@@ -1337,7 +1339,7 @@ HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU tv, int bLuma, int
 HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU tv, int comp, int save1load2)
 {
   const TU *t = &tv;
-  CtuMeta *m = e->cm; WorkSpace *ws = e->ws;
+  CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
   if (comp && !t->cW) return 0;
   const int n = comp ? t->cW : (1 << t->log2), l2 = hm_log2(n);
   const int relZ = comp ? t->cRelZ : t->relZ, z = t->cuZ + relZ;
@@ -1447,7 +1449,7 @@ HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
 // returns distortion through *distY and adds the RD cost to *rdCost, exactly like the recursive reference
 HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int checkFirst)
 {
-  CtuMeta *m = e->cm;
+  CtuMeta *m = (&e->meta);
   RqtFrame *fr = e->rqt; int sp = 0;
   uint32_t *retDist = e->rqtRetDist; double *retCost = e->rqtRetCost;     // accumulators handed to each level by its parent
   fr[0].t = rootv; fr[0].phase = 0; retDist[0] = 0; retCost[0] = 0.0;
@@ -1531,7 +1533,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
 // xSetIntraResultQT, TEncSearch.cpp:1737-1788 (luma)
 HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
 {
-  const CtuMeta *m = e->cm;
+  const CtuMeta *m = (&e->meta);
   for (int rel = root->relZ; rel < root->relZ + root->parts;) {
     const int z = root->cuZ + rel, trd = m->tr[z];
     const int log2 = 6 - root->cuDepth - trd, n = 1 << log2, layer = 5 - log2;
@@ -1548,7 +1550,7 @@ HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
 // ------------------------------------------------------------------------------------------------
 HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
 {
-  CtuMeta *m = e->cm; WorkSpace *ws = e->ws;
+  CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
   const int cuParts = 256 >> (2 * cuDepth);
   const int nxn = m->part[cuZ] == SIZE_NxN;
   const int numPU = nxn ? 4 : 1, puParts = cuParts / numPU;
@@ -1640,7 +1642,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
 { // the leaf part of xRecurIntraChromaCodingQT
-  CtuMeta *m = e->cm; const int z = t->cuZ + t->relZ;
+  CtuMeta *m = (&e->meta); const int z = t->cuZ + t->relZ;
   const int fullDepth = t->cuDepth + t->trDepth;
   int checkTS = (t->cW == 4) && (t->log2 == 2);
   if (checkTS) { int nb = 0; for (int s = 0; s < 4; s++) nb += m->ts[0][z + s]; checkTS = nb > 0; }
@@ -1677,7 +1679,7 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
 HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU rootv)
 {
   const TU *root = &rootv;
-  CtuMeta *m = e->cm;
+  CtuMeta *m = (&e->meta);
   uint32_t dist = 0;
   TuWalk &w = e->walkOuter; walk_begin(&w, root);
   uint8_t (*splitCbf)[2] = e->splitCbf;
@@ -1703,7 +1705,7 @@ HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU roo
 // xSetIntraResultChromaQT, TEncSearch.cpp:2150-2200: visit the chroma leaves
 HM_DEV inline void set_intra_result_chroma_qt(Shared *e, const TU *root)
 {
-  const CtuMeta *m = e->cm;
+  const CtuMeta *m = (&e->meta);
   TuWalk &w = e->walkOuter; walk_begin(&w, root);
   while (w.sp >= 0) {
     TU *t = &w.node[w.sp];
@@ -1726,7 +1728,7 @@ HM_DEV inline void set_intra_result_chroma_qt(Shared *e, const TU *root)
 }
 HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuDepth)
 {
-  CtuMeta *m = e->cm; WorkSpace *ws = e->ws; const int cuParts = 256 >> (2 * cuDepth);
+  CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws; const int cuParts = 256 >> (2 * cuDepth);
   const TU t = tu_root(e, cuZ, cuDepth);
   int bestMode = 0; uint32_t bestDist = 0; double bestCost = HM_MAX_DOUBLE;
   int modeList[5] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX, DM_CHROMA_IDX};       // getAllowedChromaDir, TComDataCU.cpp:1486
@@ -1756,7 +1758,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
 // ------------------------------------------------------------------------------------------------
 HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDepth)
 { // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
-  const CtuMeta *m = e->cm;
+  const CtuMeta *m = (&e->meta);
   if (cuDepth == 3) enc_bin(e, c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
   code_intra_dir_luma(e, c, cuZ, 1);
   code_intra_dir_chroma(e, c, cuZ);
@@ -1797,7 +1799,7 @@ HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDep
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline void init_est_data(Shared *e, int cuZ, int cuDepth)
 { // TComDataCU::initEstData, TComDataCU.cpp:484-552
-  CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
+  CtuMeta *m = (&e->meta); const int parts = 256 >> (2 * cuDepth);
   HM_PAR_FOR(i, parts) {
     const int z = cuZ + i;
     m->depth[z] = (uint8_t)cuDepth; m->part[z] = SIZE_NONE; m->pred[z] = MODE_NONE; m->dirL[z] = DC_IDX; m->dirC[z] = 0; m->tr[z] = 0;
@@ -1819,7 +1821,7 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
 {
   HM_PROF_BEGIN(e, PR_SAVE);
   Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
-  meta_copy_range(&b->m, e->cm, cuZ, parts);
+  meta_copy_range(&b->m, (&e->meta), cuZ, parts);
   HM_PAR_FOR(i, parts * 16) b->coef[cuZ * 16 + i] = e->cc[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { b->coef[4096 + cuZ * 4 + i] = e->cc[4096 + cuZ * 4 + i]; b->coef[5120 + cuZ * 4 + i] = e->cc[5120 + cuZ * 4 + i]; }
   const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
@@ -1834,7 +1836,7 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
 HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
 { // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
   const Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
-  meta_copy_range(e->cm, &b->m, cuZ, parts);
+  meta_copy_range((&e->meta), &b->m, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = b->coef[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = b->coef[4096 + cuZ * 4 + i]; e->cc[5120 + cuZ * 4 + i] = b->coef[5120 + cuZ * 4 + i]; }
   const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
@@ -1852,7 +1854,7 @@ HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
 // xCheckRDCostIntra, TEncCu.cpp:1574-1646; leaves the trial in place
 HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int partSize)
 {
-  CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
+  CtuMeta *m = (&e->meta); const int parts = 256 >> (2 * cuDepth);
   init_est_data(e, cuZ, cuDepth);
   HM_PAR_FOR(i, parts) { m->part[cuZ + i] = (uint8_t)partSize; m->pred[cuZ + i] = MODE_INTRA; }
   HM_SYNC();
@@ -1875,7 +1877,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
 // TEncCu::compressCtu -> xCompressCU recursion as a 4-level state machine
 HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 {
-  CtuMeta *m = e->cm;
+  CtuMeta *m = (&e->meta);
   CuFrame *fr = e->cuf; int sp = 0;
   fr[0].cuZ = 0; fr[0].phase = 0;
   double retCost = 0; uint32_t retBits = 0, retDist = 0;
@@ -1945,7 +1947,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 // TEncCu::xEncodeCU, TEncCu.cpp:1185-1295: re-encode the decided CTU to advance the contexts
 HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
 {
-  const CtuMeta *m = e->cm;
+  const CtuMeta *m = (&e->meta);
   int16_t stackZ[4]; int8_t stackNext[4]; int sp = 0;
   stackZ[0] = 0; stackNext[0] = -1;
   while (sp >= 0) {
@@ -1983,7 +1985,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   for (int c = 0; c < 3; c++) e->stride[c] = P->stride[c];
   HM_PAR_FOR(i, 256) { e->z2r[i] = P->tab->z2r[i]; e->r2z[i] = P->tab->r2z[i]; }
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
-  e->cm = e->fb.meta + e->ctuAddr; e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
+  e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
   HM_SYNC();
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   for (int i = 0; i < HM_PROF_N; i++) { e->prof[i] = 0; e->profCnt[i] = 0; }
@@ -1992,7 +1994,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   load_tmat(e);
   const int a = e->ctuAddr, numCtus = P->wCtu * P->hCtu;
   { // TComDataCU::initCtu, TComDataCU.cpp:357-470
-    CtuMeta *m = e->cm;
+    CtuMeta *m = (&e->meta);
     HM_PAR_FOR(z, 256) {
       m->depth[z] = 0; m->part[z] = SIZE_NONE; m->pred[z] = MODE_NONE; m->dirL[z] = DC_IDX; m->dirC[z] = 0; m->tr[z] = 0;
       for (int c = 0; c < 3; c++) { m->cbf[c][z] = 0; m->ts[c][z] = 0; }
@@ -2017,6 +2019,11 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   reset_bits(cb0);
   encode_ctu(e, cb0, a == numCtus - 1);
   cabac_copy(e->fb.endState + a, cb0);
+  { // decision arrays back to HBM (TComDataCU::copyToPic of the whole CTU)
+    const uint32_t *src = (const uint32_t *)&e->meta; uint32_t *dst = (uint32_t *)(e->fb.meta + a);
+    HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];
+    HM_SYNC();
+  }
   HM_PROF_END(e, PR_TOTAL);
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   if (hm_lane() == 0 && P->prof) for (int i = 0; i < HM_PROF_N; i++) { atomicAdd(P->prof + i, e->prof[i]); atomicAdd(P->prof + HM_PROF_N + i, e->profCnt[i]); }

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path[:0]=['hm-16.2_amd']
+import os; sys.path[:0]=[os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),'hm-16.2_amd')]
 import hm355, synth
 w,h,bd,F=int(sys.argv[1]),int(sys.argv[2]),10,int(sys.argv[3])
 enc=hm355.Encoder(w,h,bd,1,F)
