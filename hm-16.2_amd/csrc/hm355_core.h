@@ -18,6 +18,7 @@
 //
 // What it restates (file:line under /root/reference/source/Lib): see each function.
 #pragma once
+#include <stddef.h>
 #include "hm355_types.h"
 
 #ifdef HM355_HOSTSIM
@@ -27,6 +28,8 @@
 #define HM_DEV static
 #define HM_NOINLINE __attribute__((noinline))
 #define HM_CONST static const
+#define HM_ASSUME_LDS(p) ((void)0)
+#define HM_ASSUME_GLB(p) ((void)0)
 #define HM_NT 1
 static inline int hm_lane() { return 0; }
 #define HM_SYNC() ((void)0)
@@ -44,6 +47,15 @@ static inline int hm_wave_max_i(int v) { return v; }
 #define HM_DEV __device__
 #define HM_NOINLINE __attribute__((noinline))
 #define HM_CONST __device__ const
+/// address-space facts for pointers that arrive as generic function arguments / loaded values: lets the compiler
+// emit ds_* / global_* instead of flat_* accesses
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HM_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
+#define HM_ASSUME_GLB(p) __builtin_assume(!__builtin_amdgcn_is_shared((const void *)(p)) && !__builtin_amdgcn_is_private((const void *)(p)))
+#else
+#define HM_ASSUME_LDS(p) ((void)0)
+#define HM_ASSUME_GLB(p) ((void)0)
+#endif
 #define HM_NT 64
 __device__ __forceinline__ int hm_lane() { return (int)threadIdx.x; }
 // one wavefront per CTU: lanes run in lockstep, so a phase boundary only has to order this wave's own LDS /
@@ -103,11 +115,7 @@ enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBL
 // constant tables
 // ------------------------------------------------------------------------------------------------
 // ContextModel.cpp:66-128 (FAST_BIT_EST)
-HM_CONST uint8_t HM_NEXT_MPS[128] = {
-  2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33,
-  34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65,
-  66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97,
-  98, 99, 100, 101, 102, 103, 104, 105, 106, 107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 124, 125, 126, 127 };
+// (the MPS transition is arithmetic: hm_next_state)
 HM_CONST uint8_t HM_NEXT_LPS[128] = {
   1, 0, 0, 1, 2, 3, 4, 5, 4, 5, 8, 9, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 18, 19, 22, 23, 22, 23, 24, 25,
   26, 27, 26, 27, 30, 31, 30, 31, 32, 33, 32, 33, 36, 37, 36, 37, 38, 39, 38, 39, 42, 43, 42, 43, 44, 45, 44, 45, 46, 47, 48, 49,
@@ -166,18 +174,25 @@ struct RqLds {                         // indexed by scan position
   uint16_t pos[HM_RQ_LDS];             // raster position | sign << 15
   uint16_t dec[HM_RQ_LDS];             // level at decision time
   int16_t cur[HM_RQ_LDS];              // working / final level
-  double costCoeff[HM_RQ_LDS];         // cost of the positions that keep a non-zero level
   uint8_t ctxSig[HM_RQ_LDS];           // significance context
   uint8_t code[HM_RQ_LDS];             // significance cost of the position: 0 none, 1 bits(ctx,0), 2 bits(ctx,1)
+  // per coefficient group (all block sizes)
+  double cgC0[16], cgCoef[16], cgSigC[16];   // per-position costs of the current group (zero-level hypothesis)
+  double costCGSig[64];
+  uint16_t cgMax[16];
+  uint8_t cgCtxSet[64];                // context set each coefficient group started with
+  uint8_t cgFlag[64];
 };
 struct RefLds {
   Pel refTop[2][132], refLeft[2][132]; // [filtered][0 = corner, 1..2N]
   Pel refMain[200], refSide[200];      // angular: extended main / side reference, origin at +64
   Pel line[272];
 };
+// slot index: CI_CURR_BEST / CI_NEXT_BEST are never addressed at depth 4
+#define HM_SLOT(d, ci) ((d) * CI_NUM + (ci) - ((d) == 4 ? 2 : 0))
 struct Shared {
   Cabac cur;                           // m_pcRDGoOnSbacCoder
-  Cabac slot[5][CI_NUM];               // m_pppcRDSbacCoder[depth][CI_*]
+  Cabac slotArr[4 * CI_NUM + 3];       // m_pppcRDSbacCoder[depth][CI_*]; depth 4 (4x4 TUs of an 8x8 CU) only uses TEMP_BEST/QT_TRAFO_*
   int8_t tmat[32 * HM_TSTRIDE];        // 32-point transform matrix, padded rows
   int32_t bufA[32 * HM_TSTRIDE];
   union {                              // phase-exclusive LDS: transform temp | RDOQ state | intra reference samples
@@ -188,15 +203,7 @@ struct Shared {
   Pel tsPred[3][16], tsRec[3][16];     // transform-skip trial of a 4x4 block
   TCoeff tsCoef[3][16];
   uint8_t flags[72];
-  int32_t entBits[128];                // ContextModel::m_entropyBits staged in LDS
-  uint8_t nextSt[256];                 // [state*2 + bin] -> next state
   int32_t estB[HM_NUM_CTX * 2 + 2];    // bit cost of (context, bin) for the current estimator state
-  uint8_t cgCtxSet[64];                // context set each coefficient group started with
-  double cgC0[16], cgCoef[16], cgSigC[16];   // per-position costs of the current group (zero-level hypothesis)
-  uint16_t cgMax[16];
-  double costCGSig[64];
-  uint8_t cgFlag[64];
-  uint8_t z2r[256], r2z[256];          // z-scan <-> raster of the 4x4 partitions
   TuWalk walkOuter, walkInner;         // tree-walk stacks
   RqtFrame rqt[4]; uint32_t rqtRetDist[5]; double rqtRetCost[5];
   CuFrame cuf[4];
@@ -218,8 +225,23 @@ struct Shared {
 #endif
 };
 
+#if !defined(HM355_PROFILE)
+static_assert(sizeof(Shared) <= 20480, "Shared must stay within 1/8 of a CU's 160 KB LDS (8 CTU searches per CU)");
+#endif
+static_assert(offsetof(Shared, bufA) % 8 == 0 && (16 * HM_TSTRIDE * 4) % 8 == 0, "the RDOQ cost array aliases the lower half of bufA as doubles");
+
 HM_DEV inline int hm_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 HM_DEV inline int hm_abs(int v) { return v < 0 ? -v : v; }
+// z-scan <-> raster order of the 256 4x4 partitions of a CTU (g_auiZscanToRaster / g_auiRasterToZscan, TComRom.cpp:52-86):
+// z interleaves the bits of (y4, x4), x in the even positions
+HM_DEV inline int hm_z2r(int z)
+{
+  const int x = (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8);
+  const int y = ((z >> 1) & 1) | ((z >> 2) & 2) | ((z >> 3) & 4) | ((z >> 4) & 8);
+  return (y << 4) | x;
+}
+HM_DEV inline int hm_spread4(int v) { return (v & 1) | ((v & 2) << 1) | ((v & 4) << 2) | ((v & 8) << 3); }
+HM_DEV inline int hm_r2z(int r) { return hm_spread4(r & 15) | (hm_spread4(r >> 4) << 1); }
 HM_DEV inline int hm_log2(int n) { return n >= 64 ? 6 : (n >= 32 ? 5 : (n >= 16 ? 4 : (n >= 8 ? 3 : 2))); }
 
 // lane-parallel byte fill / copies (uniform arguments)
@@ -257,14 +279,16 @@ HM_DEV inline void cabac_init(Cabac *c, int qp)
   c->frac = 0;
   HM_SYNC();
 }
+// next context state (ContextModel::updateMPS/updateLPS): the MPS transition is +2 saturating at state 62
+HM_DEV inline int hm_next_state(int st, int bin) { return bin == (st & 1) ? (st < 124 ? st + 2 : st) : HM_NEXT_LPS[st]; }
 HM_DEV inline void enc_bin(const Shared *e, Cabac *c, int ctx, int bin)
 {
   const int st = c->s[ctx];
-  c->frac += (uint64_t)e->entBits[st ^ bin];
-  c->s[ctx] = e->nextSt[st * 2 + bin];
+  c->frac += (uint64_t)HM_ENTROPY_BITS[st ^ bin];
+  c->s[ctx] = hm_next_state(st, bin);
 }
 HM_DEV inline void enc_ep(Cabac *c, int n) { c->frac += (uint64_t)32768 * (uint64_t)n; }
-HM_DEV inline void enc_trm(const Shared *e, Cabac *c, int bin) { c->frac += (uint64_t)e->entBits[126 ^ bin]; }
+HM_DEV inline void enc_trm(const Shared *e, Cabac *c, int bin) { c->frac += (uint64_t)HM_ENTROPY_BITS[126 ^ bin]; }
 HM_DEV inline void reset_bits(Cabac *c) { c->frac &= 32767; }           // TEncBinCoderCABAC.cpp:161
 HM_DEV inline uint32_t num_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
 
@@ -355,7 +379,6 @@ HM_DEV inline uint32_t dist_sad(const Pel *org, int so, const Pel *cur, int sc, 
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline void load_tmat(Shared *e)
 {
-  HM_PAR_FOR(i, 128) { e->entBits[i] = HM_ENTROPY_BITS[i]; e->nextSt[i * 2 + (i & 1)] = HM_NEXT_MPS[i]; e->nextSt[i * 2 + ((i & 1) ^ 1)] = HM_NEXT_LPS[i]; }
   HM_PAR_FOR(i, 1024) {
     const int k = i >> 5, n = i & 31, m = (k * (2 * n + 1)) & 127;
     int v;
@@ -369,6 +392,7 @@ HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst
 // forward: src (bufA, [row][col]) -> dst (bufA); xTrMxN, TComTrQuant.cpp:836-890
 HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth)
 {
+  HM_ASSUME_LDS(e);
   const int l2 = hm_log2(n), s1 = l2 + bitDepth + 6 - 15, s2 = l2 + 6;
   const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
   int32_t *A = e->bufA, *B = e->u.bufB;
@@ -390,6 +414,7 @@ HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth
 // inverse: coefficients in bufA -> residual in bufA; xITrMxN, TComTrQuant.cpp:894-935
 HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth)
 {
+  HM_ASSUME_LDS(e);
   const int l2 = hm_log2(n), s1 = 7, s2 = 20 - bitDepth;
   int32_t *A = e->bufA, *B = e->u.bufB;
   HM_PAR_FOR(o, n * n) {
@@ -416,7 +441,7 @@ HM_DEV inline TU tu_root(const Shared *e, int cuZ, int cuDepth)
   TU t;
   t.cuZ = (int16_t)cuZ; t.cuDepth = (int16_t)cuDepth; t.cuParts = (int16_t)(256 >> (2 * cuDepth));
   t.relZ = 0; t.trDepth = 0; t.log2 = (int16_t)(6 - cuDepth); t.parts = t.cuParts; t.section = 0;
-  const int r = e->z2r[cuZ];
+  const int r = hm_z2r(cuZ);
   t.x = (int16_t)((r & 15) * 4); t.y = (int16_t)((r >> 4) * 4);
   t.cW = (int16_t)(1 << (t.log2 - 1)); t.cCodeAll = 1; t.cTrDepth = 0; t.cRelZ = 0; t.cParts = t.parts; t.cOff = (int16_t)(cuZ * 4);
   t.cx = t.x >> 1; t.cy = t.y >> 1;
@@ -443,12 +468,12 @@ HM_DEV inline TU tu_child(const TU *p, int section, int processLast)
 // neighbour helpers
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline const CtuMeta *meta_at(const Shared *e, int x4, int y4, int *z)
-{ *z = e->r2z[((y4 & 15) << 4) | (x4 & 15)]; const int ca = (y4 >> 4) * e->wCtu + (x4 >> 4); return ca == e->ctuAddr ? &e->meta : e->fb.meta + ca; }
+{ *z = hm_r2z(((y4 & 15) << 4) | (x4 & 15)); const int ca = (y4 >> 4) * e->wCtu + (x4 >> 4); return ca == e->ctuAddr ? &e->meta : e->fb.meta + ca; }
 
 // TComDataCU::getIntraDirPredictor, TComDataCU.cpp:1513-1586 (luma)
 HM_DEV inline int intra_dir_predictor(const Shared *e, int z, int preds[3])
 {
-  const int r = e->z2r[z];
+  const int r = hm_z2r(z);
   const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4);
   int left = DC_IDX, above = DC_IDX, zz;
   if (x4 > 0) { const CtuMeta *m = meta_at(e, x4 - 1, y4, &zz); left = (m->pred[zz] == MODE_INTRA) ? m->dirL[zz] : DC_IDX; }
@@ -465,7 +490,7 @@ HM_DEV inline int intra_dir_predictor(const Shared *e, int z, int preds[3])
 // TComDataCU::getCtxSplitFlag, TComDataCU.cpp:1587-1601
 HM_DEV inline int ctx_split_flag(const Shared *e, int z, int depth)
 {
-  const int r = e->z2r[z];
+  const int r = hm_z2r(z);
   const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4);
   int ctx = 0, zz;
   if (x4 > 0) { const CtuMeta *m = meta_at(e, x4 - 1, y4, &zz); ctx += m->depth[zz] > depth; }
@@ -481,7 +506,7 @@ HM_DEV inline int avail_above_right(const Shared *e, int rtx4, int rty4, int k)
   if ((rtx4 + k) * 4 >= e->width) return 0;
   const int cx = rtx4 & 15, cy = rty4 & 15;
   if (cx + k <= 15) {
-    if (cy != 0) return e->r2z[(cy << 4) | cx] > e->r2z[((cy - 1) << 4) | (cx + k)];
+    if (cy != 0) return hm_r2z((cy << 4) | cx) > hm_r2z(((cy - 1) << 4) | (cx + k));
     return rty4 > 0;
   }
   if (cy != 0) return 0;
@@ -492,7 +517,7 @@ HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
   if ((lby4 + k) * 4 >= e->height) return 0;
   const int cx = lbx4 & 15, cy = lby4 & 15;
   if (cy + k <= 15) {
-    if (cx != 0) return e->r2z[(cy << 4) | cx] > e->r2z[((cy + k) << 4) | (cx - 1)];
+    if (cx != 0) return hm_r2z((cy << 4) | cx) > hm_r2z(((cy + k) << 4) | (cx - 1));
     return lbx4 > 0;
   }
   return 0;
@@ -503,6 +528,7 @@ HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
 // units: block size in 4x4-luma units.  Result in e->u.ref.refTop/refLeft[0] (and [1] when filter != 0).
 HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, int n, int x4, int y4, int units, int filter)
 {
+  HM_ASSUME_LDS(e);
   const int uw = comp ? 2 : 4, total = 4 * units + 1, L = 2 * units, n2 = 2 * n;
   const int bitDepth = e->bitDepth;
   uint8_t *flags = e->flags;
@@ -589,6 +615,7 @@ HM_DEV inline int use_filtered_refs(int comp, int mode, int n)
 // One lane per sample.
 HM_DEV HM_NOINLINE void pred_intra(Shared *e, int comp, int mode, int n, int filtered, Pel *dst, int ds)
 {
+  HM_ASSUME_LDS(e);
   const Pel *top = e->u.ref.refTop[filtered], *left = e->u.ref.refLeft[filtered];
   const int bitDepth = e->bitDepth, l2 = hm_log2(n);
   if (mode == PLANAR_IDX) {
@@ -695,6 +722,7 @@ HM_DEV inline int pred_sample(const Shared *e, int mode, int n, int l2, int x, i
 // samples on the fly, so the whole first-pass mode estimation of a small PU is one or a few wave passes.
 HM_DEV HM_NOINLINE void satd_all_modes_small(Shared *e, const Pel *org, int so, int n)
 {
+  HM_ASSUME_LDS(e);
   const int l2 = hm_log2(n), bitDepth = e->bitDepth;
   int s = 0;
   HM_PAR_FOR(i, n) s += e->u.ref.refTop[0][i + 1] + e->u.ref.refLeft[0][i + 1];
@@ -848,6 +876,7 @@ HM_DEV inline int ic_rate(const int32_t *estB, uint32_t absLevel, int ctxOne, in
 //      coefficient groups that need a parity fix; the final levels go out lane-parallel.
 HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanType, int cbfCtx)
 {
+  HM_ASSUME_LDS(e);
   const Cabac *cb = &e->cur;
   const int chroma = comp != 0, log2n = hm_log2(n), bitDepth = e->bitDepth;
   const double lambda = chroma ? e->fb.lambdaC : e->fb.lambda;
@@ -862,7 +891,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   const int32_t *src = e->bufA;
   const int32_t *estB = e->estB;
   WorkSpace *ws = e->ws;
-  double *costCoeff = (n == 32) ? ws->costCoeff : e->u.rq.costCoeff;
+  double *costCoeff = (n == 32) ? ws->costCoeff : (double *)(e->bufA + 16 * HM_TSTRIDE);   // blocks up to 16x16 leave rows 16..31 of bufA free
   int32_t *rqLvl = (n == 32) ? ws->rqLvl : e->u.rq.lvl;
   uint16_t *rqPos = (n == 32) ? ws->rqPos : e->u.rq.pos, *rqDec = (n == 32) ? ws->rqDec : e->u.rq.dec;
   int16_t *rqCur = (n == 32) ? ws->rqCur : e->u.rq.cur;
@@ -886,10 +915,10 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   HM_SYNC();
   if (lastScanPos < 0) return 0;
   // ---- 2. bit-cost table of the current estimator state (TEncSbac::estBit, TEncSbac.cpp:1717-1956)
-  HM_PAR_FOR(i, HM_NUM_CTX * 2) e->estB[i] = e->entBits[cb->s[i >> 1] ^ (i & 1)];
-  HM_PAR_FOR(i, 64) { e->costCGSig[i] = 0; e->cgFlag[i] = 0; }
+  HM_PAR_FOR(i, HM_NUM_CTX * 2) e->estB[i] = HM_ENTROPY_BITS[cb->s[i >> 1] ^ (i & 1)];
+  HM_PAR_FOR(i, 64) { e->u.rq.costCGSig[i] = 0; e->u.rq.cgFlag[i] = 0; }
   HM_SYNC();
-  uint8_t *cgFlag = e->cgFlag; double *costCGSig = e->costCGSig;
+  uint8_t *cgFlag = e->u.rq.cgFlag; double *costCGSig = e->u.rq.costCGSig;
   // ---- 3. decision chain.  Per coefficient group: the 16 positions are costed lane-parallel under the
   //         zero-level hypothesis (state independent); the serial part only decides the positions whose
   //         quantised magnitude is non-zero and adds the costs up in the reference's order.
@@ -903,7 +932,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     double sigCost = 0, sigCost0 = 0, codedLevelAndDist = 0, uncodedDist = 0; int nnzBeforePos0 = 0;
     const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
     const int startPos = (cgScanPos == cgLastScanPos ? (lastScanPos & 15) : 15);
-    e->cgCtxSet[cgScanPos] = (uint8_t)ctxSet;
+    e->u.rq.cgCtxSet[cgScanPos] = (uint8_t)ctxSet;
     HM_PAR_FOR(k, 16) {
       const int scanPos = cgScanPos * 16 + k, blkPos = rqPos[scanPos] & 0x3ff;
       const int32_t lvl = rqLvl[scanPos];
@@ -912,18 +941,18 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       const int ctxSig = (scanPos == lastScanPos) ? 0 : sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
       const int b0 = estB[ctxSig * 2];
       const double s0 = lambda * (double)b0;
-      e->cgMax[k] = (uint16_t)mx; e->cgC0[k] = c0; e->cgSigC[k] = s0; e->cgCoef[k] = c0 + s0;
+      e->u.rq.cgMax[k] = (uint16_t)mx; e->u.rq.cgC0[k] = c0; e->u.rq.cgSigC[k] = s0; e->u.rq.cgCoef[k] = c0 + s0;
       rqCtxSig[scanPos] = (uint8_t)ctxSig; rqCode[scanPos] = 1; rqDec[scanPos] = 0; rqCur[scanPos] = 0;
     }
     HM_SYNC();
     for (int posInCG = startPos; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG;
-      const uint32_t maxAbsLevel = e->cgMax[posInCG];
-      const double c0 = e->cgC0[posInCG];
+      const uint32_t maxAbsLevel = e->u.rq.cgMax[posInCG];
+      const double c0 = e->u.rq.cgC0[posInCG];
       blockUncodedCost += c0;
       uint32_t level = 0;
       double cCoeff, cSig;
-      if (maxAbsLevel == 0) { cCoeff = e->cgCoef[posInCG]; cSig = e->cgSigC[posInCG]; }
+      if (maxAbsLevel == 0) { cCoeff = e->u.rq.cgCoef[posInCG]; cSig = e->u.rq.cgSigC[posInCG]; }
       else {
         const int32_t levelDouble = rqLvl[scanPos];
         const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
@@ -1058,7 +1087,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
           const int64_t I64MAX = 0x7fffffffffffffffLL;
           int64_t minCostInc = I64MAX, curCost = I64MAX; int minSp = -1, finalChange = 0, curChange = 0;
           // re-walk the group's decision-time state (contexts, Rice parameter, flag counters)
-          int wC1 = 1, wC1Idx = 0, wC2Idx = 0, wGoR = 0; const int wSet = e->cgCtxSet[subSet];
+          int wC1 = 1, wC1Idx = 0, wC2Idx = 0, wGoR = 0; const int wSet = e->u.rq.cgCtxSet[subSet];
           const int kStart = (lastCG == 1 ? lastNZ : 15);
           for (k = top; k >= 0; --k) {
             const int sp = k + subPos;
@@ -1116,14 +1145,15 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
 // Wavefront form: the coefficients are staged into LDS in scan order lane-parallel (with the last
 // significant position by wave-max and the coefficient-group flags), the bins are then coded by the
 // serial context chain on LDS data with the bit accumulator kept in registers.
-#define HM_BIN(ctx, bin) do { const int st_ = c->s[ctx]; fr += (uint64_t)e->entBits[st_ ^ (bin)]; c->s[ctx] = e->nextSt[st_ * 2 + (bin)]; } while (0)
+#define HM_BIN(ctx, bin) do { const int st_ = c->s[ctx]; fr += (uint64_t)HM_ENTROPY_BITS[st_ ^ (bin)]; c->s[ctx] = hm_next_state(st_, (bin)); } while (0)
 HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
 {
+  HM_ASSUME_LDS(e);
   const int chroma = comp != 0, log2n = hm_log2(n), wg = n >> 2;
   uint64_t fr = 0;
   if (n == 4) HM_BIN(C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
-  int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->cgFlag;
+  int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->u.rq.cgFlag;
   uint16_t *sposArr = (n == 32) ? e->ws->rqPos : e->u.rq.pos;
   HM_PAR_FOR(i, 64) cgFlag[i] = 0;
   HM_SYNC();
@@ -1322,6 +1352,7 @@ HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChro
 // xGetIntraBitsQT, TEncSearch.cpp:1038-1060
 HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU tv, int bLuma, int bChroma)
 {
+  HM_ASSUME_LDS(e);
   const TU *t = &tv;
   HM_PROF_BEGIN(e, PR_BITS);
   reset_bits(&e->cur);
@@ -1338,6 +1369,7 @@ HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU tv, int bLuma, int
 // ------------------------------------------------------------------------------------------------
 HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU tv, int comp, int save1load2)
 {
+  HM_ASSUME_LDS(e);
   const TU *t = &tv;
   CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
   if (comp && !t->cW) return 0;
@@ -1357,7 +1389,7 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU tv, int co
   if (comp && mode == DM_CHROMA_IDX) mode = m->dirL[z & ~3];
   if (save1load2 != 2) {
     const int filt = use_filtered_refs(comp, mode, n);
-    const int r = e->z2r[z];
+    const int r = hm_z2r(z);
     { HM_PROF_BEGIN(e, PR_ADI); init_adi_pattern(e, comp, e->ctuX * st + bx, e->ctuY * st + by, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), comp ? n / 2 : n / 4, filt); HM_PROF_END(e, PR_ADI); }
     { HM_PROF_BEGIN(e, PR_PRED); pred_intra(e, comp, mode, n, filt, pred, st); HM_PROF_END(e, PR_PRED); }
     if (save1load2 == 1) { HM_PAR_FOR(i, 16) e->tsPred[comp][i] = pred[(i >> 2) * st + (i & 3)]; HM_SYNC(); }
@@ -1449,6 +1481,7 @@ HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
 // returns distortion through *distY and adds the RD cost to *rdCost, exactly like the recursive reference
 HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int checkFirst)
 {
+  HM_ASSUME_LDS(e);
   CtuMeta *m = (&e->meta);
   RqtFrame *fr = e->rqt; int sp = 0;
   uint32_t *retDist = e->rqtRetDist; double *retCost = e->rqtRetCost;     // accumulators handed to each level by its parent
@@ -1465,7 +1498,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
       const int checkTS = (log2 == 2) && (m->part[z] == SIZE_NxN);    // TransformSkip + TransformSkipFast
       if (f->checkFull) {
         if (checkTS) {
-          cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+          cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
           for (int modeId = 0; modeId < 2; modeId++) {
             double costTmp;
             par_set8(m->ts[0] + z, modeId, t->parts);
@@ -1475,18 +1508,18 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
             else { const uint32_t bits = intra_bits_qt(e, *t, 1, 0); costTmp = calc_rd_cost(e, bits, distTmp); }
             if (costTmp < f->singleCost) {
               f->singleCost = costTmp; f->singleDist = distTmp; f->singleCbf = cbfTmp; f->bestModeId = (int8_t)modeId;
-              if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->slot[fullDepth][CI_TEMP_BEST], &e->cur); }
+              if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
             }
-            if (modeId == 0) cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]);
+            if (modeId == 0) cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
           }
           par_set8(m->ts[0] + z, f->bestModeId, t->parts);
           if (f->bestModeId == 0) {
             load_intra_result_qt(e, t, 0);
             par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
-            cabac_copy(&e->cur, &e->slot[fullDepth][CI_TEMP_BEST]);
+            cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
           }
         } else {
-          if (f->checkSplit) cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+          if (f->checkSplit) cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
           par_set8(m->ts[0] + z, 0, t->parts);
           f->singleDist = intra_coding_tu_block(e, *t, 0, 0);
           if (f->checkSplit) f->singleCbf = (m->cbf[0][z] >> t->trDepth) & 1;
@@ -1495,8 +1528,8 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
         }
       }
       if (!f->checkSplit) { retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue; }
-      if (f->checkFull) { cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_TEST], &e->cur); cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]); }
-      else cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+      if (f->checkFull) { cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); }
+      else cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
       f->splitCost = 0.0; f->splitDist = 0; f->splitCbf = 0; f->child = 0; f->phase = 1;
       retDist[sp + 1] = 0; retCost[sp + 1] = 0.0;
     }
@@ -1511,11 +1544,11 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
       }
       f->splitDist = retDist[sp + 1];
       if (f->splitCbf) { HM_PAR_FOR(o, t->parts) m->cbf[0][z + o] |= (uint8_t)(1 << t->trDepth); HM_SYNC(); }
-      cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]);
+      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
       const uint32_t splitBits = intra_bits_qt(e, *t, 1, 0);
       f->splitCost = calc_rd_cost(e, splitBits, f->splitDist);
       if (f->splitCost < f->singleCost) { retDist[sp] += f->splitDist; retCost[sp] += f->splitCost; sp--; continue; }
-      cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_TEST]);
+      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)]);
       par_set8(m->tr + z, t->trDepth, t->parts);
       par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
       par_set8(m->ts[0] + z, f->bestModeId, t->parts);
@@ -1538,7 +1571,7 @@ HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
     const int z = root->cuZ + rel, trd = m->tr[z];
     const int log2 = 6 - root->cuDepth - trd, n = 1 << log2, layer = 5 - log2;
     const int parts = root->cuParts >> (2 * trd) > 0 ? root->cuParts >> (2 * trd) : 1;
-    const int r = e->z2r[z], x = (r & 15) * 4, y = (r >> 4) * 4;
+    const int r = hm_z2r(z), x = (r & 15) * 4, y = (r >> 4) * 4;
     par_copy32(e->cc + z * 16, e->ws->qtCoef[layer] + z * 16, n * n);
     par_copy_blk(e->ws->reco + y * 64 + x, 64, e->ws->qtRec[layer] + y * 64 + x, 64, n);
     rel += parts;
@@ -1550,6 +1583,7 @@ HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
 // ------------------------------------------------------------------------------------------------
 HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
 {
+  HM_ASSUME_LDS(e);
   CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
   const int cuParts = 256 >> (2 * cuDepth);
   const int nxn = m->part[cuZ] == SIZE_NxN;
@@ -1564,7 +1598,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
     int numModesForFullRD = HM_INTRA_MODE_NUM_FAST[puLog2 - 1];
     int32_t *rdModeList = e->rdModeList; double *candCost = e->candCost;
     { // SATD pre-selection over the 35 modes, :2360-2410
-      const int r = e->z2r[z];
+      const int r = hm_z2r(z);
       init_adi_pattern(e, 0, e->ctuX * 64 + t.x, e->ctuY * 64 + t.y, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), n / 4, 1);
       for (int i = 0; i < numModesForFullRD; i++) candCost[i] = HM_MAX_DOUBLE;
       const Pel *org = e->fb.org[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x;
@@ -1573,8 +1607,8 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       const int numMpm = intra_dir_predictor(e, z, preds);
       e->mpmZ = z; e->mpmNum = numMpm; e->mpmPreds[0] = preds[0]; e->mpmPreds[1] = preds[1]; e->mpmPreds[2] = preds[2];
       // xModeBitsIntra (TEncSearch.cpp:5456-5478) depends only on whether the mode is an MPM and which
-      const uint64_t frac0 = e->slot[cuDepth][CI_CURR_BEST].frac & 32767;
-      const uint8_t st0 = e->slot[cuDepth][CI_CURR_BEST].s[C_INTRA_LUMA];
+      const uint64_t frac0 = e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)].frac & 32767;
+      const uint8_t st0 = e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)].s[C_INTRA_LUMA];
       HM_PROF_BEGIN(e, PR_SATD35);
       if (n <= 16) satd_all_modes_small(e, org, ps, n);
       for (int mode = 0; mode < 35; mode++) {
@@ -1610,7 +1644,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       const int last = (pass == numModesForFullRD);
       const int orgMode = last ? bestPUMode : rdModeList[pass];
       par_set8(m->dirL + z, orgMode, puParts);
-      cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
       recur_intra_coding_qt(e, t, !last);
       const uint32_t puDistY = e->outDistY; const double puCost = e->outRdCost;
       if (puCost < bestPUCost) {
@@ -1633,7 +1667,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
     HM_PAR_FOR(o, cuParts) for (int c = 0; c < 3; c++) m->cbf[c][cuZ + o] |= comb[c];
     HM_SYNC();
   }
-  cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+  cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
   return overallDistY;
 }
 
@@ -1649,7 +1683,7 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
   const int zc = t->cuZ + t->cRelZ;
   uint32_t dist = 0;
   for (int comp = 1; comp < 3; comp++) {
-    cabac_copy(&e->slot[fullDepth][CI_QT_TRAFO_ROOT], &e->cur);
+    cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
     double singleCost = HM_MAX_DOUBLE, costTmp = 0; uint32_t singleDistC = 0, singleCbfC = 0; int bestTS = 0, bestModeId = 0, currModeId = 0;
     const int total = checkTS ? 2 : 1;
     for (int tsMode = 0; tsMode < total; tsMode++) {
@@ -1662,14 +1696,14 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
       else if (!isOne) { reset_bits(&e->cur); enc_coeff_qt(e, t, comp); costTmp = calc_rd_cost(e, num_bits(&e->cur), distTmp); }   // xGetIntraBitsQTChroma
       if (costTmp < singleCost) {
         singleCost = costTmp; singleDistC = distTmp; bestTS = tsMode; bestModeId = currModeId; singleCbfC = cbfTmp;
-        if (!isOne && !isLast) { store_intra_result_qt(e, t, comp); cabac_copy(&e->slot[fullDepth][CI_TEMP_BEST], &e->cur); }
+        if (!isOne && !isLast) { store_intra_result_qt(e, t, comp); cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
       }
-      if (!isOne && !isLast) cabac_copy(&e->cur, &e->slot[fullDepth][CI_QT_TRAFO_ROOT]);
+      if (!isOne && !isLast) cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
     }
     if (bestModeId < total) {
       load_intra_result_qt(e, t, comp);
       par_set8(m->cbf[comp] + zc, (int)(singleCbfC << t->trDepth), t->cParts);
-      cabac_copy(&e->cur, &e->slot[fullDepth][CI_TEMP_BEST]);
+      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
     }
     par_set8(m->ts[comp] + zc, bestTS, t->cParts);
     dist += singleDistC;
@@ -1678,6 +1712,7 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
 }
 HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU rootv)
 {
+  HM_ASSUME_LDS(e);
   const TU *root = &rootv;
   CtuMeta *m = (&e->meta);
   uint32_t dist = 0;
@@ -1728,16 +1763,17 @@ HM_DEV inline void set_intra_result_chroma_qt(Shared *e, const TU *root)
 }
 HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuDepth)
 {
+  HM_ASSUME_LDS(e);
   CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws; const int cuParts = 256 >> (2 * cuDepth);
   const TU t = tu_root(e, cuZ, cuDepth);
   int bestMode = 0; uint32_t bestDist = 0; double bestCost = HM_MAX_DOUBLE;
   int modeList[5] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX, DM_CHROMA_IDX};       // getAllowedChromaDir, TComDataCU.cpp:1486
   for (int i = 0; i < 4; i++) if (m->dirL[cuZ] == modeList[i]) { modeList[i] = 34; break; }
   for (int mi = 0; mi < 5; mi++) {
-    cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+    cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
     par_set8(m->dirC + cuZ, modeList[mi], cuParts);
     const uint32_t dist = recur_intra_chroma_coding_qt(e, t);
-    cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+    cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
     const uint32_t bits = intra_bits_qt(e, t, 0, 1);
     const double cost = calc_rd_cost(e, bits, dist);
     if (cost < bestCost) {
@@ -1749,7 +1785,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
   }
   HM_PAR_FOR(i, cuParts) { for (int c = 1; c < 3; c++) { m->cbf[c][cuZ + i] = ws->saveCbf[c][i]; m->ts[c][cuZ + i] = ws->saveTs[c][i]; } m->dirC[cuZ + i] = (uint8_t)bestMode; }
   HM_SYNC();
-  cabac_copy(&e->cur, &e->slot[cuDepth][CI_CURR_BEST]);
+  cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
   return bestDist;
 }
 
@@ -1757,7 +1793,8 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
 // final syntax of a CU (TEncEntropy::xEncodeTransform, TEncEntropy.cpp:222-412)
 // ------------------------------------------------------------------------------------------------
 HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDepth)
-{ // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
+{
+  HM_ASSUME_LDS(e); // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
   const CtuMeta *m = (&e->meta);
   if (cuDepth == 3) enc_bin(e, c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
   code_intra_dir_luma(e, c, cuZ, 1);
@@ -1819,12 +1856,13 @@ HM_DEV inline void meta_copy_range(CtuMeta *d, const CtuMeta *s, int z0, int par
 }
 HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
 {
+  HM_ASSUME_LDS(e);
   HM_PROF_BEGIN(e, PR_SAVE);
   Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
   meta_copy_range(&b->m, (&e->meta), cuZ, parts);
   HM_PAR_FOR(i, parts * 16) b->coef[cuZ * 16 + i] = e->cc[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { b->coef[4096 + cuZ * 4 + i] = e->cc[4096 + cuZ * 4 + i]; b->coef[5120 + cuZ * 4 + i] = e->cc[5120 + cuZ * 4 + i]; }
-  const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
+  const int r = hm_z2r(cuZ), x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
   HM_PAR_FOR(i, n * n) { const int yy = i >> l2, xx = i & (n - 1); b->reco[(y + yy) * 64 + x + xx] = e->ws->reco[(y + yy) * 64 + x + xx]; }
   HM_PAR_FOR(i, (n * n) >> 2) {
     const int yy = i >> (l2 - 1), xx = i & ((n >> 1) - 1), o = ((y >> 1) + yy) * 32 + (x >> 1) + xx;
@@ -1834,12 +1872,13 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
   HM_PROF_END(e, PR_SAVE);
 }
 HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
-{ // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
+{
+  HM_ASSUME_LDS(e); // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
   const Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
   meta_copy_range((&e->meta), &b->m, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = b->coef[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = b->coef[4096 + cuZ * 4 + i]; e->cc[5120 + cuZ * 4 + i] = b->coef[5120 + cuZ * 4 + i]; }
-  const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
+  const int r = hm_z2r(cuZ), x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
   Pel *ry = e->fb.rec[0] + (e->ctuY * 64 + y) * e->stride[0] + e->ctuX * 64 + x;
   HM_PAR_FOR(i, n * n) { const int yy = i >> l2, xx = i & (n - 1); ry[yy * e->stride[0] + xx] = b->reco[(y + yy) * 64 + x + xx]; }
   Pel *ru = e->fb.rec[1] + (e->ctuY * 32 + (y >> 1)) * e->stride[1] + e->ctuX * 32 + (x >> 1);
@@ -1854,6 +1893,7 @@ HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
 // xCheckRDCostIntra, TEncCu.cpp:1574-1646; leaves the trial in place
 HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int partSize)
 {
+  HM_ASSUME_LDS(e);
   CtuMeta *m = (&e->meta); const int parts = 256 >> (2 * cuDepth);
   init_est_data(e, cuZ, cuDepth);
   HM_PAR_FOR(i, parts) { m->part[cuZ + i] = (uint8_t)partSize; m->pred[cuZ + i] = MODE_INTRA; }
@@ -1862,13 +1902,13 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
   uint32_t d = est_intra_pred_qt(e, cuZ, cuDepth);
   HM_PROF_END(e, PR_LUMA);
   { // luma reconstruction of the CU into the picture, TEncCu.cpp:1608
-    const int r = e->z2r[cuZ], x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, ps = e->stride[0];
+    const int r = hm_z2r(cuZ), x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, ps = e->stride[0];
     par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + y) * ps + e->ctuX * 64 + x, ps, e->ws->reco + y * 64 + x, 64, n);
   }
   { HM_PROF_BEGIN(e, PR_CHROMA); d += est_intra_pred_chroma_qt(e, cuZ, cuDepth); HM_PROF_END(e, PR_CHROMA); }
   reset_bits(&e->cur);
   { HM_PROF_BEGIN(e, PR_ENCCU); encode_cu_syntax(e, &e->cur, cuZ, cuDepth); HM_PROF_END(e, PR_ENCCU); }
-  cabac_copy(&e->slot[cuDepth][CI_TEMP_BEST], &e->cur);
+  cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
   e->outBits = num_bits(&e->cur); e->outDist = d;
   e->outCost = calc_rd_cost(e, e->outBits, e->outDist);
 }
@@ -1877,6 +1917,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
 // TEncCu::compressCtu -> xCompressCU recursion as a 4-level state machine
 HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 {
+  HM_ASSUME_LDS(e);
   CtuMeta *m = (&e->meta);
   CuFrame *fr = e->cuf; int sp = 0;
   fr[0].cuZ = 0; fr[0].phase = 0;
@@ -1885,18 +1926,18 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
     CuFrame *f = &fr[sp]; const int cuDepth = sp, cuZ = f->cuZ;
     const int size = 64 >> cuDepth, parts = 256 >> (2 * cuDepth), q = parts >> 2;
     if (f->phase == 0) {
-      const int r = e->z2r[cuZ];
+      const int r = hm_z2r(cuZ);
       const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
       f->boundary = !((lx + size - 1 < e->width) && (ty + size - 1 < e->height));
       f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
       if (!f->boundary) {
         check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N);
         double c = e->outCost; uint32_t b = e->outBits, d = e->outDist;
-        if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]); }
+        if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)]); }
         if (cuDepth == 3) {
           check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN);
           c = e->outCost; b = e->outBits; d = e->outDist;
-          if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]); }
+          if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)]); }
         }
         // split flag of the unsplit candidate, TEncCu.cpp:859-863 (coded on the go-on coder as it stands)
         reset_bits(&e->cur);
@@ -1911,14 +1952,14 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
     if (f->phase == 1) {
       if (f->sub < 4) {
         const int s = f->sub++;
-        const int subZ = cuZ + s * q, r = e->z2r[subZ];
+        const int subZ = cuZ + s * q, r = hm_z2r(subZ);
         const int sx = e->ctuX * 64 + (r & 15) * 4, sy = e->ctuY * 64 + (r >> 4) * 4;
         // TComDataCU::initSubCU, TComDataCU.cpp:555-640
         HM_PAR_FOR(i, q) { m->depth[subZ + i] = (uint8_t)(cuDepth + 1); m->part[subZ + i] = SIZE_NONE; m->pred[subZ + i] = MODE_NONE; }
         HM_SYNC();
         if (sx < e->width && sy < e->height) {
-          if (s == 0) cabac_copy(&e->slot[cuDepth + 1][CI_CURR_BEST], &e->slot[cuDepth][CI_CURR_BEST]);
-          else cabac_copy(&e->slot[cuDepth + 1][CI_CURR_BEST], &e->slot[cuDepth + 1][CI_NEXT_BEST]);
+          if (s == 0) cabac_copy(&e->slotArr[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+          else cabac_copy(&e->slotArr[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->slotArr[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
           fr[sp + 1].cuZ = (int16_t)subZ; fr[sp + 1].phase = 0;
           f->phase = 2; sp++; continue;
         }
@@ -1930,10 +1971,10 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
         f->splitBits += num_bits(&e->cur);
       }
       f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
-      cabac_copy(&e->slot[cuDepth][CI_TEMP_BEST], &e->slot[cuDepth + 1][CI_NEXT_BEST]);
+      cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->slotArr[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
       if (f->splitCost < f->bestCost) {
         f->bestCost = f->splitCost; f->bestBits = f->splitBits; f->bestDist = f->splitDist;
-        cabac_copy(&e->slot[cuDepth][CI_NEXT_BEST], &e->slot[cuDepth][CI_TEMP_BEST]);
+        cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)]);
       } else restore_best(e, cuZ, cuDepth);
       retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
     }
@@ -1947,12 +1988,13 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 // TEncCu::xEncodeCU, TEncCu.cpp:1185-1295: re-encode the decided CTU to advance the contexts
 HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
 {
+  HM_ASSUME_LDS(e);
   const CtuMeta *m = (&e->meta);
   int16_t stackZ[4]; int8_t stackNext[4]; int sp = 0;
   stackZ[0] = 0; stackNext[0] = -1;
   while (sp >= 0) {
     const int depth = sp, z = stackZ[sp], size = 64 >> depth;
-    const int r = e->z2r[z];
+    const int r = hm_z2r(z);
     const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
     const int inside = (lx + size - 1 < e->width) && (ty + size - 1 < e->height);
     if (stackNext[sp] < 0) {
@@ -1968,7 +2010,7 @@ HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
     }
     if (stackNext[sp] == 4) { sp--; continue; }
     const int s = stackNext[sp]++;
-    const int q = (256 >> (2 * depth)) >> 2, sz = z + s * q, rr = e->z2r[sz];
+    const int q = (256 >> (2 * depth)) >> 2, sz = z + s * q, rr = hm_z2r(sz);
     const int sx = e->ctuX * 64 + (rr & 15) * 4, sy = e->ctuY * 64 + (rr >> 4) * 4;
     if (sx < e->width && sy < e->height) { stackZ[sp + 1] = (int16_t)sz; stackNext[sp + 1] = -1; sp++; }
   }
@@ -1983,7 +2025,6 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab;
   e->width = P->width; e->height = P->height; e->bitDepth = P->bitDepth; e->wCtu = P->wCtu; e->mpmZ = -1;
   for (int c = 0; c < 3; c++) e->stride[c] = P->stride[c];
-  HM_PAR_FOR(i, 256) { e->z2r[i] = P->tab->z2r[i]; e->r2z[i] = P->tab->r2z[i]; }
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
   e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
   HM_SYNC();
@@ -2002,7 +2043,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     HM_SYNC();
   }
   // CABAC state hand-off (TEncSlice.cpp:733-761)
-  Cabac *cb0 = &e->slot[0][CI_CURR_BEST];
+  Cabac *cb0 = &e->slotArr[HM_SLOT(0, CI_CURR_BEST)];
   if (a == 0) cabac_init(cb0, e->fb.qp);
   else if (e->ctuX == 0 && P->wpp) {
     cabac_init(cb0, e->fb.qp);
