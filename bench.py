@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=96, help="independent pictures per GPU per step")
+    ap.add_argument("--frames", type=int, default=192, help="independent pictures per GPU per step")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=32)
@@ -154,6 +154,14 @@ def main():
     ctus_per_rank = enc.num_ctus * args.frames * args.steps
     total_ctus = ctus_per_rank * world
     if rank == 0:
+        # HBM bytes per launch from the committed PMC passes of this workload (profiles/r01_traffic.json), if they match
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if (tj["width"], tj["height"], tj["frames"]) == (args.width, args.height, args.frames):
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         ach = ALG_BYTES_PER_CTU * ctus_per_rank / (kernel_ms * 1e-3) / 1e9    # GB/s of the CTU-search kernel on this rank
         line = {
             "metric": "CTUs/sec (enc) at 4K main10; bit-exact CU partition vs HM",
@@ -165,7 +173,7 @@ def main():
                        "frames_per_gpu": args.frames, "ctus_per_step": enc.num_ctus * args.frames * world,
                        "parallelism": f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture"},
             "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches,
                          "note": "algorithmic bytes 54,278 B/CTU (SURVEY 8d) x CTUs / HIP-event kernel time; the path is "
                                  "dependency/latency bound, not HBM bound"},
