@@ -7,7 +7,7 @@
  * caller-owned buffers, blocking calls, negative return codes instead of assert/exit.
  * INTEGRATION.md shows the few lines a reference maintainer adds inside TEncSlice::compressSlice.
  *
- * All work is done by hand-written HIP kernels (hm-16.2_amd/csrc/hm355_kernels.hip).  There is NO
+ * All work is done by hand-written HIP kernels (hm-16.2_amd/csrc/hm355.hip + hm355_core.h).  There is NO
  * CPU fallback: without a usable gfx950 device hm355_create() fails with HM355_ERR_NO_DEVICE.
  */
 #ifndef HM355_H

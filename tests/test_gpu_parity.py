@@ -56,6 +56,33 @@ def test_hip_batch_equals_single(hm):
     enc.close()
 
 
+def test_full_size_4k_wpp_properties(built, hm):
+    """BASELINE.json's full size (3840x2160 10-bit, WaveFrontSynchro=1), checked through properties that do not need
+    the oracle at that size: (1) the same picture in two batch slots gives identical results; (2) picture totals are
+    the sums of the per-CTU totals; (3) crop invariance: intra decisions only depend on causal neighbours, so the CTUs
+    of the top-left 192x128 crop whose neighbourhood is identical in both pictures (row 0: x=0..2, row 1: x=0..1)
+    must equal the oracle's result on the crop alone."""
+    import oracle
+    w, h, bd, qp = 3840, 2160, 10, 32
+    planes = synth.frame(w, h, bd, 0, 1234)
+    enc = hm.Encoder(w, h, bd, 1, max_batch=2)
+    (rec0, ctus0, st0), (rec1, ctus1, st1) = enc.compress([planes, planes], qp)
+    enc.close()
+    common.assert_ctus_equal(ctus0, ctus1, "slot 0 vs slot 1")
+    for k in range(3):
+        assert np.array_equal(rec0[k], rec1[k])
+    assert st0[0] == int(ctus0["total_bits"].astype(np.uint64).sum()) and st0[2] == int(ctus0["total_dist"].astype(np.uint64).sum())
+    assert (ctus0["total_bits"] > 0).all()
+    cw, ch, wc = 192, 128, (w + 63) // 64
+    crop = (planes[0][:ch, :cw].copy(), planes[1][:ch // 2, :cw // 2].copy(), planes[2][:ch // 2, :cw // 2].copy())
+    want_rec, want_ctus = oracle.compress(crop, bd, qp, 1)
+    full_idx, crop_idx = [0, 1, 2, wc, wc + 1], [0, 1, 2, 3, 4]
+    common.assert_ctus_equal(ctus0[full_idx], want_ctus[crop_idx], "4K picture vs oracle on its top-left crop")
+    assert np.array_equal(rec0[0][:64, :192], want_rec[0][:64, :192]) and np.array_equal(rec0[0][64:128, :128], want_rec[0][64:128, :128])
+    for k in (1, 2):
+        assert np.array_equal(rec0[k][:32, :96], want_rec[k][:32, :96]) and np.array_equal(rec0[k][32:64, :64], want_rec[k][32:64, :64])
+
+
 def test_hip_primitive_kats(hm):
     """SAD/SSE/SATD and transform kernels vs the reference's known answers"""
     k = np.load(common.GOLD + "/kat_primitives.npz")
