@@ -51,7 +51,6 @@ __device__ __attribute__((noinline)) int hm355_wait_flag(const unsigned int *fla
 
 extern "C" __global__ void __launch_bounds__(64, 2) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
 {
-  __shared__ Shared sh;
   __shared__ WorkItem curItem;
   for (;;) {
     int idx = 0;
@@ -73,7 +72,7 @@ extern "C" __global__ void __launch_bounds__(64, 2) hm355_ctu_kernel(const Param
     if (!bad && dep1 >= 0) bad = hm355_wait_flag(done + dep1, sched + 1, epoch);
     if (bad) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    process_ctu(&sh, P, &curItem, (int)blockIdx.x);
+    process_ctu(&g_sh, P, &curItem, (int)blockIdx.x);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -97,7 +96,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dist_kernel(int kind, int
 // batched transforms: LDS-staged, one wavefront per block
 extern "C" __global__ void __launch_bounds__(64) hm355_transform_kernel(int inverse, int n, int bitDepth, int useDst, int count, const int32_t *in, int32_t *out)
 {
-  __shared__ Shared sh;
+  Shared &sh = g_sh;
   load_tmat(&sh);
   const int l2 = hm_log2(n);
   for (int b = (int)blockIdx.x; b < count; b += (int)gridDim.x) {
@@ -273,7 +272,7 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
 
 #ifdef HM355_PROFILE
 extern "C" int hm355_read_profile(hm355_ctx *c, unsigned long long *out32)
-{ return hipMemcpy(out32, c->hp.prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : HM355_ERR_DEVICE; }
+{ return hipMemcpy(out32, c->hp.prof, 2 * HM_PROF_N * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : HM355_ERR_DEVICE; }
 #endif
 
 extern "C" int hm355_last_run_info(const hm355_ctx *c, double *kernel_ms, int *launches)

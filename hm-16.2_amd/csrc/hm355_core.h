@@ -37,12 +37,28 @@ static inline uint32_t hm_wave_sum(uint32_t v) { return v; }
 static inline int hm_wave_sum_i(int v) { return v; }
 static inline int hm_wave_max_i(int v) { return v; }
 #define HM_UNI(x) (x)
+#define HM_UCALL(x) (x)
+#define hm_uni_ptr(p) (p)
+#define hm_uni_struct(v) (v)
+#define HM_ENTRY(e) ((void)0)
 #define HM_LDS_ADD(p, v) (*(p) += (v))
 #ifdef HM355_HOSTSIM_REVERSE   /* run every lane-parallel loop backwards: catches order dependence */
 #define HM_PAR_FOR(i, n) for (int i = (n) - 1; i >= 0; i--)
+#define HM_WAVE_FOR(k) for (int k = 63; k >= 0; k--)
 #else
 #define HM_PAR_FOR(i, n) for (int i = 0; i < (n); i++)
+#define HM_WAVE_FOR(k) for (int k = 0; k < 64; k++)
 #endif
+// lane variables (one value per lane of the wavefront) are plain arrays in the host twin
+#define HM_LV(T, name) T name[64]
+#define HM_LVARG(T, name) const T *name
+#define HM_LVK(name, k) name[k]
+#define HM_LV_GET(name, i) (name[i])
+#define HM_LV_GETD(name, i) (name[i])
+#define HM_LV_SET(name, i, v) (name[i] = (v))
+#define HM_LV_SETD(name, i, v) (name[i] = (v))
+#define HM_LV_GATHER(name, idx) (name[idx])
+#define HM_BALLOT(m, k, cond) do { if (cond) (m) |= 1ull << (k); } while (0)
 #else
 #define HM_DEV __device__
 #define HM_NOINLINE __attribute__((noinline))
@@ -65,29 +81,66 @@ __device__ __forceinline__ uint32_t hm_wave_sum(uint32_t v)
 {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-  return v;
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);   // every lane holds the total: tell the compiler it is wave-uniform
 }
 __device__ __forceinline__ int hm_wave_sum_i(int v)
 {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ int hm_wave_max_i(int v)
 {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-  return v;
+  return __builtin_amdgcn_readfirstlane(v);
 }
 #define HM_LDS_ADD(p, v) atomicAdd((p), (v))
 // wave-uniform value loaded through the vector path -> SGPR, so that the dependent control code runs on the scalar unit
 #define HM_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
+// Arguments and results of non-inlined device functions travel in VGPRs and count as divergent for the compiler.
+// Every such function re-states at its entry that they are wave-uniform (one v_readfirstlane per dword), so that
+// the decision logic compiles to scalar (SALU / s_cbranch) code; HM_ENTRY re-derives the LDS state pointer from the
+// workgroup's one static instance for the same reason.
+template <class T> __device__ __forceinline__ T *hm_uni_ptr(T *p)
+{
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+template <class T> __device__ __forceinline__ T hm_uni_struct(T v)
+{
+  static_assert(sizeof(T) % 4 == 0, "dword-sized aggregates only");
+  int w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+  __builtin_memcpy(&v, w, sizeof(T));
+  return v;
+}
+#define HM_ENTRY(e) ((e) = &g_sh)
+#define HM_UCALL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define HM_PAR_FOR(i, n) for (int i = hm_lane(); i < (n); i += HM_NT)
+// Lane variables: one value per lane of the wavefront, held in a VGPR.  HM_WAVE_FOR runs its body once on every
+// lane (k = lane id, all lanes active); a wave-uniform lane index reads a lane with v_readlane and writes one with
+// a compare + select (no memory access); a per-lane index gathers through ds_bpermute; HM_BALLOT collects a predicate.
+#define HM_WAVE_FOR(k) for (int k = hm_lane(), k##_once = 1; k##_once; k##_once = 0)
+#define HM_LV(T, name) T name
+#define HM_LVARG(T, name) const T name
+#define HM_LVK(name, k) name
+#define HM_LV_GET(name, i) __builtin_amdgcn_readlane((int)(name), (int)(i))
+#define HM_LV_GETD(name, i) hm_readlane_d((name), (int)(i))
+#define HM_LV_SET(name, i, v) ((name) = (hm_lane() == (int)(i)) ? (v) : (name))        /* v_cmp + v_cndmask: no writelane builtin here */
+#define HM_LV_SETD(name, i, v) ((name) = (hm_lane() == (int)(i)) ? (v) : (name))
+#define HM_LV_GATHER(name, idx) __builtin_amdgcn_ds_bpermute((int)(idx) << 2, (int)(name))
+#define HM_BALLOT(m, k, cond) ((m) = __ballot(cond))
+__device__ __forceinline__ double hm_readlane_d(double v, int i)
+{ return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i)); }
 #endif
 
 // optional in-kernel cycle accounting (diagnostic build only: -DHM355_PROFILE, never in the product build)
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-#define HM_PROF_N 16
+#define HM_PROF_N 24
 #define HM_PROF_BEGIN(e, id) const unsigned long long prof_t0_##id = __builtin_readcyclecounter()
 #define HM_PROF_END(e, id) do { (e)->prof[id] += __builtin_readcyclecounter() - prof_t0_##id; (e)->profCnt[id] += 1; } while (0)
 #else
@@ -116,7 +169,7 @@ enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBL
 // ------------------------------------------------------------------------------------------------
 // ContextModel.cpp:66-128 (FAST_BIT_EST)
 // (the MPS transition is arithmetic: hm_next_state)
-HM_CONST uint8_t HM_NEXT_LPS[128] = {
+HM_CONST uint8_t HM_NEXT_LPS[128] __attribute__((aligned(4))) = {
   1, 0, 0, 1, 2, 3, 4, 5, 4, 5, 8, 9, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 18, 19, 22, 23, 22, 23, 24, 25,
   26, 27, 26, 27, 30, 31, 30, 31, 32, 33, 32, 33, 36, 37, 36, 37, 38, 39, 38, 39, 42, 43, 42, 43, 44, 45, 44, 45, 46, 47, 48, 49,
   48, 49, 50, 51, 52, 53, 52, 53, 54, 55, 54, 55, 56, 57, 58, 59, 58, 59, 60, 61, 60, 61, 60, 61, 62, 63, 64, 65, 64, 65, 66, 67,
@@ -177,9 +230,6 @@ struct RqLds {                         // indexed by scan position
   uint8_t ctxSig[HM_RQ_LDS];           // significance context
   uint8_t code[HM_RQ_LDS];             // significance cost of the position: 0 none, 1 bits(ctx,0), 2 bits(ctx,1)
   // per coefficient group (all block sizes)
-  double cgC0[16], cgCoef[16], cgSigC[16];   // per-position costs of the current group (zero-level hypothesis)
-  double costCGSig[64];
-  uint16_t cgMax[16];
   uint8_t cgCtxSet[64];                // context set each coefficient group started with
   uint8_t cgFlag[64];
 };
@@ -203,7 +253,6 @@ struct Shared {
   Pel tsPred[3][16], tsRec[3][16];     // transform-skip trial of a 4x4 block
   TCoeff tsCoef[3][16];
   uint8_t flags[72];
-  int32_t estB[HM_NUM_CTX * 2 + 2];    // bit cost of (context, bin) for the current estimator state
   TuWalk walkOuter, walkInner;         // tree-walk stacks
   RqtFrame rqt[4]; uint32_t rqtRetDist[5]; double rqtRetCost[5];
   CuFrame cuf[4];
@@ -225,6 +274,9 @@ struct Shared {
 #endif
 };
 
+#ifndef HM355_HOSTSIM
+__shared__ Shared g_sh;                // the one CTU search of this workgroup (HM_ENTRY)
+#endif
 #if !defined(HM355_PROFILE)
 static_assert(sizeof(Shared) <= 20480, "Shared must stay within 1/8 of a CU's 160 KB LDS (8 CTU searches per CU)");
 #endif
@@ -392,7 +444,7 @@ HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst
 // forward: src (bufA, [row][col]) -> dst (bufA); xTrMxN, TComTrQuant.cpp:836-890
 HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); n = HM_UNI(n); useDst = HM_UNI(useDst); bitDepth = HM_UNI(bitDepth);
   const int l2 = hm_log2(n), s1 = l2 + bitDepth + 6 - 15, s2 = l2 + 6;
   const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
   int32_t *A = e->bufA, *B = e->u.bufB;
@@ -414,7 +466,7 @@ HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth
 // inverse: coefficients in bufA -> residual in bufA; xITrMxN, TComTrQuant.cpp:894-935
 HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); n = HM_UNI(n); useDst = HM_UNI(useDst); bitDepth = HM_UNI(bitDepth);
   const int l2 = hm_log2(n), s1 = 7, s2 = 20 - bitDepth;
   int32_t *A = e->bufA, *B = e->u.bufB;
   HM_PAR_FOR(o, n * n) {
@@ -528,7 +580,7 @@ HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
 // units: block size in 4x4-luma units.  Result in e->u.ref.refTop/refLeft[0] (and [1] when filter != 0).
 HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, int n, int x4, int y4, int units, int filter)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); comp = HM_UNI(comp); px = HM_UNI(px); py = HM_UNI(py); n = HM_UNI(n); x4 = HM_UNI(x4); y4 = HM_UNI(y4); units = HM_UNI(units); filter = HM_UNI(filter);
   const int uw = comp ? 2 : 4, total = 4 * units + 1, L = 2 * units, n2 = 2 * n;
   const int bitDepth = e->bitDepth;
   uint8_t *flags = e->flags;
@@ -615,7 +667,7 @@ HM_DEV inline int use_filtered_refs(int comp, int mode, int n)
 // One lane per sample.
 HM_DEV HM_NOINLINE void pred_intra(Shared *e, int comp, int mode, int n, int filtered, Pel *dst, int ds)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); comp = HM_UNI(comp); mode = HM_UNI(mode); n = HM_UNI(n); filtered = HM_UNI(filtered); ds = HM_UNI(ds); dst = hm_uni_ptr(dst);
   const Pel *top = e->u.ref.refTop[filtered], *left = e->u.ref.refLeft[filtered];
   const int bitDepth = e->bitDepth, l2 = hm_log2(n);
   if (mode == PLANAR_IDX) {
@@ -722,7 +774,7 @@ HM_DEV inline int pred_sample(const Shared *e, int mode, int n, int l2, int x, i
 // samples on the fly, so the whole first-pass mode estimation of a small PU is one or a few wave passes.
 HM_DEV HM_NOINLINE void satd_all_modes_small(Shared *e, const Pel *org, int so, int n)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); so = HM_UNI(so); n = HM_UNI(n); org = hm_uni_ptr(org);
   const int l2 = hm_log2(n), bitDepth = e->bitDepth;
   int s = 0;
   HM_PAR_FOR(i, n) s += e->u.ref.refTop[0][i + 1] + e->u.ref.refLeft[0][i + 1];
@@ -847,7 +899,18 @@ HM_DEV inline void last_ctx_params(int chroma, int n, int *off, int *shift)
 // (stride HM_TSTRIDE); levels go to dst (dense n*n, HBM).  The level decision is a serial chain over
 // the scan (running c1/c2/Rice state), evaluated wave-uniformly.
 // ------------------------------------------------------------------------------------------------
-HM_DEV inline int ic_rate(const int32_t *estB, uint32_t absLevel, int ctxOne, int ctxAbs, int goRice, int c1Idx, int c2Idx)
+HM_DEV inline int hm_group_idx(int v)
+{ // g_uiGroupIdx (TComRom.cpp:318) in closed form
+  if (v < 4) return v;
+  const int msb = 31 - __builtin_clz((unsigned)v);
+  return 2 * msb + ((v >> (msb - 1)) & 1);
+}
+// bit-cost tables of one RDOQ call: one entry per lane (lane variables), index = (context - group base) * 2 + bin
+//   tSig  the 28 (luma) / 16 (chroma) significance contexts of the component
+//   tOne  the 24 greater-than-1 contexts, then the 6 greater-than-2 contexts (lanes 48..59)
+//   tLast the 15 last-X contexts of the component, then its 15 last-Y contexts (lanes 30..59)
+//   tMisc the 4 coded-sub-block contexts, then the 10 cbf contexts (lanes 8..27)
+HM_DEV inline int ic_rate(HM_LVARG(int32_t, tOne), uint32_t absLevel, int ctxOne, int ctxAbs, int goRice, int c1Idx, int c2Idx)
 { // xGetICRate, TComTrQuant.cpp:2725-2800
   int rate = 32768;
   const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
@@ -859,9 +922,9 @@ HM_DEV inline int ic_rate(const int32_t *estB, uint32_t absLevel, int ctxOne, in
       while (symbol >= (1u << length)) symbol -= (1u << (length++));
       rate += (int)((3 + length + 1 - goRice + length) << 15);
     }
-    if (c1Idx < 8) { rate += estB[(C_ONE + ctxOne) * 2 + 1]; if (c2Idx < 1) rate += estB[(C_ABS + ctxAbs) * 2 + 1]; }
-  } else if (absLevel == 1) rate += estB[(C_ONE + ctxOne) * 2];
-  else if (absLevel == 2) { rate += estB[(C_ONE + ctxOne) * 2 + 1]; rate += estB[(C_ABS + ctxAbs) * 2]; }
+    if (c1Idx < 8) { rate += HM_LV_GET(tOne, ctxOne * 2 + 1); if (c2Idx < 1) rate += HM_LV_GET(tOne, 48 + ctxAbs * 2 + 1); }
+  } else if (absLevel == 1) rate += HM_LV_GET(tOne, ctxOne * 2);
+  else if (absLevel == 2) { rate += HM_LV_GET(tOne, ctxOne * 2 + 1); rate += HM_LV_GET(tOne, 48 + ctxAbs * 2); }
   else rate = 0;
   return rate;
 }
@@ -869,14 +932,18 @@ HM_DEV inline int ic_rate(const int32_t *estB, uint32_t absLevel, int ctxOne, in
 // Structure on the wavefront:
 //   1. lane-parallel pre-pass over the scan: |c|*scale, sign, raster position -> LDS; wave-max gives the
 //      last significant scan position, all-zero blocks leave here;
-//   2. the bit cost of every (context, bin) for the current estimator state is tabulated once (estB);
-//   3. the level decision is the reference's serial chain (running c1/c2/Rice state, double costs in the
-//      reference's operation order), evaluated wave-uniformly on LDS-resident data;
-//   4. sign-bit hiding re-derives its rate deltas from the packed decision-time state only for the
-//      coefficient groups that need a parity fix; the final levels go out lane-parallel.
+//   2. the bit costs of the contexts RDOQ can touch are tabulated for the current estimator state in four
+//      lane variables (one VGPR each) and read back with v_readlane / ds_bpermute: the serial parts below
+//      touch no memory;
+//   3. per coefficient group the 16 positions are loaded and costed lane-parallel under the zero-level
+//      hypothesis; the level decision is the reference's serial chain (running c1/c2/Rice state, double
+//      sums in the reference's operation order) evaluated wave-uniformly on lane-variable data; only the
+//      positions with a non-zero quantised magnitude run the level search;
+//   4. the last-position search and sign-bit hiding work the same way: lane-parallel per-group precompute,
+//      then a wave-uniform serial pass in the reference's order.
 HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanType, int cbfCtx)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); n = HM_UNI(n); comp = HM_UNI(comp); scanType = HM_UNI(scanType); cbfCtx = HM_UNI(cbfCtx); dst = hm_uni_ptr(dst);
   const Cabac *cb = &e->cur;
   const int chroma = comp != 0, log2n = hm_log2(n), bitDepth = e->bitDepth;
   const double lambda = chroma ? e->fb.lambdaC : e->fb.lambda;
@@ -889,7 +956,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   const int firstCtx = first_sig_ctx(n, scanType, chroma);
   const int sigOff = C_SIG + (chroma ? 28 : 0);
   const int32_t *src = e->bufA;
-  const int32_t *estB = e->estB;
   WorkSpace *ws = e->ws;
   double *costCoeff = (n == 32) ? ws->costCoeff : (double *)(e->bufA + 16 * HM_TSTRIDE);   // blocks up to 16x16 leave rows 16..31 of bufA free
   int32_t *rqLvl = (n == 32) ? ws->rqLvl : e->u.rq.lvl;
@@ -897,6 +963,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   int16_t *rqCur = (n == 32) ? ws->rqCur : e->u.rq.cur;
   uint8_t *rqCtxSig = (n == 32) ? ws->rqCtxSig : e->u.rq.ctxSig, *rqCode = (n == 32) ? ws->rqCode : e->u.rq.code;
   // ---- 1. pre-pass
+  HM_PROF_BEGIN(e, 16);
   int lastLocal = -1;
   {
     const int64_t cap = 2147483647LL - (1LL << (qBits - 1));
@@ -913,75 +980,123 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   }
   const int lastScanPos = hm_wave_max_i(lastLocal);
   HM_SYNC();
+  HM_PROF_END(e, 16);
   if (lastScanPos < 0) return 0;
-  // ---- 2. bit-cost table of the current estimator state (TEncSbac::estBit, TEncSbac.cpp:1717-1956)
-  HM_PAR_FOR(i, HM_NUM_CTX * 2) e->estB[i] = HM_ENTROPY_BITS[cb->s[i >> 1] ^ (i & 1)];
-  HM_PAR_FOR(i, 64) { e->u.rq.costCGSig[i] = 0; e->u.rq.cgFlag[i] = 0; }
-  HM_SYNC();
-  uint8_t *cgFlag = e->u.rq.cgFlag; double *costCGSig = e->u.rq.costCGSig;
-  // ---- 3. decision chain.  Per coefficient group: the 16 positions are costed lane-parallel under the
-  //         zero-level hypothesis (state independent); the serial part only decides the positions whose
-  //         quantised magnitude is non-zero and adds the costs up in the reference's order.
+  HM_PROF_BEGIN(e, 17);
+  // ---- 2. bit-cost tables of the current estimator state (TEncSbac::estBit, TEncSbac.cpp:1717-1956)
+  int lastOff, lastShift; last_ctx_params(chroma, n, &lastOff, &lastShift);
+  HM_LV(int32_t, tSig); HM_LV(int32_t, tOne); HM_LV(int32_t, tLast); HM_LV(int32_t, tMisc); HM_LV(int32_t, tLastCost);
+  HM_LV(double, vCGSig);                  // cost of the coded-sub-block flag per coefficient group (scan order)
+  HM_WAVE_FOR(k) {
+    const int bin = k & 1, c = k >> 1;
+    HM_LVK(tSig, k) = c < (chroma ? 16 : 28) ? HM_ENTROPY_BITS[cb->s[sigOff + c] ^ bin] : 0;
+    HM_LVK(tOne, k) = c < 30 ? HM_ENTROPY_BITS[cb->s[C_ONE + c] ^ bin] : 0;                   // C_ABS follows C_ONE
+    HM_LVK(tLast, k) = c < 30 ? HM_ENTROPY_BITS[cb->s[(c < 15 ? C_LASTX + c : C_LASTY + c - 15) + (chroma ? 15 : 0)] ^ bin] : 0;
+    HM_LVK(tMisc, k) = c < 14 ? HM_ENTROPY_BITS[cb->s[c < 4 ? C_SIG_CG + c : C_QT_CBF + c - 4] ^ bin] : 0;
+    HM_LVK(tLastCost, k) = 0;
+    HM_LVK(vCGSig, k) = 0;
+  }
+  { // bits of a last-position group index (xGetRateLast, TComTrQuant.cpp:2815-2832 over estLastSignificantPositionBit,
+    // TEncSbac.cpp:1846-1892): prefix + bypass bits; lane g = X component, lane 16+g = Y component
+    const int gmax = HM_GROUP_IDX[n - 1];
+    int accX = 0, accY = 0;
+    for (int g = 0; g <= gmax; g++) {
+      const int cx = (lastOff + (g >> lastShift)) * 2, cy = 30 + cx;
+      int bx = accX, by = accY;
+      if (g < gmax) { bx += HM_LV_GET(tLast, cx); by += HM_LV_GET(tLast, cy); }
+      if (g > 3) { bx += 32768 * ((g - 2) >> 1); by += 32768 * ((g - 2) >> 1); }
+      HM_LV_SET(tLastCost, g, bx); HM_LV_SET(tLastCost, 16 + g, by);
+      accX += HM_LV_GET(tLast, cx + 1); accY += HM_LV_GET(tLast, cy + 1);
+    }
+  }
+  HM_PROF_END(e, 17);
+  HM_PROF_BEGIN(e, 18);
+  // ---- 3. decision chain
   double blockUncodedCost = 0;
-  for (int sp = numCoef - 1; sp > lastScanPos; sp--) { const double err = (double)rqLvl[sp]; blockUncodedCost += err * err * errScale; }
+  // distortion of the positions behind the last significant one: only non-zero terms change the sum
+  for (int base = numCoef > 64 ? numCoef - 64 : 0; base >= 0 && base + 63 > lastScanPos; base -= 64) {
+    HM_LV(double, vT); uint64_t m = 0;
+    HM_WAVE_FOR(k) {
+      const int sp = base + k;
+      const int32_t lvl = (sp < numCoef && sp > lastScanPos) ? rqLvl[sp] : 0;
+      const double err = (double)lvl;
+      HM_LVK(vT, k) = err * err * errScale;
+      HM_BALLOT(m, k, lvl != 0);
+    }
+    while (m) { const int k = 63 - __builtin_clzll(m); blockUncodedCost += HM_LV_GETD(vT, k); m &= ~(1ull << k); }
+  }
+  HM_PROF_END(e, 18);
   double baseCost = blockUncodedCost;
+  uint64_t cgMask = 0;                    // significant-coefficient-group flags, bit = raster position of the group
   const int cgLastScanPos = lastScanPos >> 4;
   int ctxSet = ctx_set_index(chroma, lastScanPos >> 4, 0), c1 = 1, c2 = 0, c1Idx = 0, c2Idx = 0, goRice = 0;
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
     const int cgBlkPos = scanCG[cgScanPos], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
+    const uint64_t cgBit = 1ull << cgBlkPos;
     double sigCost = 0, sigCost0 = 0, codedLevelAndDist = 0, uncodedDist = 0; int nnzBeforePos0 = 0;
-    const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
+    const int sigRight = (cgx < wg - 1) ? (int)((cgMask >> (cgBlkPos + 1)) & 1) : 0;       // calcPatternSigCtx, TComTrQuant.cpp:2522
+    const int sigLower = (cgy < wg - 1) ? (int)((cgMask >> (cgBlkPos + wg)) & 1) : 0;
+    const int pattern = wg <= 1 ? 0 : sigRight + (sigLower << 1);
     const int startPos = (cgScanPos == cgLastScanPos ? (lastScanPos & 15) : 15);
-    e->u.rq.cgCtxSet[cgScanPos] = (uint8_t)ctxSet;
-    HM_PAR_FOR(k, 16) {
-      const int scanPos = cgScanPos * 16 + k, blkPos = rqPos[scanPos] & 0x3ff;
+    const int wSet = ctxSet;              // context set this group starts with (sign-bit hiding walks it again)
+    HM_LV(int32_t, vLvl); HM_LV(int32_t, vMx); HM_LV(int32_t, vSigIdx); HM_LV(int32_t, vB0); HM_LV(int32_t, vB1);
+    HM_LV(int32_t, vDec); HM_LV(int32_t, vCode);
+    HM_LV(double, vC0); HM_LV(double, vS0); HM_LV(double, vCoef0); HM_LV(double, vCC);
+    uint64_t nzMask = 0;
+    HM_PROF_BEGIN(e, 22);
+    HM_WAVE_FOR(k) {
+      const int scanPos = cgScanPos * 16 + (k & 15), blkPos = rqPos[scanPos] & 0x3ff;
       const int32_t lvl = rqLvl[scanPos];
       uint32_t mx = (uint32_t)((lvl + (1 << (qBits - 1))) >> qBits); if (mx > 32767u) mx = 32767u;
       const double err = (double)lvl, c0 = err * err * errScale;
-      const int ctxSig = (scanPos == lastScanPos) ? 0 : sigOff + sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
-      const int b0 = estB[ctxSig * 2];
+      const int sigIdx = (scanPos == lastScanPos) ? 0 : sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
+      const int b0 = HM_LV_GATHER(tSig, sigIdx * 2), b1 = HM_LV_GATHER(tSig, sigIdx * 2 + 1);
       const double s0 = lambda * (double)b0;
-      e->u.rq.cgMax[k] = (uint16_t)mx; e->u.rq.cgC0[k] = c0; e->u.rq.cgSigC[k] = s0; e->u.rq.cgCoef[k] = c0 + s0;
-      rqCtxSig[scanPos] = (uint8_t)ctxSig; rqCode[scanPos] = 1; rqDec[scanPos] = 0; rqCur[scanPos] = 0;
+      HM_LVK(vLvl, k) = lvl; HM_LVK(vMx, k) = (int32_t)mx; HM_LVK(vSigIdx, k) = sigIdx; HM_LVK(vB0, k) = b0; HM_LVK(vB1, k) = b1;
+      HM_LVK(vC0, k) = c0; HM_LVK(vS0, k) = s0; HM_LVK(vCoef0, k) = c0 + s0; HM_LVK(vCC, k) = 0;
+      HM_LVK(vDec, k) = 0; HM_LVK(vCode, k) = 1;
+      HM_BALLOT(nzMask, k, mx > 0 && k < 16);
     }
-    HM_SYNC();
+    HM_PROF_END(e, 22);
+    HM_PROF_BEGIN(e, 23);
     for (int posInCG = startPos; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG;
-      const uint32_t maxAbsLevel = e->u.rq.cgMax[posInCG];
-      const double c0 = e->u.rq.cgC0[posInCG];
+      const double c0 = HM_LV_GETD(vC0, posInCG);
       blockUncodedCost += c0;
       uint32_t level = 0;
       double cCoeff, cSig;
-      if (maxAbsLevel == 0) { cCoeff = e->u.rq.cgCoef[posInCG]; cSig = e->u.rq.cgSigC[posInCG]; }
+      if (!((nzMask >> posInCG) & 1)) { cCoeff = HM_LV_GETD(vCoef0, posInCG); cSig = HM_LV_GETD(vS0, posInCG); }
       else {
-        const int32_t levelDouble = rqLvl[scanPos];
+        HM_PROF_BEGIN(e, 15);
+        const uint32_t maxAbsLevel = (uint32_t)HM_LV_GET(vMx, posInCG);
+        const int32_t levelDouble = HM_LV_GET(vLvl, posInCG);
         const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
         const int isLast = (scanPos == lastScanPos);
-        const int ctxSig = rqCtxSig[scanPos];
         int sigBits = 0, sigCode = 0;
         { // xGetCodedLevel, TComTrQuant.cpp:2660-2715
           int currSigBits = 0;
-          if (!isLast && maxAbsLevel < 3) { sigBits = estB[ctxSig * 2]; sigCode = 1; cCoeff = c0 + lambda * (double)sigBits; }
+          if (!isLast && maxAbsLevel < 3) { sigBits = HM_LV_GET(vB0, posInCG); sigCode = 1; cCoeff = HM_LV_GETD(vCoef0, posInCG); }
           else cCoeff = HM_MAX_DOUBLE;
           double currCostSig = 0;
-          if (!isLast) { currSigBits = estB[ctxSig * 2 + 1]; currCostSig = lambda * (double)currSigBits; }
+          if (!isLast) { currSigBits = HM_LV_GET(vB1, posInCG); currCostSig = lambda * (double)currSigBits; }
           const uint32_t minAbs = maxAbsLevel > 1 ? maxAbsLevel - 1 : 1;
           for (int al = (int)maxAbsLevel; al >= (int)minAbs; al--) {
             const double de = (double)(levelDouble - (int32_t)((uint32_t)al << qBits));
             const double dist = de * de * errScale;
-            const double rc = lambda * (double)ic_rate(estB, (uint32_t)al, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
+            const double rc = lambda * (double)ic_rate(tOne, (uint32_t)al, ctxOne, ctxAbs, goRice, c1Idx, c2Idx);
             double cc = dist + rc;
             cc += currCostSig;
             if (cc < cCoeff) { level = (uint32_t)al; cCoeff = cc; sigBits = currSigBits; sigCode = isLast ? 0 : 2; }
           }
         }
         cSig = lambda * (double)sigBits;
-        rqCode[scanPos] = (uint8_t)sigCode; rqDec[scanPos] = (uint16_t)level; rqCur[scanPos] = (int16_t)level;
+        HM_LV_SET(vCode, posInCG, sigCode); HM_LV_SET(vDec, posInCG, (int32_t)level);
         const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
         if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
         if (level >= 1) c1Idx++;
         if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
         else if (c1 < 3 && c1 > 0 && level) c1++;
+        HM_PROF_END(e, 15);
       }
       baseCost += cCoeff;
       if (posInCG == 0 && scanPos > 0) {
@@ -991,76 +1106,87 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       sigCost += cSig;
       if (posInCG == 0) sigCost0 = cSig;
       if (level) {
-        costCoeff[scanPos] = cCoeff;
-        cgFlag[cgBlkPos] = 1;
+        HM_LV_SETD(vCC, posInCG, cCoeff);
+        cgMask |= cgBit;
         codedLevelAndDist += cCoeff - cSig;
         uncodedDist += c0;
         if (posInCG != 0) nnzBeforePos0++;
       }
     }
+    HM_PROF_END(e, 23);
+    int zeroed = 0;
     if (cgScanPos) {
-      if (cgFlag[cgBlkPos] == 0) {
-        const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
-        const double r0 = lambda * (double)estB[ctx * 2];
+      const int cgCtx = ((sigRight + sigLower) != 0) * 2;                                   // getSigCoeffGroupCtxInc, TComTrQuant.cpp:2872
+      if (!(cgMask & cgBit)) {
+        const double r0 = lambda * (double)HM_LV_GET(tMisc, (chroma ? 4 : 0) + cgCtx);
         baseCost += r0 - sigCost;
-        costCGSig[cgScanPos] = r0;
+        HM_LV_SETD(vCGSig, cgScanPos, r0);
       } else if (cgScanPos < cgLastScanPos) {
         if (nnzBeforePos0 == 0) { baseCost -= sigCost0; sigCost -= sigCost0; }
         double costZeroCG = baseCost;
-        const int ctx = C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg);
-        const double r0 = lambda * (double)estB[ctx * 2], r1 = lambda * (double)estB[ctx * 2 + 1];
+        const double r0 = lambda * (double)HM_LV_GET(tMisc, (chroma ? 4 : 0) + cgCtx), r1 = lambda * (double)HM_LV_GET(tMisc, (chroma ? 4 : 0) + cgCtx + 1);
         baseCost += r1;
         costZeroCG += r0;
-        costCGSig[cgScanPos] = r1;
         costZeroCG += uncodedDist; costZeroCG -= codedLevelAndDist; costZeroCG -= sigCost;
-        if (costZeroCG < baseCost) {
-          cgFlag[cgBlkPos] = 0; baseCost = costZeroCG;
-          costCGSig[cgScanPos] = r0;
-          HM_PAR_FOR(k, 16) { const int scanPos = cgScanPos * 16 + k; if (rqCur[scanPos]) { rqCur[scanPos] = 0; rqCode[scanPos] = 0; } }
-        }
+        if (costZeroCG < baseCost) { cgMask &= ~cgBit; baseCost = costZeroCG; HM_LV_SETD(vCGSig, cgScanPos, r0); zeroed = 1; }
+        else HM_LV_SETD(vCGSig, cgScanPos, r1);
       }
-    } else cgFlag[cgBlkPos] = 1;
-    HM_SYNC();
+    } else cgMask |= cgBit;
+    // park the group's decisions for the passes below
+    HM_WAVE_FOR(k) {
+      if (k < 16) {
+        const int scanPos = cgScanPos * 16 + k, dec = HM_LVK(vDec, k);
+        rqDec[scanPos] = (uint16_t)dec; rqCur[scanPos] = (int16_t)(zeroed ? 0 : dec);
+        rqCode[scanPos] = (uint8_t)((zeroed && dec) ? 0 : HM_LVK(vCode, k));
+        rqCtxSig[scanPos] = (uint8_t)HM_LVK(vSigIdx, k);
+        costCoeff[scanPos] = HM_LVK(vCC, k);
+      }
+    }
+    e->u.rq.cgCtxSet[cgScanPos] = (uint8_t)wSet;
   }
-  double bestCost = blockUncodedCost + lambda * (double)estB[(C_QT_CBF + cbfCtx) * 2];   // TComTrQuant.cpp:2310-2316
-  baseCost += lambda * (double)estB[(C_QT_CBF + cbfCtx) * 2 + 1];
+  HM_SYNC();
+  HM_PROF_BEGIN(e, 19);
+  double bestCost = blockUncodedCost + lambda * (double)HM_LV_GET(tMisc, 8 + cbfCtx * 2);   // TComTrQuant.cpp:2310-2316
+  baseCost += lambda * (double)HM_LV_GET(tMisc, 8 + cbfCtx * 2 + 1);
   int bestLastIdxP1 = 0, foundLast = 0;
-  int lastOff, lastShift; last_ctx_params(chroma, n, &lastOff, &lastShift);
-  const int cLX = C_LASTX + (chroma ? 15 : 0) + lastOff, cLY = C_LASTY + (chroma ? 15 : 0) + lastOff;
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0 && !foundLast; cgScanPos--) {
     const int cgBlkPos = scanCG[cgScanPos];
-    baseCost -= costCGSig[cgScanPos];
-    if (!cgFlag[cgBlkPos]) continue;
+    baseCost -= HM_LV_GETD(vCGSig, cgScanPos);
+    if (!((cgMask >> cgBlkPos) & 1)) continue;
+    HM_LV(double, dSig); HM_LV(double, dLast); HM_LV(double, dCC); HM_LV(double, dErr);
+    uint64_t curMask = 0, gt1Mask = 0;
+    HM_WAVE_FOR(k) {
+      const int scanPos = cgScanPos * 16 + (k & 15);
+      const int cur = rqCur[scanPos], code = rqCode[scanPos], sigIdx = rqCtxSig[scanPos];
+      const int sb = HM_LV_GATHER(tSig, sigIdx * 2 + (code ? code - 1 : 0));
+      HM_LVK(dSig, k) = lambda * (double)(code ? sb : 0);
+      const int blkPos = rqPos[scanPos] & 0x3ff;
+      int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
+      if (scanType == SCAN_VER) { const int t = posX; posX = posY; posY = t; }
+      const int lb = HM_LV_GATHER(tLastCost, hm_group_idx(posX)) + HM_LV_GATHER(tLastCost, 16 + hm_group_idx(posY));
+      HM_LVK(dLast, k) = lambda * (double)lb;
+      HM_LVK(dCC, k) = costCoeff[scanPos];
+      const double err = (double)rqLvl[scanPos];
+      HM_LVK(dErr, k) = err * err * errScale;
+      HM_BALLOT(curMask, k, cur != 0 && k < 16);
+      HM_BALLOT(gt1Mask, k, cur > 1 && k < 16);
+    }
     for (int posInCG = 15; posInCG >= 0; posInCG--) {
       const int scanPos = cgScanPos * 16 + posInCG;
       if (scanPos > lastScanPos) continue;
-      const int cur = rqCur[scanPos];
-      const int code = rqCode[scanPos];
-      const double cSig = lambda * (double)(code ? estB[rqCtxSig[scanPos] * 2 + code - 1] : 0);
-      if (cur) {
-        const int blkPos = rqPos[scanPos] & 0x3ff;
-        int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
-        if (scanType == SCAN_VER) { const int t = posX; posX = posY; posY = t; }
-        // xGetRateLast, TComTrQuant.cpp:2815-2832 over estLastSignificantPositionBit, TEncSbac.cpp:1846-1892
-        const int gx = HM_GROUP_IDX[posX], gy = HM_GROUP_IDX[posY], gmax = HM_GROUP_IDX[n - 1];
-        int bx = 0, by = 0;
-        for (int c = 0; c < gx; c++) bx += estB[(cLX + (c >> lastShift)) * 2 + 1];
-        if (gx < gmax) bx += estB[(cLX + (gx >> lastShift)) * 2];
-        for (int c = 0; c < gy; c++) by += estB[(cLY + (c >> lastShift)) * 2 + 1];
-        if (gy < gmax) by += estB[(cLY + (gy >> lastShift)) * 2];
-        double cst = (double)(bx + by);
-        if (gx > 3) cst += 32768.0 * (double)((gx - 2) >> 1);
-        if (gy > 3) cst += 32768.0 * (double)((gy - 2) >> 1);
-        const double costLast = lambda * cst;
+      const double cSig = HM_LV_GETD(dSig, posInCG);
+      if ((curMask >> posInCG) & 1) {
+        const double costLast = HM_LV_GETD(dLast, posInCG);
         const double t1 = baseCost + costLast;
         const double totalCost = t1 - cSig;
         if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
-        if (cur > 1) { foundLast = 1; break; }
-        const double err = (double)rqLvl[scanPos];
-        baseCost -= costCoeff[scanPos]; baseCost += err * err * errScale;
+        if ((gt1Mask >> posInCG) & 1) { foundLast = 1; break; }
+        baseCost -= HM_LV_GETD(dCC, posInCG); baseCost += HM_LV_GETD(dErr, posInCG);
       } else baseCost -= cSig;
     }
   }
+  HM_PROF_END(e, 19);
+  HM_PROF_BEGIN(e, 20);
   // ---- levels with signs, truncated at the chosen last position (lane-parallel)
   int absPart = 0;
   HM_PAR_FOR(sp, lastScanPos + 1) {
@@ -1075,23 +1201,31 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     const int64_t rdFactor = e->fb.rdFactor[chroma];
     int lastCG = -1;
     for (int subSet = cgLastScanPos; subSet >= 0; subSet--) {
-      const int subPos = subSet << 4; int firstNZ = 16, lastNZ = -1, sum = 0, k;
+      const int subPos = subSet << 4;
       const int top = (subPos + 15 <= lastScanPos) ? 15 : (lastScanPos - subPos);
-      for (k = top; k >= 0; --k) if (rqCur[k + subPos]) { lastNZ = k; break; }
-      for (k = 0; k <= top; k++) if (rqCur[k + subPos]) { firstNZ = k; break; }
-      for (k = firstNZ; k <= lastNZ; k++) sum += rqCur[k + subPos];
+      HM_LV(int32_t, sCur); HM_LV(int32_t, sDec); HM_LV(int32_t, sLvl); HM_LV(int32_t, sNeg); HM_LV(int32_t, sDelta);
+      uint64_t nzM = 0, oddM = 0;
+      HM_WAVE_FOR(k) {
+        const int kk = k & 15, sp = subPos + kk;
+        const int cur = (kk <= top) ? rqCur[sp] : 0, sigIdx = rqCtxSig[sp];
+        HM_LVK(sCur, k) = cur; HM_LVK(sDec, k) = rqDec[sp]; HM_LVK(sLvl, k) = rqLvl[sp]; HM_LVK(sNeg, k) = (rqPos[sp] >> 15) & 1;
+        const int d = HM_LV_GATHER(tSig, sigIdx * 2 + 1) - HM_LV_GATHER(tSig, sigIdx * 2);
+        HM_LVK(sDelta, k) = (sp == lastScanPos) ? 0 : d;
+        HM_BALLOT(nzM, k, cur != 0 && k < 16);
+        HM_BALLOT(oddM, k, (cur & 1) && k < 16);
+      }
+      const int lastNZ = nzM ? 63 - __builtin_clzll(nzM) : -1, firstNZ = nzM ? __builtin_ctzll(nzM) : 16;
       if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
       if (lastNZ - firstNZ >= 4) {
-        const uint32_t signbit = rqCur[subPos + firstNZ] > 0 ? 0 : 1;
-        if (signbit != (uint32_t)(sum & 1)) {
+        const uint32_t signbit = HM_LV_GET(sCur, firstNZ) > 0 ? 0 : 1;
+        if (signbit != (uint32_t)(__builtin_popcountll(oddM) & 1)) {
           const int64_t I64MAX = 0x7fffffffffffffffLL;
-          int64_t minCostInc = I64MAX, curCost = I64MAX; int minSp = -1, finalChange = 0, curChange = 0;
+          int64_t minCostInc = I64MAX, curCost = I64MAX; int minK = -1, finalChange = 0, curChange = 0;
           // re-walk the group's decision-time state (contexts, Rice parameter, flag counters)
           int wC1 = 1, wC1Idx = 0, wC2Idx = 0, wGoR = 0; const int wSet = e->u.rq.cgCtxSet[subSet];
           const int kStart = (lastCG == 1 ? lastNZ : 15);
-          for (k = top; k >= 0; --k) {
-            const int sp = k + subPos;
-            const uint32_t dec = rqDec[sp];
+          for (int k = top; k >= 0; --k) {
+            const uint32_t dec = (uint32_t)HM_LV_GET(sDec, k);
             const int ctxOne = 4 * wSet + wC1, ctxSetD = wSet, goR = wGoR, c1I = wC1Idx, c2I = wC2Idx;
             { // advance the walk past this position (same updates as the decision chain)
               const uint32_t baseLevel = (wC1Idx < 8) ? (2 + (wC2Idx < 1)) : 1;
@@ -1101,17 +1235,16 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
               else if (wC1 < 3 && wC1 > 0 && dec) wC1++;
             }
             if (k > kStart) continue;
-            const int ctxSig = rqCtxSig[sp], wasLast = (sp == lastScanPos);
-            const int32_t lvlD = rqLvl[sp];
+            const int32_t lvlD = HM_LV_GET(sLvl, k);
             const int32_t deltaU = (int32_t)((lvlD - (int32_t)(dec << qBits)) >> (qBits - 8));
-            const int sigRateDelta = wasLast ? 0 : (estB[ctxSig * 2 + 1] - estB[ctxSig * 2]);
+            const int sigRateDelta = HM_LV_GET(sDelta, k);
             int rateIncUp, rateIncDown = 0;
             if (dec > 0) {
-              const int rateNow = ic_rate(estB, dec, ctxOne, ctxSetD, goR, c1I, c2I);
-              rateIncUp = ic_rate(estB, dec + 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
-              rateIncDown = ic_rate(estB, dec - 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
-            } else rateIncUp = estB[(C_ONE + ctxOne) * 2];
-            const int dv = rqCur[sp];
+              const int rateNow = ic_rate(tOne, dec, ctxOne, ctxSetD, goR, c1I, c2I);
+              rateIncUp = ic_rate(tOne, dec + 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
+              rateIncDown = ic_rate(tOne, dec - 1, ctxOne, ctxSetD, goR, c1I, c2I) - rateNow;
+            } else rateIncUp = HM_LV_GET(tOne, ctxOne * 2);
+            const int dv = HM_LV_GET(sCur, k);
             if (dv != 0) {
               const int64_t costUp = rdFactor * (-deltaU) + rateIncUp;
               int64_t costDown = rdFactor * (deltaU) + rateIncDown - ((hm_abs(dv) == 1) ? sigRateDelta : 0);
@@ -1121,37 +1254,76 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
             } else {
               curCost = rdFactor * (-(hm_abs(deltaU))) + (1 << 15) + rateIncUp + sigRateDelta;
               curChange = 1;
-              if (k < firstNZ) { const uint32_t thissign = (rqPos[sp] & 0x8000) ? 1 : 0; if (thissign != signbit) curCost = I64MAX; }
+              if (k < firstNZ) { const uint32_t thissign = (uint32_t)HM_LV_GET(sNeg, k); if (thissign != signbit) curCost = I64MAX; }
             }
-            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minSp = sp; }
+            if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minK = k; }
           }
-          if (rqCur[minSp] == 32767 || rqCur[minSp] == -32768) finalChange = -1;
-          if (!(rqPos[minSp] & 0x8000)) rqCur[minSp] = (int16_t)(rqCur[minSp] + finalChange); else rqCur[minSp] = (int16_t)(rqCur[minSp] - finalChange);
+          if (minK >= 0) {
+            const int mv = HM_LV_GET(sCur, minK);
+            if (mv == 32767 || mv == -32768) finalChange = -1;
+            rqCur[subPos + minK] = (int16_t)(HM_LV_GET(sNeg, minK) ? mv - finalChange : mv + finalChange);
+          }
         }
       }
       if (lastCG == 1) lastCG = 0;
     }
   }
   HM_SYNC();
+  HM_PROF_END(e, 20);
+  HM_PROF_BEGIN(e, 21);
   HM_PAR_FOR(sp, lastScanPos + 1) dst[rqPos[sp] & 0x3ff] = rqCur[sp];
   HM_SYNC();
+  HM_PROF_END(e, 21);
   return absSum;
 }
 
 // ------------------------------------------------------------------------------------------------
 // syntax element coding on the estimator (TEncSbac.cpp)
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// The estimator in registers.  One Cabac (163 context states, 4 per dword) fits one lane variable; the entropy
+// table (2 x 64 dwords) and the LPS transition table (128 bytes = 32 dwords) sit in three more.  A bin then costs
+// a few v_readlane + scalar instructions and no memory access.  Functions that code many bins load the state
+// from its LDS home at entry and store it back at exit.
+// ------------------------------------------------------------------------------------------------
+struct CabacR { HM_LV(int32_t, st); HM_LV(int32_t, eb0); HM_LV(int32_t, eb1); HM_LV(int32_t, lps); uint64_t frac; };
+HM_DEV inline void cabr_load(CabacR &r, const Cabac *c)
+{
+  HM_WAVE_FOR(k) {
+    HM_LVK(r.st, k) = k < 42 ? ((const int32_t *)c->s)[k] : 0;
+    HM_LVK(r.eb0, k) = HM_ENTROPY_BITS[k]; HM_LVK(r.eb1, k) = HM_ENTROPY_BITS[64 + k];
+    HM_LVK(r.lps, k) = ((const int32_t *)HM_NEXT_LPS)[k & 31];
+  }
+  r.frac = c->frac;
+}
+HM_DEV inline void cabr_store(const CabacR &r, Cabac *c)
+{
+  HM_WAVE_FOR(k) { if (k < 42) ((int32_t *)c->s)[k] = HM_LVK(r.st, k); }
+  c->frac = r.frac;
+  HM_SYNC();
+}
+HM_DEV inline void enc_bin(const Shared *e, CabacR *r, int ctx, int bin)
+{
+  const int w = HM_LV_GET(r->st, ctx >> 2), sh = (ctx & 3) * 8, s = (w >> sh) & 0xff, i = s ^ bin;
+  const int b0 = HM_LV_GET(r->eb0, i & 63), b1 = HM_LV_GET(r->eb1, i & 63);
+  r->frac += (uint64_t)(uint32_t)(i < 64 ? b0 : b1);
+  const int lw = HM_LV_GET(r->lps, s >> 2);
+  const int ns = (bin == (s & 1)) ? (s < 124 ? s + 2 : s) : ((lw >> ((s & 3) * 8)) & 0xff);
+  HM_LV_SET(r->st, ctx >> 2, (w & ~(0xff << sh)) | (ns << sh));
+}
+HM_DEV inline void enc_ep(CabacR *r, int n) { r->frac += (uint64_t)32768 * (uint64_t)n; }
+
 // TEncSbac::codeCoeffNxN, TEncSbac.cpp:1172-1525 (+codeLastSignificantXY :1106, xWriteCoefRemainExGolomb :337)
-// Wavefront form: the coefficients are staged into LDS in scan order lane-parallel (with the last
-// significant position by wave-max and the coefficient-group flags), the bins are then coded by the
-// serial context chain on LDS data with the bit accumulator kept in registers.
-#define HM_BIN(ctx, bin) do { const int st_ = c->s[ctx]; fr += (uint64_t)HM_ENTROPY_BITS[st_ ^ (bin)]; c->s[ctx] = hm_next_state(st_, (bin)); } while (0)
+// Wavefront form: the coefficients are staged into LDS in scan order lane-parallel (last significant position by
+// wave-max, coefficient-group flags by ballot); per coefficient group the 16 levels, their significance contexts
+// and the >0 / >1 / >2 masks are produced lane-parallel, and the bins are coded by the serial context chain on
+// register-resident data (CabacR).
 HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); n = HM_UNI(n); comp = HM_UNI(comp); scanType = HM_UNI(scanType); tskipFlag = HM_UNI(tskipFlag); c = hm_uni_ptr(c); HM_ASSUME_LDS(c); coef = hm_uni_ptr(coef);
   const int chroma = comp != 0, log2n = hm_log2(n), wg = n >> 2;
-  uint64_t fr = 0;
-  if (n == 4) HM_BIN(C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
+  CabacR r; cabr_load(r, c);
+  if (n == 4) enc_bin(e, &r, C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
   int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->u.rq.cgFlag;
   uint16_t *sposArr = (n == 32) ? e->ws->rqPos : e->u.rq.pos;
@@ -1165,72 +1337,91 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
   }
   const int scanPosLast = hm_wave_max_i(lastLocal);
   HM_SYNC();
+  uint64_t cgMask = 0;                    // coefficient-group flags, bit = raster position of the group
+  HM_LV(int32_t, vScanCG);                // raster position of the group at scan index = lane
+  HM_WAVE_FOR(k) { HM_BALLOT(cgMask, k, cgFlag[k] != 0); HM_LVK(vScanCG, k) = k < wg * wg ? scanCG[k] : 0; }
   const int posLast = sposArr[scanPosLast];
   {
     int py = posLast >> log2n, px = posLast - (py << log2n);
     if (scanType == SCAN_VER) { const int t = px; px = py; py = t; }
-    const int gx = HM_GROUP_IDX[px], gy = HM_GROUP_IDX[py], gmax = HM_GROUP_IDX[n - 1];
+    const int gx = hm_group_idx(px), gy = hm_group_idx(py), gmax = hm_group_idx(n - 1);
     int off, shift; last_ctx_params(chroma, n, &off, &shift);
     const int bxc = C_LASTX + (chroma ? 15 : 0) + off, byc = C_LASTY + (chroma ? 15 : 0) + off;
     int k;
-    for (k = 0; k < gx; k++) HM_BIN(bxc + (k >> shift), 1);
-    if (gx < gmax) HM_BIN(bxc + (k >> shift), 0);
-    for (k = 0; k < gy; k++) HM_BIN(byc + (k >> shift), 1);
-    if (gy < gmax) HM_BIN(byc + (k >> shift), 0);
-    if (gx > 3) fr += (uint64_t)32768 * (uint64_t)((gx - 2) >> 1);
-    if (gy > 3) fr += (uint64_t)32768 * (uint64_t)((gy - 2) >> 1);
+    for (k = 0; k < gx; k++) enc_bin(e, &r, bxc + (k >> shift), 1);
+    if (gx < gmax) enc_bin(e, &r, bxc + (k >> shift), 0);
+    for (k = 0; k < gy; k++) enc_bin(e, &r, byc + (k >> shift), 1);
+    if (gy < gmax) enc_bin(e, &r, byc + (k >> shift), 0);
+    if (gx > 3) enc_ep(&r, (gx - 2) >> 1);
+    if (gy > 3) enc_ep(&r, (gy - 2) >> 1);
   }
   const int firstCtx = first_sig_ctx(n, scanType, chroma), sigOff = C_SIG + (chroma ? 28 : 0);
   const int lastScanSet = scanPosLast >> 4;
-  uint32_t c1 = 1; int scanPosSig = scanPosLast;
+  int c1 = 1;
   for (int subSet = lastScanSet; subSet >= 0; subSet--) {
-    int numNonZero = 0; const int subPos = subSet << 4; uint32_t goRice = 0;
-    int32_t *absCoeff = e->absCoeff; int lastNZ = -1, firstNZ = 16; int escape = 0;
-    if (scanPosSig == scanPosLast) { absCoeff[0] = hm_abs(lv[scanPosLast]); numNonZero = 1; lastNZ = scanPosSig; firstNZ = scanPosSig; scanPosSig--; }
-    const int cgBlkPos = scanCG[subSet], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
-    if (subSet == lastScanSet || subSet == 0) cgFlag[cgBlkPos] = 1;
-    else HM_BIN(C_SIG_CG + (chroma ? 2 : 0) + sig_cg_ctx(cgFlag, cgx, cgy, wg), cgFlag[cgBlkPos] != 0);
-    if (cgFlag[cgBlkPos]) {
-      const int pattern = pattern_sig_ctx(cgFlag, cgx, cgy, wg);
-      for (; scanPosSig >= subPos; scanPosSig--) {
-        const int cv = lv[scanPosSig]; const int sig = cv != 0;
-        if (scanPosSig > subPos || subSet == 0 || numNonZero)
-          HM_BIN(sigOff + sig_ctx_inc(pattern, firstCtx, sposArr[scanPosSig], log2n, chroma), sig);
-        if (sig) { absCoeff[numNonZero] = hm_abs(cv); numNonZero++; if (lastNZ == -1) lastNZ = scanPosSig; firstNZ = scanPosSig; }
+    const int subPos = subSet << 4, isLastSet = subSet == lastScanSet;
+    const int cgBlkPos = HM_LV_GET(vScanCG, subSet), cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
+    const int sigRight = (cgx < wg - 1) ? (int)((cgMask >> (cgBlkPos + 1)) & 1) : 0;
+    const int sigLower = (cgy < wg - 1) ? (int)((cgMask >> (cgBlkPos + wg)) & 1) : 0;
+    if (isLastSet || subSet == 0) cgMask |= 1ull << cgBlkPos;
+    else enc_bin(e, &r, C_SIG_CG + (chroma ? 2 : 0) + ((sigRight + sigLower) != 0), (int)((cgMask >> cgBlkPos) & 1));
+    if (!((cgMask >> cgBlkPos) & 1)) continue;
+    const int pattern = wg <= 1 ? 0 : sigRight + (sigLower << 1);
+    const int top = isLastSet ? (scanPosLast & 15) : 15;            // highest coded position of this group
+    HM_LV(int32_t, vCtx); HM_LV(int32_t, vAbs);
+    uint64_t nz = 0, g1 = 0, g2 = 0;
+    HM_WAVE_FOR(k) {
+      const int kk = k & 15, sp = subPos + kk;
+      const int a = (kk <= top) ? hm_abs((int)lv[sp]) : 0;
+      HM_LVK(vAbs, k) = a;
+      HM_LVK(vCtx, k) = sig_ctx_inc(pattern, firstCtx, sposArr[sp], log2n, chroma);
+      HM_BALLOT(nz, k, a != 0 && k < 16); HM_BALLOT(g1, k, a > 1 && k < 16); HM_BALLOT(g2, k, a > 2 && k < 16);
+    }
+    { // significance flags; the last significant coefficient itself is implied
+      int seen = isLastSet ? 1 : 0;
+      for (int p = isLastSet ? top - 1 : 15; p >= 0; p--) {
+        const int sig = (int)((nz >> p) & 1);
+        if (p > 0 || subSet == 0 || seen) enc_bin(e, &r, sigOff + HM_LV_GET(vCtx, p), sig);
+        seen += sig;
       }
-    } else scanPosSig = subPos - 1;
+    }
+    const int numNonZero = __builtin_popcountll(nz);
     if (numNonZero > 0) {
+      const int lastNZ = 63 - __builtin_clzll(nz), firstNZ = __builtin_ctzll(nz);
       const int signHidden = (lastNZ - firstNZ >= 4);
       const int ctxSet = ctx_set_index(chroma, subSet, c1 == 0);
       c1 = 1;
-      const int numC1 = numNonZero < 8 ? numNonZero : 8; int firstC2 = -1;
-      for (int idx = 0; idx < numC1; idx++) {
-        const int sym = absCoeff[idx] > 1;
-        HM_BIN(C_ONE + 4 * ctxSet + (int)c1, sym);
-        if (sym) { c1 = 0; if (firstC2 == -1) firstC2 = idx; else escape = 1; }
+      int firstC2 = -1, escape = 0, idx = 0;
+      for (uint64_t m = nz; m && idx < 8; idx++) {
+        const int p = 63 - __builtin_clzll(m); m &= ~(1ull << p);
+        const int sym = (int)((g1 >> p) & 1);
+        enc_bin(e, &r, C_ONE + 4 * ctxSet + c1, sym);
+        if (sym) { c1 = 0; if (firstC2 == -1) firstC2 = p; else escape = 1; }
         else if (c1 < 3 && c1 > 0) c1++;
       }
-      if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; HM_BIN(C_ABS + ctxSet, sym); if (sym) escape = 1; }
+      if (c1 == 0 && firstC2 != -1) { const int sym = (int)((g2 >> firstC2) & 1); enc_bin(e, &r, C_ABS + ctxSet, sym); if (sym) escape = 1; }
       escape = escape || (numNonZero > 8);
-      fr += (uint64_t)32768 * (uint64_t)(signHidden ? numNonZero - 1 : numNonZero);
-      int firstCoeff2 = 1;
-      if (escape)
-        for (int idx = 0; idx < numNonZero; idx++) {
+      enc_ep(&r, signHidden ? numNonZero - 1 : numNonZero);
+      if (escape) {
+        int firstCoeff2 = 1; uint32_t goRice = 0; idx = 0;
+        for (uint64_t m = nz; m; idx++) {
+          const int p = 63 - __builtin_clzll(m); m &= ~(1ull << p);
+          const int a = HM_LV_GET(vAbs, p);
           const int baseLevel = (idx < 8) ? (2 + firstCoeff2) : 1;
-          if (absCoeff[idx] >= baseLevel) {
-            uint32_t sym = (uint32_t)(absCoeff[idx] - baseLevel);
-            if (sym < (3u << goRice)) fr += (uint64_t)32768 * (uint64_t)((sym >> goRice) + 1 + goRice);
-            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++)); fr += (uint64_t)32768 * (uint64_t)(3 + len + 1 - goRice + len); }
-            if ((uint32_t)absCoeff[idx] > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
+          if (a >= baseLevel) {
+            uint32_t sym = (uint32_t)(a - baseLevel);
+            if (sym < (3u << goRice)) enc_ep(&r, (int)((sym >> goRice) + 1 + goRice));
+            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++)); enc_ep(&r, (int)(3 + len + 1 - goRice + len)); }
+            if ((uint32_t)a > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
           }
-          if (absCoeff[idx] >= 2) firstCoeff2 = 0;
+          if (a >= 2) firstCoeff2 = 0;
         }
+      }
     }
   }
-  c->frac += fr;
-  HM_SYNC();
+  cabr_store(r, c);
 }
-#undef HM_BIN
+
 
 // TEncSbac::codeIntraDirLumaAng, TEncSbac.cpp:636-690
 HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
@@ -1350,9 +1541,9 @@ HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChro
   if (bChroma && relZ == 0) code_intra_dir_chroma(e, &e->cur, t->cuZ + relZ);
 }
 // xGetIntraBitsQT, TEncSearch.cpp:1038-1060
-HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU tv, int bLuma, int bChroma)
+HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, TU tv, int bLuma, int bChroma)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); bLuma = HM_UNI(bLuma); bChroma = HM_UNI(bChroma); tv = hm_uni_struct(tv);
   const TU *t = &tv;
   HM_PROF_BEGIN(e, PR_BITS);
   reset_bits(&e->cur);
@@ -1367,9 +1558,9 @@ HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, const TU tv, int bLuma, int
 // ------------------------------------------------------------------------------------------------
 // one TU: predict, transform, RDOQ, reconstruct (TEncSearch::xIntraCodingTUBlock :1074-1357)
 // ------------------------------------------------------------------------------------------------
-HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU tv, int comp, int save1load2)
+HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, TU tv, int comp, int save1load2)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); comp = HM_UNI(comp); save1load2 = HM_UNI(save1load2); tv = hm_uni_struct(tv);
   const TU *t = &tv;
   CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
   if (comp && !t->cW) return 0;
@@ -1407,10 +1598,10 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, const TU tv, int co
   { HM_PROF_BEGIN(e, PR_FWD); if (!tskip) fwd_transform(e, n, comp == 0 && n == 4, bitDepth); HM_PROF_END(e, PR_FWD); }      // TComTrQuant::xT, :1805
   const int cbfCtx = comp ? 5 + t->trDepth : (t->trDepth == 0 ? 1 : 0);
   HM_PROF_BEGIN(e, PR_RDOQ);
-  const int absSum = rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx);
+  const int absSum = HM_UCALL(rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx));
   HM_PROF_END(e, PR_RDOQ);
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-  { const int pid = l2 == 2 ? (absSum ? 13 : 7) : (l2 == 3 ? 14 : 15); e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }
+  { const int pid = l2 == 2 ? (absSum ? 13 : 7) : 14; e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }
 #endif
   par_set8(m->cbf[comp] + z, (absSum > 0 ? 1 : 0) << t->trDepth, parts);   // setCbfPartRange, TComTrQuant.cpp:1419
   HM_PROF_BEGIN(e, PR_INV);
@@ -1479,9 +1670,9 @@ HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
 // luma residual quadtree (TEncSearch::xRecurIntraCodingQT :1364-1733, bLumaOnly), explicit stack
 // ------------------------------------------------------------------------------------------------
 // returns distortion through *distY and adds the RD cost to *rdCost, exactly like the recursive reference
-HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int checkFirst)
+HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirst)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); checkFirst = HM_UNI(checkFirst); rootv = hm_uni_struct(rootv);
   CtuMeta *m = (&e->meta);
   RqtFrame *fr = e->rqt; int sp = 0;
   uint32_t *retDist = e->rqtRetDist; double *retCost = e->rqtRetCost;     // accumulators handed to each level by its parent
@@ -1502,10 +1693,10 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
           for (int modeId = 0; modeId < 2; modeId++) {
             double costTmp;
             par_set8(m->ts[0] + z, modeId, t->parts);
-            const uint32_t distTmp = intra_coding_tu_block(e, *t, 0, modeId == 0 ? 1 : 2);
+            const uint32_t distTmp = HM_UCALL(intra_coding_tu_block(e, *t, 0, modeId == 0 ? 1 : 2));
             const uint32_t cbfTmp = (m->cbf[0][z] >> t->trDepth) & 1;
             if (modeId == 1 && cbfTmp == 0) costTmp = HM_MAX_DOUBLE;
-            else { const uint32_t bits = intra_bits_qt(e, *t, 1, 0); costTmp = calc_rd_cost(e, bits, distTmp); }
+            else { const uint32_t bits = HM_UCALL(intra_bits_qt(e, *t, 1, 0)); costTmp = calc_rd_cost(e, bits, distTmp); }
             if (costTmp < f->singleCost) {
               f->singleCost = costTmp; f->singleDist = distTmp; f->singleCbf = cbfTmp; f->bestModeId = (int8_t)modeId;
               if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
@@ -1521,9 +1712,9 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
         } else {
           if (f->checkSplit) cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
           par_set8(m->ts[0] + z, 0, t->parts);
-          f->singleDist = intra_coding_tu_block(e, *t, 0, 0);
+          f->singleDist = HM_UCALL(intra_coding_tu_block(e, *t, 0, 0));
           if (f->checkSplit) f->singleCbf = (m->cbf[0][z] >> t->trDepth) & 1;
-          const uint32_t bits = intra_bits_qt(e, *t, 1, 0);
+          const uint32_t bits = HM_UCALL(intra_bits_qt(e, *t, 1, 0));
           f->singleCost = calc_rd_cost(e, bits, f->singleDist);
         }
       }
@@ -1545,7 +1736,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, const TU rootv, int che
       f->splitDist = retDist[sp + 1];
       if (f->splitCbf) { HM_PAR_FOR(o, t->parts) m->cbf[0][z + o] |= (uint8_t)(1 << t->trDepth); HM_SYNC(); }
       cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
-      const uint32_t splitBits = intra_bits_qt(e, *t, 1, 0);
+      const uint32_t splitBits = HM_UCALL(intra_bits_qt(e, *t, 1, 0));
       f->splitCost = calc_rd_cost(e, splitBits, f->splitDist);
       if (f->splitCost < f->singleCost) { retDist[sp] += f->splitDist; retCost[sp] += f->splitCost; sp--; continue; }
       cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)]);
@@ -1583,7 +1774,7 @@ HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
 // ------------------------------------------------------------------------------------------------
 HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth);
   CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
   const int cuParts = 256 >> (2 * cuDepth);
   const int nxn = m->part[cuZ] == SIZE_NxN;
@@ -1690,7 +1881,7 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
       par_set8(m->ts[comp] + zc, tsMode, t->cParts);
       currModeId++;
       const int isOne = (total == 1), isLast = (currModeId == total);
-      const uint32_t distTmp = intra_coding_tu_block(e, *t, comp, isOne ? 0 : (tsMode == 0 ? 1 : 2));
+      const uint32_t distTmp = HM_UCALL(intra_coding_tu_block(e, *t, comp, isOne ? 0 : (tsMode == 0 ? 1 : 2)));
       const uint32_t cbfTmp = (m->cbf[comp][zc] >> t->trDepth) & 1;
       if (tsMode == 1 && cbfTmp == 0) costTmp = HM_MAX_DOUBLE;
       else if (!isOne) { reset_bits(&e->cur); enc_coeff_qt(e, t, comp); costTmp = calc_rd_cost(e, num_bits(&e->cur), distTmp); }   // xGetIntraBitsQTChroma
@@ -1710,9 +1901,9 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
   }
   return dist;
 }
-HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, const TU rootv)
+HM_DEV HM_NOINLINE uint32_t recur_intra_chroma_coding_qt(Shared *e, TU rootv)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); rootv = hm_uni_struct(rootv);
   const TU *root = &rootv;
   CtuMeta *m = (&e->meta);
   uint32_t dist = 0;
@@ -1763,7 +1954,7 @@ HM_DEV inline void set_intra_result_chroma_qt(Shared *e, const TU *root)
 }
 HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuDepth)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth);
   CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws; const int cuParts = 256 >> (2 * cuDepth);
   const TU t = tu_root(e, cuZ, cuDepth);
   int bestMode = 0; uint32_t bestDist = 0; double bestCost = HM_MAX_DOUBLE;
@@ -1772,9 +1963,9 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
   for (int mi = 0; mi < 5; mi++) {
     cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
     par_set8(m->dirC + cuZ, modeList[mi], cuParts);
-    const uint32_t dist = recur_intra_chroma_coding_qt(e, t);
+    const uint32_t dist = HM_UCALL(recur_intra_chroma_coding_qt(e, t));
     cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
-    const uint32_t bits = intra_bits_qt(e, t, 0, 1);
+    const uint32_t bits = HM_UCALL(intra_bits_qt(e, t, 0, 1));
     const double cost = calc_rd_cost(e, bits, dist);
     if (cost < bestCost) {
       bestCost = cost; bestDist = dist; bestMode = modeList[mi];
@@ -1794,7 +1985,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
 // ------------------------------------------------------------------------------------------------
 HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDepth)
 {
-  HM_ASSUME_LDS(e); // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); c = hm_uni_ptr(c); HM_ASSUME_LDS(c); // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
   const CtuMeta *m = (&e->meta);
   if (cuDepth == 3) enc_bin(e, c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
   code_intra_dir_luma(e, c, cuZ, 1);
@@ -1856,7 +2047,7 @@ HM_DEV inline void meta_copy_range(CtuMeta *d, const CtuMeta *s, int z0, int par
 }
 HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth);
   HM_PROF_BEGIN(e, PR_SAVE);
   Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
   meta_copy_range(&b->m, (&e->meta), cuZ, parts);
@@ -1873,7 +2064,7 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
 }
 HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
 {
-  HM_ASSUME_LDS(e); // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
   const Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
   meta_copy_range((&e->meta), &b->m, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = b->coef[cuZ * 16 + i];
@@ -1893,19 +2084,19 @@ HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
 // xCheckRDCostIntra, TEncCu.cpp:1574-1646; leaves the trial in place
 HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int partSize)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize);
   CtuMeta *m = (&e->meta); const int parts = 256 >> (2 * cuDepth);
   init_est_data(e, cuZ, cuDepth);
   HM_PAR_FOR(i, parts) { m->part[cuZ + i] = (uint8_t)partSize; m->pred[cuZ + i] = MODE_INTRA; }
   HM_SYNC();
   HM_PROF_BEGIN(e, PR_LUMA);
-  uint32_t d = est_intra_pred_qt(e, cuZ, cuDepth);
+  uint32_t d = HM_UCALL(est_intra_pred_qt(e, cuZ, cuDepth));
   HM_PROF_END(e, PR_LUMA);
   { // luma reconstruction of the CU into the picture, TEncCu.cpp:1608
     const int r = hm_z2r(cuZ), x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, ps = e->stride[0];
     par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + y) * ps + e->ctuX * 64 + x, ps, e->ws->reco + y * 64 + x, 64, n);
   }
-  { HM_PROF_BEGIN(e, PR_CHROMA); d += est_intra_pred_chroma_qt(e, cuZ, cuDepth); HM_PROF_END(e, PR_CHROMA); }
+  { HM_PROF_BEGIN(e, PR_CHROMA); d += HM_UCALL(est_intra_pred_chroma_qt(e, cuZ, cuDepth)); HM_PROF_END(e, PR_CHROMA); }
   reset_bits(&e->cur);
   { HM_PROF_BEGIN(e, PR_ENCCU); encode_cu_syntax(e, &e->cur, cuZ, cuDepth); HM_PROF_END(e, PR_ENCCU); }
   cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
@@ -1917,7 +2108,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
 // TEncCu::compressCtu -> xCompressCU recursion as a 4-level state machine
 HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e);
   CtuMeta *m = (&e->meta);
   CuFrame *fr = e->cuf; int sp = 0;
   fr[0].cuZ = 0; fr[0].phase = 0;
@@ -1988,7 +2179,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 // TEncCu::xEncodeCU, TEncCu.cpp:1185-1295: re-encode the decided CTU to advance the contexts
 HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
 {
-  HM_ASSUME_LDS(e);
+  HM_ENTRY(e); lastCtuOfSlice = HM_UNI(lastCtuOfSlice); c = hm_uni_ptr(c); HM_ASSUME_LDS(c);
   const CtuMeta *m = (&e->meta);
   int16_t stackZ[4]; int8_t stackNext[4]; int sp = 0;
   stackZ[0] = 0; stackNext[0] = -1;
