@@ -59,6 +59,8 @@ static inline int hm_wave_max_i(int v) { return v; }
 #define HM_LV_SETD(name, i, v) (name[i] = (v))
 #define HM_LV_GATHER(name, idx) (name[idx])
 #define HM_BALLOT(m, k, cond) do { if (cond) (m) |= 1ull << (k); } while (0)
+#define HM_ORDERED_ADD16(acc, name) do { for (int k_ = 15; k_ >= 0; k_--) (acc) += name[k_]; } while (0)
+#define HM_ORDERED_CHAIN16(acc, a, b, pre) do { for (int k_ = 15; k_ >= 0; k_--) { pre[k_] = (acc); (acc) -= a[k_]; (acc) += b[k_]; } } while (0)
 #else
 #define HM_DEV __device__
 #define HM_NOINLINE __attribute__((noinline))
@@ -77,23 +79,24 @@ __device__ __forceinline__ int hm_lane() { return (int)threadIdx.x; }
 // one wavefront per CTU: lanes run in lockstep, so a phase boundary only has to order this wave's own LDS /
 // global accesses (wavefront-scope fence) -- no s_barrier and no drain of outstanding stores
 #define HM_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-__device__ __forceinline__ uint32_t hm_wave_sum(uint32_t v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);   // every lane holds the total: tell the compiler it is wave-uniform
-}
+// Wave reductions on the DPP path: four row_shr steps leave each 16-lane row's result in its last lane, the four row
+// results are read with v_readlane and combined on the scalar unit.  The result is wave-uniform by construction
+// (SGPR), which keeps the decision code that depends on it scalar.
+template <int CTRL> __device__ __forceinline__ int hm_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
 __device__ __forceinline__ int hm_wave_sum_i(int v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return __builtin_amdgcn_readfirstlane(v);
+  v += hm_dpp<0x111>(0, v); v += hm_dpp<0x112>(0, v); v += hm_dpp<0x114>(0, v); v += hm_dpp<0x118>(0, v);   // row_shr:1,2,4,8
+  return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ uint32_t hm_wave_sum(uint32_t v) { return (uint32_t)hm_wave_sum_i((int)v); }
 __device__ __forceinline__ int hm_wave_max_i(int v)
 {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-  return __builtin_amdgcn_readfirstlane(v);
+  int t;
+  t = hm_dpp<0x111>(v, v); v = t > v ? t : v; t = hm_dpp<0x112>(v, v); v = t > v ? t : v;
+  t = hm_dpp<0x114>(v, v); v = t > v ? t : v; t = hm_dpp<0x118>(v, v); v = t > v ? t : v;
+  const int a = __builtin_amdgcn_readlane(v, 15), b = __builtin_amdgcn_readlane(v, 31), c = __builtin_amdgcn_readlane(v, 47), d = __builtin_amdgcn_readlane(v, 63);
+  const int ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
 #define HM_LDS_ADD(p, v) atomicAdd((p), (v))
 // wave-uniform value loaded through the vector path -> SGPR, so that the dependent control code runs on the scalar unit
@@ -134,6 +137,12 @@ template <class T> __device__ __forceinline__ T hm_uni_struct(T v)
 #define HM_LV_SETD(name, i, v) ((name) = (hm_lane() == (int)(i)) ? (v) : (name))
 #define HM_LV_GATHER(name, idx) __builtin_amdgcn_ds_bpermute((int)(idx) << 2, (int)(name))
 #define HM_BALLOT(m, k, cond) ((m) = __ballot(cond))
+// acc += lane 15, then lane 14, ... lane 0 of a double lane variable: the reference's position-by-position running sum
+// (fp64 additions do not commute), fully unrolled so that every v_readlane has an immediate lane index
+#define HM_ORDERED_ADD16(acc, name) do { _Pragma("unroll") for (int k_ = 15; k_ >= 0; k_--) (acc) += hm_readlane_d((name), k_); } while (0)
+// the same for acc = (acc - a[k]) + b[k], remembering in pre[k] the value acc had before position k
+#define HM_ORDERED_CHAIN16(acc, a, b, pre) do { _Pragma("unroll") for (int k_ = 15; k_ >= 0; k_--) { \
+    (pre) = (hm_lane() == k_) ? (acc) : (pre); (acc) -= hm_readlane_d((a), k_); (acc) += hm_readlane_d((b), k_); } } while (0)
 __device__ __forceinline__ double hm_readlane_d(double v, int i)
 { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), i), __builtin_amdgcn_readlane(__double2loint(v), i)); }
 #endif
@@ -413,8 +422,8 @@ HM_DEV inline uint32_t had4(const Pel *org, int so, const Pel *cur, int sc)
 }
 HM_DEV inline uint32_t dist_hads(const Pel *org, int so, const Pel *cur, int sc, int n, int bitDepth)
 { // xGetHADs, TComRdCost.cpp:1537-1606
-  uint32_t sum = 0;
-  if (n >= 8) { const int nb = n >> 3; HM_PAR_FOR(b, nb * nb) { const int by = b / nb, bx = b - by * nb; sum += had8(org + by * 8 * so + bx * 8, so, cur + by * 8 * sc + bx * 8, sc); } }
+  uint32_t sum = 0; const int l2 = hm_log2(n);
+  if (n >= 8) { const int nb = n >> 3; HM_PAR_FOR(b, nb * nb) { const int by = b >> (l2 - 3), bx = b & (nb - 1); sum += had8(org + by * 8 * so + bx * 8, so, cur + by * 8 * sc + bx * 8, sc); } }
   else { HM_PAR_FOR(b, 1) sum += had4(org, so, cur, sc); }
   return hm_wave_sum(sum) >> (bitDepth - 8);
 }
@@ -581,7 +590,7 @@ HM_DEV inline int avail_below_left(const Shared *e, int lbx4, int lby4, int k)
 HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, int n, int x4, int y4, int units, int filter)
 {
   HM_ENTRY(e); comp = HM_UNI(comp); px = HM_UNI(px); py = HM_UNI(py); n = HM_UNI(n); x4 = HM_UNI(x4); y4 = HM_UNI(y4); units = HM_UNI(units); filter = HM_UNI(filter);
-  const int uw = comp ? 2 : 4, total = 4 * units + 1, L = 2 * units, n2 = 2 * n;
+  const int uw = comp ? 2 : 4, uwShift = comp ? 1 : 2, total = 4 * units + 1, L = 2 * units, n2 = 2 * n;
   const int bitDepth = e->bitDepth;
   uint8_t *flags = e->flags;
   // availability flag of every unit: one lane per unit, then a wave reduction for the count
@@ -609,9 +618,9 @@ HM_DEV HM_NOINLINE void init_adi_pattern(Shared *e, int comp, int px, int py, in
     Pel *line = e->u.ref.line; const int nl = n2 + uw + n2;
     HM_PAR_FOR(i, nl) {
       int v = dc;
-      if (i < n2) { const int j = (n2 - 1 - i); if (flags[L - 1 - j / uw]) v = rec[(py + j) * st + px - 1]; }
+      if (i < n2) { const int j = (n2 - 1 - i); if (flags[L - 1 - (j >> uwShift)]) v = rec[(py + j) * st + px - 1]; }
       else if (i < n2 + uw) { if (flags[L]) v = rec[(py - 1) * st + px - 1]; }
-      else { const int j = i - n2 - uw; if (flags[L + 1 + j / uw]) v = rec[(py - 1) * st + px + j]; }
+      else { const int j = i - n2 - uw; if (flags[L + 1 + (j >> uwShift)]) v = rec[(py - 1) * st + px + j]; }
       line[i] = (Pel)v;
     }
     HM_SYNC();
@@ -802,7 +811,7 @@ HM_DEV HM_NOINLINE void satd_all_modes_small(Shared *e, const Pel *org, int so, 
   } else {
     const int nb = n >> 3;
     HM_PAR_FOR(task, 35 * nb * nb) {
-      const int mode = task / (nb * nb), b = task - mode * nb * nb, by = (b / nb) * 8, bx = (b % nb) * 8;
+      const int mode = task >> (2 * (l2 - 3)), b = task & (nb * nb - 1), by = (b >> (l2 - 3)) * 8, bx = (b & (nb - 1)) * 8;
       int d[64];
 #pragma unroll
       for (int i = 0; i < 64; i++) d[i] = org[(by + (i >> 3)) * so + bx + (i & 7)] - pred_sample(e, mode, n, l2, bx + (i & 7), by + (i >> 3), dcVal, bitDepth);
@@ -1031,7 +1040,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   const int cgLastScanPos = lastScanPos >> 4;
   int ctxSet = ctx_set_index(chroma, lastScanPos >> 4, 0), c1 = 1, c2 = 0, c1Idx = 0, c2Idx = 0, goRice = 0;
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0; cgScanPos--) {
-    const int cgBlkPos = scanCG[cgScanPos], cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
+    const int cgBlkPos = scanCG[cgScanPos], cgy = cgBlkPos >> (log2n - 2), cgx = cgBlkPos & (wg - 1);
     const uint64_t cgBit = 1ull << cgBlkPos;
     double sigCost = 0, sigCost0 = 0, codedLevelAndDist = 0, uncodedDist = 0; int nnzBeforePos0 = 0;
     const int sigRight = (cgx < wg - 1) ? (int)((cgMask >> (cgBlkPos + 1)) & 1) : 0;       // calcPatternSigCtx, TComTrQuant.cpp:2522
@@ -1046,12 +1055,13 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     HM_PROF_BEGIN(e, 22);
     HM_WAVE_FOR(k) {
       const int scanPos = cgScanPos * 16 + (k & 15), blkPos = rqPos[scanPos] & 0x3ff;
+      const int inRange = (k & 15) <= startPos;                   // positions behind the last significant one add +0.0
       const int32_t lvl = rqLvl[scanPos];
       uint32_t mx = (uint32_t)((lvl + (1 << (qBits - 1))) >> qBits); if (mx > 32767u) mx = 32767u;
-      const double err = (double)lvl, c0 = err * err * errScale;
+      const double err = (double)lvl, c0 = inRange ? err * err * errScale : 0.0;
       const int sigIdx = (scanPos == lastScanPos) ? 0 : sig_ctx_inc(pattern, firstCtx, blkPos, log2n, chroma);
       const int b0 = HM_LV_GATHER(tSig, sigIdx * 2), b1 = HM_LV_GATHER(tSig, sigIdx * 2 + 1);
-      const double s0 = lambda * (double)b0;
+      const double s0 = inRange ? lambda * (double)b0 : 0.0;
       HM_LVK(vLvl, k) = lvl; HM_LVK(vMx, k) = (int32_t)mx; HM_LVK(vSigIdx, k) = sigIdx; HM_LVK(vB0, k) = b0; HM_LVK(vB1, k) = b1;
       HM_LVK(vC0, k) = c0; HM_LVK(vS0, k) = s0; HM_LVK(vCoef0, k) = c0 + s0; HM_LVK(vCC, k) = 0;
       HM_LVK(vDec, k) = 0; HM_LVK(vCode, k) = 1;
@@ -1059,15 +1069,14 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     }
     HM_PROF_END(e, 22);
     HM_PROF_BEGIN(e, 23);
-    for (int posInCG = startPos; posInCG >= 0; posInCG--) {
+    // level decisions: only the positions with a non-zero quantised magnitude take part in the context chain; their
+    // final cost replaces the zero-hypothesis cost in the lane variables (vCoef0 / vS0)
+    for (uint64_t todo = nzMask; todo;) {
+      const int posInCG = 63 - __builtin_clzll(todo); todo &= ~(1ull << posInCG);
       const int scanPos = cgScanPos * 16 + posInCG;
-      const double c0 = HM_LV_GETD(vC0, posInCG);
-      blockUncodedCost += c0;
       uint32_t level = 0;
       double cCoeff, cSig;
-      if (!((nzMask >> posInCG) & 1)) { cCoeff = HM_LV_GETD(vCoef0, posInCG); cSig = HM_LV_GETD(vS0, posInCG); }
-      else {
-        HM_PROF_BEGIN(e, 15);
+      {
         const uint32_t maxAbsLevel = (uint32_t)HM_LV_GET(vMx, posInCG);
         const int32_t levelDouble = HM_LV_GET(vLvl, posInCG);
         const int ctxOne = 4 * ctxSet + c1, ctxAbs = ctxSet;
@@ -1091,28 +1100,29 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
         }
         cSig = lambda * (double)sigBits;
         HM_LV_SET(vCode, posInCG, sigCode); HM_LV_SET(vDec, posInCG, (int32_t)level);
+        HM_LV_SETD(vCoef0, posInCG, cCoeff); HM_LV_SETD(vS0, posInCG, cSig);
         const uint32_t baseLevel = (c1Idx < 8) ? (2 + (c2Idx < 1)) : 1;
         if (level >= baseLevel && level > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
         if (level >= 1) c1Idx++;
         if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
         else if (c1 < 3 && c1 > 0 && level) c1++;
-        HM_PROF_END(e, 15);
       }
-      baseCost += cCoeff;
-      if (posInCG == 0 && scanPos > 0) {
-        ctxSet = ctx_set_index(chroma, (scanPos - 1) >> 4, c1 == 0);
-        c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
-      }
-      sigCost += cSig;
-      if (posInCG == 0) sigCost0 = cSig;
       if (level) {
         HM_LV_SETD(vCC, posInCG, cCoeff);
         cgMask |= cgBit;
         codedLevelAndDist += cCoeff - cSig;
-        uncodedDist += c0;
+        uncodedDist += HM_LV_GETD(vC0, posInCG);
         if (posInCG != 0) nnzBeforePos0++;
       }
     }
+    if (cgScanPos > 0) {                   // the next group starts a fresh context set
+      ctxSet = ctx_set_index(chroma, (cgScanPos * 16 - 1) >> 4, c1 == 0);
+      c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0;
+    }
+    // the three running sums of the reference, position by position from 15 down to 0
+    HM_ORDERED_ADD16(baseCost, vCoef0);
+    HM_ORDERED_ADD16(blockUncodedCost, vC0);
+    if (cgScanPos) { HM_ORDERED_ADD16(sigCost, vS0); sigCost0 = HM_LV_GETD(vS0, 0); }
     HM_PROF_END(e, 23);
     int zeroed = 0;
     if (cgScanPos) {
@@ -1153,36 +1163,36 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     const int cgBlkPos = scanCG[cgScanPos];
     baseCost -= HM_LV_GETD(vCGSig, cgScanPos);
     if (!((cgMask >> cgBlkPos) & 1)) continue;
-    HM_LV(double, dSig); HM_LV(double, dLast); HM_LV(double, dCC); HM_LV(double, dErr);
+    // per position: baseCost = (baseCost - A) + B with A = cost of the coded level (or of the significance flag of a
+    // zero), B = distortion of the uncoded level (or +0.0); a coded position first offers itself as the last one
+    HM_LV(double, dSig); HM_LV(double, dLast); HM_LV(double, dA); HM_LV(double, dB); HM_LV(double, dPre);
     uint64_t curMask = 0, gt1Mask = 0;
     HM_WAVE_FOR(k) {
       const int scanPos = cgScanPos * 16 + (k & 15);
+      const int inRange = scanPos <= lastScanPos;
       const int cur = rqCur[scanPos], code = rqCode[scanPos], sigIdx = rqCtxSig[scanPos];
       const int sb = HM_LV_GATHER(tSig, sigIdx * 2 + (code ? code - 1 : 0));
-      HM_LVK(dSig, k) = lambda * (double)(code ? sb : 0);
+      const double cSig = lambda * (double)(code ? sb : 0);
+      HM_LVK(dSig, k) = cSig;
       const int blkPos = rqPos[scanPos] & 0x3ff;
       int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
       if (scanType == SCAN_VER) { const int t = posX; posX = posY; posY = t; }
       const int lb = HM_LV_GATHER(tLastCost, hm_group_idx(posX)) + HM_LV_GATHER(tLastCost, 16 + hm_group_idx(posY));
       HM_LVK(dLast, k) = lambda * (double)lb;
-      HM_LVK(dCC, k) = costCoeff[scanPos];
       const double err = (double)rqLvl[scanPos];
-      HM_LVK(dErr, k) = err * err * errScale;
+      HM_LVK(dA, k) = !inRange ? 0.0 : (cur ? costCoeff[scanPos] : cSig);
+      HM_LVK(dB, k) = (inRange && cur) ? err * err * errScale : 0.0;
+      HM_LVK(dPre, k) = 0;
       HM_BALLOT(curMask, k, cur != 0 && k < 16);
       HM_BALLOT(gt1Mask, k, cur > 1 && k < 16);
     }
-    for (int posInCG = 15; posInCG >= 0; posInCG--) {
-      const int scanPos = cgScanPos * 16 + posInCG;
-      if (scanPos > lastScanPos) continue;
-      const double cSig = HM_LV_GETD(dSig, posInCG);
-      if ((curMask >> posInCG) & 1) {
-        const double costLast = HM_LV_GETD(dLast, posInCG);
-        const double t1 = baseCost + costLast;
-        const double totalCost = t1 - cSig;
-        if (totalCost < bestCost) { bestLastIdxP1 = scanPos + 1; bestCost = totalCost; }
-        if ((gt1Mask >> posInCG) & 1) { foundLast = 1; break; }
-        baseCost -= HM_LV_GETD(dCC, posInCG); baseCost += HM_LV_GETD(dErr, posInCG);
-      } else baseCost -= cSig;
+    HM_ORDERED_CHAIN16(baseCost, dA, dB, dPre);                  // dPre[k] = baseCost before position k
+    for (uint64_t todo = curMask; todo;) {
+      const int posInCG = 63 - __builtin_clzll(todo); todo &= ~(1ull << posInCG);
+      const double t1 = HM_LV_GETD(dPre, posInCG) + HM_LV_GETD(dLast, posInCG);
+      const double totalCost = t1 - HM_LV_GETD(dSig, posInCG);
+      if (totalCost < bestCost) { bestLastIdxP1 = cgScanPos * 16 + posInCG + 1; bestCost = totalCost; }
+      if ((gt1Mask >> posInCG) & 1) { foundLast = 1; break; }
     }
   }
   HM_PROF_END(e, 19);
@@ -1360,7 +1370,7 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
   int c1 = 1;
   for (int subSet = lastScanSet; subSet >= 0; subSet--) {
     const int subPos = subSet << 4, isLastSet = subSet == lastScanSet;
-    const int cgBlkPos = HM_LV_GET(vScanCG, subSet), cgy = cgBlkPos / wg, cgx = cgBlkPos - cgy * wg;
+    const int cgBlkPos = HM_LV_GET(vScanCG, subSet), cgy = cgBlkPos >> (log2n - 2), cgx = cgBlkPos & (wg - 1);
     const int sigRight = (cgx < wg - 1) ? (int)((cgMask >> (cgBlkPos + 1)) & 1) : 0;
     const int sigLower = (cgy < wg - 1) ? (int)((cgMask >> (cgBlkPos + wg)) & 1) : 0;
     if (isLastSet || subSet == 0) cgMask |= 1ull << cgBlkPos;
@@ -1536,7 +1546,7 @@ HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChro
   if (bLuma) {
     if (relZ == 0 && t->cuDepth == 3) enc_bin(e, &e->cur, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
     if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, &e->cur, t->cuZ, 0); }
-    else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ % q) == 0) code_intra_dir_luma(e, &e->cur, t->cuZ + relZ, 0); }
+    else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ & (q - 1)) == 0) code_intra_dir_luma(e, &e->cur, t->cuZ + relZ, 0); }
   }
   if (bChroma && relZ == 0) code_intra_dir_chroma(e, &e->cur, t->cuZ + relZ);
 }
