@@ -49,7 +49,7 @@ __device__ __attribute__((noinline)) int hm355_wait_flag(const unsigned int *fla
   return __shfl(bad, 0, 64);
 }
 
-extern "C" __global__ void __launch_bounds__(64, 2) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
+extern "C" __global__ void __launch_bounds__(64, 4) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
 {
   __shared__ WorkItem curItem;
   for (;;) {
@@ -174,7 +174,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   delete ht;
   HM_CHECK(c, e);
   // one scratch area per resident workgroup of the persistent grid: 256 CUs x 8 single-wave workgroups, or fewer when the batch is small
-  c->wsCount = (size_t)c->numCtus * (size_t)cfg->max_batch; if (c->wsCount > 2048) c->wsCount = 2048;
+  c->wsCount = (size_t)c->numCtus * (size_t)cfg->max_batch; if (c->wsCount > 3072) c->wsCount = 3072;   // 12 searches per CU x 256 CUs is the most that can be resident
   HM_CHECK(c, hipMalloc((void **)&c->dSched, 64)); HM_CHECK(c, hipMemset(c->dSched, 0, 64));
   HM_CHECK(c, hipMalloc((void **)&c->dWs, c->wsCount * sizeof(WorkSpace)));
   HM_CHECK(c, hipMalloc((void **)&c->dFrames, sizeof(FrameBuf) * cfg->max_batch));

@@ -149,7 +149,7 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 
 // optional in-kernel cycle accounting (diagnostic build only: -DHM355_PROFILE, never in the product build)
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-#define HM_PROF_N 24
+#define HM_PROF_N 16
 #define HM_PROF_BEGIN(e, id) const unsigned long long prof_t0_##id = __builtin_readcyclecounter()
 #define HM_PROF_END(e, id) do { (e)->prof[id] += __builtin_readcyclecounter() - prof_t0_##id; (e)->profCnt[id] += 1; } while (0)
 #else
@@ -249,9 +249,9 @@ struct RefLds {
 };
 // slot index: CI_CURR_BEST / CI_NEXT_BEST are never addressed at depth 4
 #define HM_SLOT(d, ci) ((d) * CI_NUM + (ci) - ((d) == 4 ? 2 : 0))
+#define HM_NUM_SLOTS (4 * CI_NUM + 3)
 struct Shared {
   Cabac cur;                           // m_pcRDGoOnSbacCoder
-  Cabac slotArr[4 * CI_NUM + 3];       // m_pppcRDSbacCoder[depth][CI_*]; depth 4 (4x4 TUs of an 8x8 CU) only uses TEMP_BEST/QT_TRAFO_*
   int8_t tmat[32 * HM_TSTRIDE];        // 32-point transform matrix, padded rows
   int32_t bufA[32 * HM_TSTRIDE];
   union {                              // phase-exclusive LDS: transform temp | RDOQ state | intra reference samples
@@ -287,7 +287,7 @@ struct Shared {
 __shared__ Shared g_sh;                // the one CTU search of this workgroup (HM_ENTRY)
 #endif
 #if !defined(HM355_PROFILE)
-static_assert(sizeof(Shared) <= 20480, "Shared must stay within 1/8 of a CU's 160 KB LDS (8 CTU searches per CU)");
+static_assert(sizeof(Shared) + 16 <= 16384, "Shared (+ the kernel's work item) must stay within 1/10 of a CU's 160 KB LDS (10 CTU searches per CU)");
 #endif
 static_assert(offsetof(Shared, bufA) % 8 == 0 && (16 * HM_TSTRIDE * 4) % 8 == 0, "the RDOQ cost array aliases the lower half of bufA as doubles");
 
@@ -972,7 +972,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   int16_t *rqCur = (n == 32) ? ws->rqCur : e->u.rq.cur;
   uint8_t *rqCtxSig = (n == 32) ? ws->rqCtxSig : e->u.rq.ctxSig, *rqCode = (n == 32) ? ws->rqCode : e->u.rq.code;
   // ---- 1. pre-pass
-  HM_PROF_BEGIN(e, 16);
   int lastLocal = -1;
   {
     const int64_t cap = 2147483647LL - (1LL << (qBits - 1));
@@ -989,9 +988,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   }
   const int lastScanPos = hm_wave_max_i(lastLocal);
   HM_SYNC();
-  HM_PROF_END(e, 16);
   if (lastScanPos < 0) return 0;
-  HM_PROF_BEGIN(e, 17);
   // ---- 2. bit-cost tables of the current estimator state (TEncSbac::estBit, TEncSbac.cpp:1717-1956)
   int lastOff, lastShift; last_ctx_params(chroma, n, &lastOff, &lastShift);
   HM_LV(int32_t, tSig); HM_LV(int32_t, tOne); HM_LV(int32_t, tLast); HM_LV(int32_t, tMisc); HM_LV(int32_t, tLastCost);
@@ -1018,8 +1015,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       accX += HM_LV_GET(tLast, cx + 1); accY += HM_LV_GET(tLast, cy + 1);
     }
   }
-  HM_PROF_END(e, 17);
-  HM_PROF_BEGIN(e, 18);
   // ---- 3. decision chain
   double blockUncodedCost = 0;
   // distortion of the positions behind the last significant one: only non-zero terms change the sum
@@ -1034,7 +1029,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     }
     while (m) { const int k = 63 - __builtin_clzll(m); blockUncodedCost += HM_LV_GETD(vT, k); m &= ~(1ull << k); }
   }
-  HM_PROF_END(e, 18);
   double baseCost = blockUncodedCost;
   uint64_t cgMask = 0;                    // significant-coefficient-group flags, bit = raster position of the group
   const int cgLastScanPos = lastScanPos >> 4;
@@ -1052,7 +1046,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     HM_LV(int32_t, vDec); HM_LV(int32_t, vCode);
     HM_LV(double, vC0); HM_LV(double, vS0); HM_LV(double, vCoef0); HM_LV(double, vCC);
     uint64_t nzMask = 0;
-    HM_PROF_BEGIN(e, 22);
     HM_WAVE_FOR(k) {
       const int scanPos = cgScanPos * 16 + (k & 15), blkPos = rqPos[scanPos] & 0x3ff;
       const int inRange = (k & 15) <= startPos;                   // positions behind the last significant one add +0.0
@@ -1067,8 +1060,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       HM_LVK(vDec, k) = 0; HM_LVK(vCode, k) = 1;
       HM_BALLOT(nzMask, k, mx > 0 && k < 16);
     }
-    HM_PROF_END(e, 22);
-    HM_PROF_BEGIN(e, 23);
     // level decisions: only the positions with a non-zero quantised magnitude take part in the context chain; their
     // final cost replaces the zero-hypothesis cost in the lane variables (vCoef0 / vS0)
     for (uint64_t todo = nzMask; todo;) {
@@ -1123,7 +1114,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     HM_ORDERED_ADD16(baseCost, vCoef0);
     HM_ORDERED_ADD16(blockUncodedCost, vC0);
     if (cgScanPos) { HM_ORDERED_ADD16(sigCost, vS0); sigCost0 = HM_LV_GETD(vS0, 0); }
-    HM_PROF_END(e, 23);
     int zeroed = 0;
     if (cgScanPos) {
       const int cgCtx = ((sigRight + sigLower) != 0) * 2;                                   // getSigCoeffGroupCtxInc, TComTrQuant.cpp:2872
@@ -1155,7 +1145,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     e->u.rq.cgCtxSet[cgScanPos] = (uint8_t)wSet;
   }
   HM_SYNC();
-  HM_PROF_BEGIN(e, 19);
   double bestCost = blockUncodedCost + lambda * (double)HM_LV_GET(tMisc, 8 + cbfCtx * 2);   // TComTrQuant.cpp:2310-2316
   baseCost += lambda * (double)HM_LV_GET(tMisc, 8 + cbfCtx * 2 + 1);
   int bestLastIdxP1 = 0, foundLast = 0;
@@ -1195,8 +1184,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       if ((gt1Mask >> posInCG) & 1) { foundLast = 1; break; }
     }
   }
-  HM_PROF_END(e, 19);
-  HM_PROF_BEGIN(e, 20);
   // ---- levels with signs, truncated at the chosen last position (lane-parallel)
   int absPart = 0;
   HM_PAR_FOR(sp, lastScanPos + 1) {
@@ -1279,11 +1266,8 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     }
   }
   HM_SYNC();
-  HM_PROF_END(e, 20);
-  HM_PROF_BEGIN(e, 21);
   HM_PAR_FOR(sp, lastScanPos + 1) dst[rqPos[sp] & 0x3ff] = rqCur[sp];
   HM_SYNC();
-  HM_PROF_END(e, 21);
   return absSum;
 }
 
@@ -1434,7 +1418,7 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
 
 
 // TEncSbac::codeIntraDirLumaAng, TEncSbac.cpp:636-690
-HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
+template <class C> HM_DEV inline void code_intra_dir_luma(Shared *e, C *c, int z, int multiple)
 {
   const CtuMeta *m = (&e->meta);
   const int partNum = multiple ? (m->part[z] == SIZE_NxN ? 4 : 1) : 1;
@@ -1454,13 +1438,13 @@ HM_DEV inline void code_intra_dir_luma(Shared *e, Cabac *c, int z, int multiple)
   }
 }
 // TEncSbac::codeIntraDirChroma, TEncSbac.cpp:692-718
-HM_DEV inline void code_intra_dir_chroma(Shared *e, Cabac *c, int z)
+template <class C> HM_DEV inline void code_intra_dir_chroma(Shared *e, C *c, int z)
 {
   if ((&e->meta)->dirC[z] == DM_CHROMA_IDX) enc_bin(e, c, C_CHROMA_PRED, 0);
   else { enc_bin(e, c, C_CHROMA_PRED, 1); enc_ep(c, 2); }
 }
 // TEncSbac::codeQtCbf, TEncSbac.cpp:911-960 (square TUs)
-HM_DEV inline void code_qt_cbf(Shared *e, Cabac *c, const TU *t, int comp, int lowestLevel)
+template <class C> HM_DEV inline void code_qt_cbf(Shared *e, C *c, const TU *t, int comp, int lowestLevel)
 {
   const int z = t->cuZ + (comp ? t->cRelZ : t->relZ);
   const int ctx = comp ? t->trDepth : (t->trDepth == 0 ? 1 : 0);
@@ -1492,7 +1476,7 @@ HM_DEV inline int codes_subdiv_flag(const CtuMeta *m, const TU *t)
 HM_DEV inline void walk_begin(TuWalk *w, const TU *root) { w->node[0] = *root; w->next[0] = -1; w->sp = 0; }
 
 // xEncSubdivCbfQT, TEncSearch.cpp:856-921
-HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int bChroma)
+template <class C> HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, C *c, const TU *root, int bLuma, int bChroma)
 {
   const CtuMeta *m = (&e->meta);
   TuWalk &w = e->walkInner; walk_begin(&w, root);
@@ -1501,12 +1485,12 @@ HM_DEV inline void enc_subdiv_cbf_qt(Shared *e, const TU *root, int bLuma, int b
     const int z = t->cuZ + t->relZ;
     const int subdiv = m->tr[z] > t->trDepth;
     if (w.next[w.sp] < 0) { // first visit
-      if (bLuma && codes_subdiv_flag(m, t)) enc_bin(e, &e->cur, C_SUBDIV + (5 - t->log2), subdiv);
+      if (bLuma && codes_subdiv_flag(m, t)) enc_bin(e, c, C_SUBDIV + (5 - t->log2), subdiv);
       if (bChroma)
         for (int comp = 1; comp < 3; comp++)
           if (t->cCodeAll && (t->trDepth == 0 || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)))
-            code_qt_cbf(e, &e->cur, t, comp, subdiv == 0);
-      if (!subdiv) { if (bLuma) code_qt_cbf(e, &e->cur, t, 0, 1); w.sp--; continue; }
+            code_qt_cbf(e, c, t, comp, subdiv == 0);
+      if (!subdiv) { if (bLuma) code_qt_cbf(e, c, t, 0, 1); w.sp--; continue; }
       w.next[w.sp] = 0;
     }
     if (w.next[w.sp] == 4) { w.sp--; continue; }
@@ -1540,15 +1524,15 @@ HM_DEV inline void enc_coeff_qt(Shared *e, const TU *root, int comp)
   }
 }
 // xEncIntraHeader, TEncSearch.cpp:965-1032 (I slice, no PCM)
-HM_DEV inline void enc_intra_header(Shared *e, const TU *t, int bLuma, int bChroma)
+template <class C> HM_DEV inline void enc_intra_header(Shared *e, C *c, const TU *t, int bLuma, int bChroma)
 {
   const CtuMeta *m = (&e->meta); const int relZ = t->relZ;
   if (bLuma) {
-    if (relZ == 0 && t->cuDepth == 3) enc_bin(e, &e->cur, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
-    if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, &e->cur, t->cuZ, 0); }
-    else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ & (q - 1)) == 0) code_intra_dir_luma(e, &e->cur, t->cuZ + relZ, 0); }
+    if (relZ == 0 && t->cuDepth == 3) enc_bin(e, c, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
+    if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, c, t->cuZ, 0); }
+    else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ & (q - 1)) == 0) code_intra_dir_luma(e, c, t->cuZ + relZ, 0); }
   }
-  if (bChroma && relZ == 0) code_intra_dir_chroma(e, &e->cur, t->cuZ + relZ);
+  if (bChroma && relZ == 0) code_intra_dir_chroma(e, c, t->cuZ + relZ);
 }
 // xGetIntraBitsQT, TEncSearch.cpp:1038-1060
 HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, TU tv, int bLuma, int bChroma)
@@ -1556,9 +1540,13 @@ HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, TU tv, int bLuma, int bChro
   HM_ENTRY(e); bLuma = HM_UNI(bLuma); bChroma = HM_UNI(bChroma); tv = hm_uni_struct(tv);
   const TU *t = &tv;
   HM_PROF_BEGIN(e, PR_BITS);
-  reset_bits(&e->cur);
-  enc_intra_header(e, t, bLuma, bChroma);
-  enc_subdiv_cbf_qt(e, t, bLuma, bChroma);
+  {
+    CabacR r; cabr_load(r, &e->cur);
+    r.frac &= 32767;                       // resetBits, TEncBinCoderCABAC.cpp:161
+    enc_intra_header(e, &r, t, bLuma, bChroma);
+    enc_subdiv_cbf_qt(e, &r, t, bLuma, bChroma);
+    cabr_store(r, &e->cur);
+  }
   if (bLuma) enc_coeff_qt(e, t, 0);
   if (bChroma) { enc_coeff_qt(e, t, 1); enc_coeff_qt(e, t, 2); }
   HM_PROF_END(e, PR_BITS);
@@ -1611,7 +1599,7 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, TU tv, int comp, in
   const int absSum = HM_UCALL(rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx));
   HM_PROF_END(e, PR_RDOQ);
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-  { const int pid = l2 == 2 ? (absSum ? 13 : 7) : 14; e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }
+  { const int pid = l2 == 2 ? (absSum ? 13 : 7) : (l2 == 3 ? 14 : 15); e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }
 #endif
   par_set8(m->cbf[comp] + z, (absSum > 0 ? 1 : 0) << t->trDepth, parts);   // setCbfPartRange, TComTrQuant.cpp:1419
   HM_PROF_BEGIN(e, PR_INV);
@@ -1699,7 +1687,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
       const int checkTS = (log2 == 2) && (m->part[z] == SIZE_NxN);    // TransformSkip + TransformSkipFast
       if (f->checkFull) {
         if (checkTS) {
-          cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+          cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
           for (int modeId = 0; modeId < 2; modeId++) {
             double costTmp;
             par_set8(m->ts[0] + z, modeId, t->parts);
@@ -1709,18 +1697,18 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
             else { const uint32_t bits = HM_UCALL(intra_bits_qt(e, *t, 1, 0)); costTmp = calc_rd_cost(e, bits, distTmp); }
             if (costTmp < f->singleCost) {
               f->singleCost = costTmp; f->singleDist = distTmp; f->singleCbf = cbfTmp; f->bestModeId = (int8_t)modeId;
-              if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
+              if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
             }
-            if (modeId == 0) cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+            if (modeId == 0) cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
           }
           par_set8(m->ts[0] + z, f->bestModeId, t->parts);
           if (f->bestModeId == 0) {
             load_intra_result_qt(e, t, 0);
             par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
-            cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
+            cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
           }
         } else {
-          if (f->checkSplit) cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+          if (f->checkSplit) cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
           par_set8(m->ts[0] + z, 0, t->parts);
           f->singleDist = HM_UCALL(intra_coding_tu_block(e, *t, 0, 0));
           if (f->checkSplit) f->singleCbf = (m->cbf[0][z] >> t->trDepth) & 1;
@@ -1729,8 +1717,8 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
         }
       }
       if (!f->checkSplit) { retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue; }
-      if (f->checkFull) { cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); }
-      else cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+      if (f->checkFull) { cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); }
+      else cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
       f->splitCost = 0.0; f->splitDist = 0; f->splitCbf = 0; f->child = 0; f->phase = 1;
       retDist[sp + 1] = 0; retCost[sp + 1] = 0.0;
     }
@@ -1745,11 +1733,11 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
       }
       f->splitDist = retDist[sp + 1];
       if (f->splitCbf) { HM_PAR_FOR(o, t->parts) m->cbf[0][z + o] |= (uint8_t)(1 << t->trDepth); HM_SYNC(); }
-      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
       const uint32_t splitBits = HM_UCALL(intra_bits_qt(e, *t, 1, 0));
       f->splitCost = calc_rd_cost(e, splitBits, f->splitDist);
       if (f->splitCost < f->singleCost) { retDist[sp] += f->splitDist; retCost[sp] += f->splitCost; sp--; continue; }
-      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)]);
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)]);
       par_set8(m->tr + z, t->trDepth, t->parts);
       par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
       par_set8(m->ts[0] + z, f->bestModeId, t->parts);
@@ -1808,8 +1796,8 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       const int numMpm = intra_dir_predictor(e, z, preds);
       e->mpmZ = z; e->mpmNum = numMpm; e->mpmPreds[0] = preds[0]; e->mpmPreds[1] = preds[1]; e->mpmPreds[2] = preds[2];
       // xModeBitsIntra (TEncSearch.cpp:5456-5478) depends only on whether the mode is an MPM and which
-      const uint64_t frac0 = e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)].frac & 32767;
-      const uint8_t st0 = e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)].s[C_INTRA_LUMA];
+      const uint64_t frac0 = e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)].frac & 32767;
+      const uint8_t st0 = e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)].s[C_INTRA_LUMA];
       HM_PROF_BEGIN(e, PR_SATD35);
       if (n <= 16) satd_all_modes_small(e, org, ps, n);
       for (int mode = 0; mode < 35; mode++) {
@@ -1845,7 +1833,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       const int last = (pass == numModesForFullRD);
       const int orgMode = last ? bestPUMode : rdModeList[pass];
       par_set8(m->dirL + z, orgMode, puParts);
-      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
       recur_intra_coding_qt(e, t, !last);
       const uint32_t puDistY = e->outDistY; const double puCost = e->outRdCost;
       if (puCost < bestPUCost) {
@@ -1868,7 +1856,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
     HM_PAR_FOR(o, cuParts) for (int c = 0; c < 3; c++) m->cbf[c][cuZ + o] |= comb[c];
     HM_SYNC();
   }
-  cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+  cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
   return overallDistY;
 }
 
@@ -1884,7 +1872,7 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
   const int zc = t->cuZ + t->cRelZ;
   uint32_t dist = 0;
   for (int comp = 1; comp < 3; comp++) {
-    cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+    cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
     double singleCost = HM_MAX_DOUBLE, costTmp = 0; uint32_t singleDistC = 0, singleCbfC = 0; int bestTS = 0, bestModeId = 0, currModeId = 0;
     const int total = checkTS ? 2 : 1;
     for (int tsMode = 0; tsMode < total; tsMode++) {
@@ -1897,14 +1885,14 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
       else if (!isOne) { reset_bits(&e->cur); enc_coeff_qt(e, t, comp); costTmp = calc_rd_cost(e, num_bits(&e->cur), distTmp); }   // xGetIntraBitsQTChroma
       if (costTmp < singleCost) {
         singleCost = costTmp; singleDistC = distTmp; bestTS = tsMode; bestModeId = currModeId; singleCbfC = cbfTmp;
-        if (!isOne && !isLast) { store_intra_result_qt(e, t, comp); cabac_copy(&e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
+        if (!isOne && !isLast) { store_intra_result_qt(e, t, comp); cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
       }
-      if (!isOne && !isLast) cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+      if (!isOne && !isLast) cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
     }
     if (bestModeId < total) {
       load_intra_result_qt(e, t, comp);
       par_set8(m->cbf[comp] + zc, (int)(singleCbfC << t->trDepth), t->cParts);
-      cabac_copy(&e->cur, &e->slotArr[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
     }
     par_set8(m->ts[comp] + zc, bestTS, t->cParts);
     dist += singleDistC;
@@ -1971,10 +1959,10 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
   int modeList[5] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX, DM_CHROMA_IDX};       // getAllowedChromaDir, TComDataCU.cpp:1486
   for (int i = 0; i < 4; i++) if (m->dirL[cuZ] == modeList[i]) { modeList[i] = 34; break; }
   for (int mi = 0; mi < 5; mi++) {
-    cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+    cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
     par_set8(m->dirC + cuZ, modeList[mi], cuParts);
     const uint32_t dist = HM_UCALL(recur_intra_chroma_coding_qt(e, t));
-    cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+    cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
     const uint32_t bits = HM_UCALL(intra_bits_qt(e, t, 0, 1));
     const double cost = calc_rd_cost(e, bits, dist);
     if (cost < bestCost) {
@@ -1986,7 +1974,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
   }
   HM_PAR_FOR(i, cuParts) { for (int c = 1; c < 3; c++) { m->cbf[c][cuZ + i] = ws->saveCbf[c][i]; m->ts[c][cuZ + i] = ws->saveTs[c][i]; } m->dirC[cuZ + i] = (uint8_t)bestMode; }
   HM_SYNC();
-  cabac_copy(&e->cur, &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+  cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
   return bestDist;
 }
 
@@ -2109,7 +2097,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
   { HM_PROF_BEGIN(e, PR_CHROMA); d += HM_UCALL(est_intra_pred_chroma_qt(e, cuZ, cuDepth)); HM_PROF_END(e, PR_CHROMA); }
   reset_bits(&e->cur);
   { HM_PROF_BEGIN(e, PR_ENCCU); encode_cu_syntax(e, &e->cur, cuZ, cuDepth); HM_PROF_END(e, PR_ENCCU); }
-  cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
+  cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
   e->outBits = num_bits(&e->cur); e->outDist = d;
   e->outCost = calc_rd_cost(e, e->outBits, e->outDist);
 }
@@ -2134,11 +2122,11 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
       if (!f->boundary) {
         check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N);
         double c = e->outCost; uint32_t b = e->outBits, d = e->outDist;
-        if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)]); }
+        if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]); }
         if (cuDepth == 3) {
           check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN);
           c = e->outCost; b = e->outBits; d = e->outDist;
-          if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)]); }
+          if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]); }
         }
         // split flag of the unsplit candidate, TEncCu.cpp:859-863 (coded on the go-on coder as it stands)
         reset_bits(&e->cur);
@@ -2159,8 +2147,8 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
         HM_PAR_FOR(i, q) { m->depth[subZ + i] = (uint8_t)(cuDepth + 1); m->part[subZ + i] = SIZE_NONE; m->pred[subZ + i] = MODE_NONE; }
         HM_SYNC();
         if (sx < e->width && sy < e->height) {
-          if (s == 0) cabac_copy(&e->slotArr[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_CURR_BEST)]);
-          else cabac_copy(&e->slotArr[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->slotArr[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
+          if (s == 0) cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+          else cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
           fr[sp + 1].cuZ = (int16_t)subZ; fr[sp + 1].phase = 0;
           f->phase = 2; sp++; continue;
         }
@@ -2172,10 +2160,10 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
         f->splitBits += num_bits(&e->cur);
       }
       f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
-      cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->slotArr[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
+      cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
       if (f->splitCost < f->bestCost) {
         f->bestCost = f->splitCost; f->bestBits = f->splitBits; f->bestDist = f->splitDist;
-        cabac_copy(&e->slotArr[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->slotArr[HM_SLOT(cuDepth, CI_TEMP_BEST)]);
+        cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]);
       } else restore_best(e, cuZ, cuDepth);
       retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
     }
@@ -2244,7 +2232,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     HM_SYNC();
   }
   // CABAC state hand-off (TEncSlice.cpp:733-761)
-  Cabac *cb0 = &e->slotArr[HM_SLOT(0, CI_CURR_BEST)];
+  Cabac *cb0 = &e->ws->slot[HM_SLOT(0, CI_CURR_BEST)];
   if (a == 0) cabac_init(cb0, e->fb.qp);
   else if (e->ctuX == 0 && P->wpp) {
     cabac_init(cb0, e->fb.qp);
@@ -2257,10 +2245,12 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   cabac_copy(&e->cur, cb0);
   compress_ctu(e);
   e->fb.stat[a].cost = e->outCost; e->fb.stat[a].bits = e->outBits; e->fb.stat[a].dist = e->outDist;
-  // TEncCu::encodeCtu on m_pppcRDSbacCoder[0][CI_CURR_BEST], TEncSlice.cpp:818-825
-  reset_bits(cb0);
-  encode_ctu(e, cb0, a == numCtus - 1);
-  cabac_copy(e->fb.endState + a, cb0);
+  // TEncCu::encodeCtu on m_pppcRDSbacCoder[0][CI_CURR_BEST] (the search never writes that snapshot), TEncSlice.cpp:818-825:
+  // run it on the LDS-resident coder and hand the end state to the next CTU
+  cabac_copy(&e->cur, cb0);
+  reset_bits(&e->cur);
+  encode_ctu(e, &e->cur, a == numCtus - 1);
+  cabac_copy(e->fb.endState + a, &e->cur);
   { // decision arrays back to HBM (TComDataCU::copyToPic of the whole CTU)
     const uint32_t *src = (const uint32_t *)&e->meta; uint32_t *dst = (uint32_t *)(e->fb.meta + a);
     HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];

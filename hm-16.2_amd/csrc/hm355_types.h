@@ -46,6 +46,7 @@ struct WorkSpace {
   double costCoeff[1024];            // RDOQ: cost of the positions that keep a non-zero level
   int32_t rqLvl[1024];               // RDOQ per-position state of 32x32 blocks (smaller blocks keep it in LDS)
   uint16_t rqPos[1024], rqDec[1024]; int16_t rqCur[1024]; uint8_t rqCtxSig[1024], rqCode[1024];
+  Cabac slot[4 * CI_NUM + 3];        // m_pppcRDSbacCoder[depth][CI_*] snapshots (the live coder stays in LDS); depth 4 only holds TEMP_BEST/QT_TRAFO_*
   uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
 };
 
