@@ -23,10 +23,20 @@ typedef int32_t TCoeff;
 #define VER_IDX 26
 #define DM_CHROMA_IDX 36
 #define SIZE_2Nx2N 0
+#define SIZE_2NxN 1
+#define SIZE_Nx2N 2
 #define SIZE_NxN 3
+#define SIZE_2NxnU 4
+#define SIZE_2NxnD 5
+#define SIZE_nLx2N 6
+#define SIZE_nRx2N 7
 #define SIZE_NONE 8  /* NUMBER_OF_PART_SIZES */
+#define MODE_INTER 0
 #define MODE_INTRA 1
 #define MODE_NONE 2  /* NUMBER_OF_PREDICTION_MODES */
+#define B_SLICE 0
+#define P_SLICE 1
+#define I_SLICE 2
 #define SCAN_DIAG 0
 #define SCAN_HOR 1
 #define SCAN_VER 2
@@ -76,7 +86,9 @@ static const int32_t ENTROPY_BITS[128] = {
 /* context layout (own numbering); sizes follow ContextTables.h:51-161 */
 enum {
   C_SPLIT = 0, C_PART = 3, C_INTRA_LUMA = 7, C_CHROMA_PRED = 8, C_SUBDIV = 10, C_QT_CBF = 13, C_SIG_CG = 23,
-  C_SIG = 27, C_LASTX = 71, C_LASTY = 101, C_ONE = 131, C_ABS = 155, C_TSKIP = 161, NUM_CTX = 163
+  C_SIG = 27, C_LASTX = 71, C_LASTY = 101, C_ONE = 131, C_ABS = 155, C_TSKIP = 161,
+  /* inter syntax */ C_SKIP = 163, C_MRG_FLAG = 166, C_MRG_IDX = 167, C_PRED_MODE = 168, C_INTER_DIR = 169, C_MVD = 174, C_REF = 176,
+  C_ROOT_CBF = 178, C_MVP_IDX = 179, NUM_CTX = 180
 };
 /* I-slice initialisation values, ContextTables.h:170-502 (row [2] of each table; CNU = 154) */
 static const uint8_t CTX_INIT_I[NUM_CTX] = {
@@ -93,7 +105,47 @@ static const uint8_t CTX_INIT_I[NUM_CTX] = {
   /* last y */ 110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79,  108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
   /* one: luma 16, chroma 8 */ 140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152,  140, 179, 166, 182, 140, 227, 122, 197,
   /* abs: luma 4, chroma 2 */ 138, 153, 136, 167, 152, 152,
-  /* transform skip */ 139, 139
+  /* transform skip */ 139, 139,
+  /* skip */ 154, 154, 154, /* merge flag, idx */ 154, 154, /* pred mode */ 154, /* inter dir */ 154, 154, 154, 154, 154, /* mvd */ 154, 154,
+  /* ref idx */ 154, 154, /* root cbf */ 154, /* mvp idx */ 154
+};
+/* P-slice initialisation values (row [1] of each table) */
+static const uint8_t CTX_INIT_P[NUM_CTX] = {
+  /* split */ 107, 139, 126,
+  /* part size */ 154, 139, 154, 154,
+  /* intra luma */ 154,
+  /* chroma pred */ 152, 139,
+  /* trans subdiv */ 124, 138, 94,
+  /* qt cbf */ 153, 111, 154, 154, 154,   149, 107, 167, 154, 154,
+  /* sig cg */ 121, 140, 61, 154,
+  /* sig luma 28 */ 155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 140,
+  /* sig chroma 16 */ 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140, 140,
+  /* last x */ 125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94,  108, 123, 108, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* last y */ 125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94,  108, 123, 108, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* one: luma 16, chroma 8 */ 154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137,  169, 194, 166, 167, 154, 167, 137, 182,
+  /* abs: luma 4, chroma 2 */ 107, 167, 91, 122, 107, 167,
+  /* transform skip */ 139, 139,
+  /* skip */ 197, 185, 201, /* merge flag, idx */ 110, 122, /* pred mode */ 149, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 140, 198,
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
+};
+/* B-slice initialisation values (row [0] of each table) */
+static const uint8_t CTX_INIT_B[NUM_CTX] = {
+  /* split */ 107, 139, 126,
+  /* part size */ 154, 139, 154, 154,
+  /* intra luma */ 183,
+  /* chroma pred */ 152, 139,
+  /* trans subdiv */ 224, 167, 122,
+  /* qt cbf */ 153, 111, 154, 154, 154,   149, 92, 167, 154, 154,
+  /* sig cg */ 121, 140, 61, 154,
+  /* sig luma 28 */ 170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 140,
+  /* sig chroma 16 */ 170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140, 140,
+  /* last x */ 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79,  108, 123, 93, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* last y */ 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79,  108, 123, 93, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* one: luma 16, chroma 8 */ 154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122,  169, 208, 166, 167, 154, 152, 167, 182,
+  /* abs: luma 4, chroma 2 */ 107, 167, 91, 107, 107, 167,
+  /* transform skip */ 139, 139,
+  /* skip */ 197, 185, 201, /* merge flag, idx */ 154, 137, /* pred mode */ 134, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 169, 198,
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
 };
 
 static void gen_scan(int w, int h, int stride, int type, int offx, int offy, uint16_t *out, int count)
@@ -151,13 +203,15 @@ static inline int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; 
 /* ============================================================================================ */
 /* CABAC bit estimator (TEncBinCABACCounter, TEncBinCoderCABACCounter.cpp:56-131)                */
 /* ============================================================================================ */
-typedef struct { uint8_t s[NUM_CTX]; uint8_t pad[5]; uint64_t frac; } Cabac;
+typedef struct { uint8_t s[NUM_CTX]; uint8_t pad[4]; uint64_t frac; } Cabac;
 
+static int g_slice_type = I_SLICE;        /* selects the initialisation table (TEncSbac::resetEntropy uses the slice type) */
 static void cabac_init(Cabac *c, int qp)
 { /* ContextModel::init, ContextModel.cpp:55-64; TEncSbac::resetEntropy, TEncSbac.cpp:106-161 */
+  const uint8_t *tab = g_slice_type == I_SLICE ? CTX_INIT_I : (g_slice_type == P_SLICE ? CTX_INIT_P : CTX_INIT_B);
   qp = clip3(0, 51, qp);
   for (int i = 0; i < NUM_CTX; i++) {
-    int iv = CTX_INIT_I[i];
+    int iv = tab[i];
     int slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
     int st = ((slope * qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
     int mps = st >= 64;
@@ -182,8 +236,13 @@ static inline int ebits(const Cabac *c, int ctx, int bin) { return ENTROPY_BITS[
 /* ============================================================================================ */
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_CHROMA_INTRA, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };
 
+typedef struct { int16_t x, y; } Mv;
 typedef struct {
   uint8_t depth[256], part[256], pred[256], dirL[256], dirC[256], tr[256], cbf[3][256], ts[3][256];
+  /* inter (TComDataCU m_skipFlag, m_pbMergeFlag, m_puhMergeIndex, m_puhInterDir, m_acCUMvField[2], m_apiMVPIdx/Num) */
+  uint8_t skip[256], mrg[256], mrgIdx[256], interDir[256];
+  Mv mv[2][256], mvd[2][256];
+  int8_t refIdx[2][256], mvpIdx[2][256], mvpNum[2][256];
 } CtuMeta;
 
 typedef struct {
@@ -194,8 +253,30 @@ typedef struct {
   double cost; uint32_t bits, dist;
 } Best;
 
+#define REF_MARGIN 80                      /* TComPicYuv margin: g_uiMaxCUWidth + 16 (TComPic::create) */
+typedef struct {
+  int poc, isLongTerm, sliceType;
+  Pel *buf[3]; Pel *plane[3]; int stride[3];      /* border-extended planes, plane[] points at sample (0,0) */
+  /* motion field as later pictures see it (after TComPic::compressMotion): per CTU, 256 partitions */
+  const uint8_t *predMode; const int16_t *mv[2]; const int8_t *refIdx[2];
+  int numRef[2], refPoc[2][16], refLT[2][16];
+} RefPic;
+
+typedef struct {
+  int sliceType, poc;
+  int numRefIdx[2];
+  RefPic *ref[2][16];
+  int colFromL0, colRefIdx, tmvp, mvdL1Zero, maxMergeCand, checkLDC;
+  uint32_t lambdaMotionSAD, lambdaMotionSSE;        /* TComRdCost::m_uiLambdaMotionSAD/SSE[0] */
+  /* TComRdCost motion-cost state (getMotionCost / setPredictor / setCostScale) */
+  uint32_t mcost; Mv mvPredictor; int costScale;
+  /* TEncSearch::m_integerMv2Nx2N[list][refIdx]: integer MV of the last 2Nx2N ME on that reference (persists across CUs) */
+  Mv integerMv2Nx2N[2][16];
+} InterSlice;
+
 typedef struct {
   hmo_cfg cfg;
+  InterSlice *is;                  /* NULL for I slices */
   int wCtu, hCtu;
   int stride[3], ph[3];            /* plane strides / heights padded to whole CTUs */
   Pel *org[3], *rec[3];
@@ -212,6 +293,8 @@ typedef struct {
   Best best[4];
   /* per-trial scratch, CTU-relative */
   Pel pred[3][64 * 64], resi[3][64 * 64], reco[3][64 * 64];
+  Pel tmpPred[3][64 * 64];         /* m_tmpYuvPred (merge / ME prediction error) */
+  Pel resiBest[3][64 * 64];        /* m_ppcResiYuvBest[depth] */
   Pel qtRec[4][3][64 * 64];        /* m_pcQTTempTComYuv[layer] */
   TCoeff qtCoef[3][4][4096];       /* m_ppcQTTempCoeff[comp][layer] */
   TCoeff tsCoef[3][1024];          /* m_pcQTTempTUCoeff */
@@ -544,6 +627,7 @@ static void pred_intra(Enc *e, int comp, int mode, int n, int filtered, Pel *dst
 /* TComDataCU::getCoefScanIdx, TComDataCU.cpp:3340-3380 */
 static int coef_scan_idx(const CtuMeta *m, int z, int n, int comp)
 {
+  if (m->pred[z] != MODE_INTRA) return SCAN_DIAG;     /* getMDCSScanOrder... only intra CUs scan mode-dependently, TComTU.cpp / TComCodingStatistics */
   if (n > (comp ? 4 : 8)) return SCAN_DIAG;
   int dir = comp ? m->dirC[z] : m->dirL[z];
   if (dir == DM_CHROMA_IDX) dir = m->dirL[z & ~3];
@@ -1007,10 +1091,12 @@ static void enc_coeff_qt(Enc *e, const TU *t, int comp)
   code_coeff_nxn(e, &e->cur, coef, n, comp, coef_scan_idx(m, zc, n, comp), m->ts[comp][zc]);
 }
 /* xEncIntraHeader, TEncSearch.cpp:965-1032 (I slice, no PCM) */
+static void code_skip_flag(Enc *e, Cabac *c, int z);
 static void enc_intra_header(Enc *e, const TU *t, int bLuma, int bChroma)
 {
   const CtuMeta *m = e->cm; const int relZ = t->relZ;
   if (bLuma) {
+    if (relZ == 0 && e->is) { code_skip_flag(e, &e->cur, t->cuZ); enc_bin(&e->cur, C_PRED_MODE, 1); }   /* P/B slices: skip flag + pred mode, TEncSearch.cpp:975-984 */
     if (relZ == 0 && t->cuDepth == 3) enc_bin(&e->cur, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);   /* codePartSize, TEncSbac.cpp:431 */
     if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, &e->cur, t->cuZ, 0); }
     else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ % q) == 0) code_intra_dir_luma(e, &e->cur, t->cuZ + relZ, 0); }
@@ -1404,6 +1490,7 @@ static void encode_transform(Enc *e, Cabac *c, const TU *t)
 static void encode_cu_syntax(Enc *e, Cabac *c, int cuZ, int cuDepth)
 {
   const CtuMeta *m = e->cm;
+  if (e->is) { code_skip_flag(e, c, cuZ); enc_bin(c, C_PRED_MODE, 1); }
   if (cuDepth == 3) enc_bin(c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
   code_intra_dir_luma(e, c, cuZ, 1);
   code_intra_dir_chroma(e, c, cuZ);
@@ -1420,6 +1507,11 @@ static void init_est_data(Enc *e, int cuZ, int cuDepth)
   memset(m->depth + cuZ, cuDepth, parts); memset(m->part + cuZ, SIZE_NONE, parts); memset(m->pred + cuZ, MODE_NONE, parts);
   memset(m->dirL + cuZ, DC_IDX, parts); memset(m->dirC + cuZ, 0, parts); memset(m->tr + cuZ, 0, parts);
   for (int c = 0; c < 3; c++) { memset(m->cbf[c] + cuZ, 0, parts); memset(m->ts[c] + cuZ, 0, parts); }
+  memset(m->skip + cuZ, 0, parts); memset(m->mrg + cuZ, 0, parts); memset(m->mrgIdx + cuZ, 0, parts); memset(m->interDir + cuZ, 0, parts);
+  for (int l = 0; l < 2; l++) {
+    memset(m->mv[l] + cuZ, 0, sizeof(Mv) * parts); memset(m->mvd[l] + cuZ, 0, sizeof(Mv) * parts);
+    memset(m->refIdx[l] + cuZ, -1, parts); memset(m->mvpIdx[l] + cuZ, -1, parts); memset(m->mvpNum[l] + cuZ, -1, parts);
+  }
   memset(e->cc[0] + cuZ * 16, 0, sizeof(TCoeff) * parts * 16);
   memset(e->cc[1] + cuZ * 4, 0, sizeof(TCoeff) * parts * 4);
   memset(e->cc[2] + cuZ * 4, 0, sizeof(TCoeff) * parts * 4);
@@ -1431,12 +1523,21 @@ static void copy_cu_planes(Pel *const dst[3], const int dstStride[3], Pel *const
     for (int r = 0; r < nn; r++) memcpy(dst[c] + ((y >> sh) + r) * dstStride[c] + (x >> sh), src[c] + ((y >> sh) + r) * srcStride[c] + (x >> sh), sizeof(Pel) * nn);
   }
 }
+static void meta_copy_inter(CtuMeta *d, const CtuMeta *s, int z, int parts)
+{
+  memcpy(d->skip + z, s->skip + z, parts); memcpy(d->mrg + z, s->mrg + z, parts); memcpy(d->mrgIdx + z, s->mrgIdx + z, parts); memcpy(d->interDir + z, s->interDir + z, parts);
+  for (int l = 0; l < 2; l++) {
+    memcpy(d->mv[l] + z, s->mv[l] + z, sizeof(Mv) * parts); memcpy(d->mvd[l] + z, s->mvd[l] + z, sizeof(Mv) * parts);
+    memcpy(d->refIdx[l] + z, s->refIdx[l] + z, parts); memcpy(d->mvpIdx[l] + z, s->mvpIdx[l] + z, parts); memcpy(d->mvpNum[l] + z, s->mvpNum[l] + z, parts);
+  }
+}
 static void save_best(Enc *e, int cuZ, int cuDepth, double cost, uint32_t bits, uint32_t dist)
 {
   Best *b = &e->best[cuDepth]; const CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
   const uint8_t *src[12] = {m->depth, m->part, m->pred, m->dirL, m->dirC, m->tr, m->cbf[0], m->cbf[1], m->cbf[2], m->ts[0], m->ts[1], m->ts[2]};
   uint8_t *dst[12] = {b->m.depth, b->m.part, b->m.pred, b->m.dirL, b->m.dirC, b->m.tr, b->m.cbf[0], b->m.cbf[1], b->m.cbf[2], b->m.ts[0], b->m.ts[1], b->m.ts[2]};
   for (int i = 0; i < 12; i++) memcpy(dst[i] + cuZ, src[i] + cuZ, parts);
+  meta_copy_inter(&b->m, m, cuZ, parts);
   memcpy(b->coef[0] + cuZ * 16, e->cc[0] + cuZ * 16, sizeof(TCoeff) * parts * 16);
   memcpy(b->coef[1] + cuZ * 4, e->cc[1] + cuZ * 4, sizeof(TCoeff) * parts * 4);
   memcpy(b->coef[2] + cuZ * 4, e->cc[2] + cuZ * 4, sizeof(TCoeff) * parts * 4);
@@ -1451,6 +1552,7 @@ static void restore_best(Enc *e, int cuZ, int cuDepth)
   uint8_t *dst[12] = {m->depth, m->part, m->pred, m->dirL, m->dirC, m->tr, m->cbf[0], m->cbf[1], m->cbf[2], m->ts[0], m->ts[1], m->ts[2]};
   const uint8_t *src[12] = {b->m.depth, b->m.part, b->m.pred, b->m.dirL, b->m.dirC, b->m.tr, b->m.cbf[0], b->m.cbf[1], b->m.cbf[2], b->m.ts[0], b->m.ts[1], b->m.ts[2]};
   for (int i = 0; i < 12; i++) memcpy(dst[i] + cuZ, src[i] + cuZ, parts);
+  meta_copy_inter(m, &b->m, cuZ, parts);
   memcpy(e->cc[0] + cuZ * 16, b->coef[0] + cuZ * 16, sizeof(TCoeff) * parts * 16);
   memcpy(e->cc[1] + cuZ * 4, b->coef[1] + cuZ * 4, sizeof(TCoeff) * parts * 4);
   memcpy(e->cc[2] + cuZ * 4, b->coef[2] + cuZ * 4, sizeof(TCoeff) * parts * 4);
@@ -1462,7 +1564,7 @@ static void restore_best(Enc *e, int cuZ, int cuDepth)
   }
 }
 
-/* xCheckRDCostIntra; returns through *cost/*bits/*dist, leaves the trial in place */
+/* xCheckRDCostIntra; returns through cost / bits / dist, leaves the trial in place */
 static void check_rd_cost_intra(Enc *e, int cuZ, int cuDepth, int partSize, double *cost, uint32_t *bits, uint32_t *dist)
 {
   CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
@@ -1482,14 +1584,32 @@ static void check_rd_cost_intra(Enc *e, int cuZ, int cuDepth, int partSize, doub
   *cost = calc_rd_cost(e, *bits, *dist);
 }
 
-static void compress_cu(Enc *e, int cuZ, int cuDepth, double *outCost, uint32_t *outBits, uint32_t *outDist)
+#include "hm_oracle_inter.inc"
+
+static void compress_cu(Enc *e, int cuZ, int cuDepth, int parentPartSize, double *outCost, uint32_t *outBits, uint32_t *outDist)
 {
   CtuMeta *m = e->cm;
   const int size = 64 >> cuDepth, parts = 256 >> (2 * cuDepth);
   const int lx = e->ctuX * 64 + (Z2R[cuZ] & 15) * 4, ty = e->ctuY * 64 + (Z2R[cuZ] >> 4) * 4;
   const int boundary = !((lx + size - 1 < e->cfg.width) && (ty + size - 1 < e->cfg.height));
   double bestCost = MAX_DOUBLE; uint32_t bestBits = 0, bestDist = 0;
-  if (!boundary) {
+  if (!boundary && e->is) { /* P/B slice: TEncCu.cpp:628-836 */
+    BestRd br = { MAX_DOUBLE, 0, 0 };
+    compress_cu_inter_modes(e, cuZ, cuDepth, parentPartSize, &br);
+    const CtuMeta *bm = &e->best[cuDepth].m;
+    if (bm->cbf[0][cuZ] != 0 || bm->cbf[1][cuZ] != 0 || bm->cbf[2][cuZ] != 0) {   /* avoid very complex intra if it is unlikely, :820 */
+      double c; uint32_t b, d;
+      check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N, &c, &b, &d);
+      check_best_mode(e, cuZ, cuDepth, &br, c, b, d);
+      if (cuDepth == 3) { check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN, &c, &b, &d); check_best_mode(e, cuZ, cuDepth, &br, c, b, d); }
+    }
+    bestCost = br.cost; bestBits = br.bits; bestDist = br.dist;
+    reset_bits(&e->cur);
+    if (cuDepth != 3) enc_bin(&e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
+    bestBits += num_bits(&e->cur);
+    bestCost = calc_rd_cost(e, bestBits, bestDist);
+    e->best[cuDepth].cost = bestCost; e->best[cuDepth].bits = bestBits;
+  } else if (!boundary) {
     double c; uint32_t b, d;
     check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N, &c, &b, &d);
     if (c < bestCost) { bestCost = c; bestBits = b; bestDist = d; save_best(e, cuZ, cuDepth, c, b, d); e->slot[cuDepth][CI_NEXT_BEST] = e->slot[cuDepth][CI_TEMP_BEST]; }
@@ -1518,7 +1638,8 @@ static void compress_cu(Enc *e, int cuZ, int cuDepth, double *outCost, uint32_t 
         if (s == 0) e->slot[cuDepth + 1][CI_CURR_BEST] = e->slot[cuDepth][CI_CURR_BEST];
         else e->slot[cuDepth + 1][CI_CURR_BEST] = e->slot[cuDepth + 1][CI_NEXT_BEST];
         double c; uint32_t b, d;
-        compress_cu(e, subZ, cuDepth + 1, &c, &b, &d);
+        const int bestIsInter = !boundary && e->best[cuDepth].m.pred[cuZ] == MODE_INTER;   /* rpcBestCU->isInter(0), :1026 */
+        compress_cu(e, subZ, cuDepth + 1, bestIsInter ? e->best[cuDepth].m.part[cuZ] : SIZE_NONE, &c, &b, &d);
         splitBits += b; splitDist += d;
       }
     }
@@ -1554,7 +1675,7 @@ static void encode_cu(Enc *e, Cabac *c, int z, int depth, int lastCtuOfSlice)
     }
     return;
   }
-  encode_cu_syntax(e, c, z, depth);
+  if (m->pred[z] == MODE_INTER) encode_cu_syntax_inter(e, c, z, depth); else encode_cu_syntax(e, c, z, depth);
   /* finishCU, TEncCu.cpp:1130-1147 */
   const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->cfg.width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->cfg.height);
   if (lastX && lastY && !lastCtuOfSlice) enc_trm(c, 0);
@@ -1571,7 +1692,8 @@ void hmo_cfg_set_qp(hmo_cfg *c, int qp)
   c->chroma_weight = pow(2.0, (qp - qpc) / 3.0);
 }
 
-static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus, int maxCtus)
+static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus, int maxCtus,
+                         const hmo_inter_slice *hs, hmo_ctu_inter *ictus)
 {
   if (!cfg || cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || (cfg->bit_depth != 8 && cfg->bit_depth != 10)) return -1;
   init_tables();
@@ -1589,6 +1711,35 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
     e->coef[c] = (TCoeff *)calloc((size_t)numCtus * (c ? 1024 : 4096), sizeof(TCoeff));
   }
   e->meta = (CtuMeta *)calloc(numCtus, sizeof(CtuMeta));
+  InterSlice islice; RefPic refPics[32]; int numRefPics = 0;
+  g_slice_type = I_SLICE;
+  if (hs) { /* slice header / DPB view of a P slice */
+    if (hs->slice_type != P_SLICE) { free(e); return -3; }
+    memset(&islice, 0, sizeof(islice));
+    islice.sliceType = hs->slice_type; islice.poc = hs->poc;
+    islice.colFromL0 = hs->col_from_l0; islice.colRefIdx = hs->col_ref_idx; islice.tmvp = hs->tmvp; islice.mvdL1Zero = hs->mvd_l1_zero;
+    islice.maxMergeCand = hs->max_merge_cand; islice.checkLDC = hs->check_ldc;
+    islice.lambdaMotionSAD = hs->lambda_motion_sad; islice.lambdaMotionSSE = hs->lambda_motion_sse;
+    const hmo_ref_pic *seen[32];
+    for (int l = 0; l < 2; l++) {
+      islice.numRefIdx[l] = hs->num_ref_idx[l];
+      for (int i = 0; i < hs->num_ref_idx[l]; i++) {
+        const hmo_ref_pic *hp = hs->ref[l][i]; int k;
+        for (k = 0; k < numRefPics; k++) if (seen[k] == hp) break;
+        if (k == numRefPics) {
+          RefPic *rp = &refPics[numRefPics]; seen[numRefPics++] = hp;
+          memset(rp, 0, sizeof(*rp));
+          rp->poc = hp->poc; rp->isLongTerm = hp->long_term; rp->sliceType = hp->slice_type;
+          refpic_extend(rp, hp->plane, cfg->width, cfg->height);
+          rp->predMode = hp->pred_mode;
+          for (int ll = 0; ll < 2; ll++) { rp->mv[ll] = hp->mv[ll]; rp->refIdx[ll] = hp->ref_idx[ll]; rp->numRef[ll] = hp->num_ref[ll]; memcpy(rp->refPoc[ll], hp->ref_poc[ll], sizeof(rp->refPoc[ll])); memcpy(rp->refLT[ll], hp->ref_lt[ll], sizeof(rp->refLT[ll])); }
+        }
+        islice.ref[l][i] = &refPics[k];
+      }
+    }
+    e->is = &islice;
+    g_slice_type = hs->cabac_init_type;
+  }
   e->lambda = cfg->lambda; e->sqrtLambda = sqrt(cfg->lambda);
   e->chromaWeight = cfg->chroma_weight; e->lambdaC = cfg->lambda / cfg->chroma_weight;
   { /* QpParam, TComTrQuant.cpp:71-119 */
@@ -1608,6 +1759,8 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
       memset(m->depth, 0, 256); memset(m->part, SIZE_NONE, 256); memset(m->pred, MODE_NONE, 256);
       memset(m->dirL, DC_IDX, 256); memset(m->dirC, 0, 256); memset(m->tr, 0, 256);
       for (int c = 0; c < 3; c++) { memset(m->cbf[c], 0, 256); memset(m->ts[c], 0, 256); }
+      memset(m->skip, 0, 256); memset(m->mrg, 0, 256); memset(m->mrgIdx, 0, 256); memset(m->interDir, 0, 256);
+      for (int l = 0; l < 2; l++) { memset(m->mv[l], 0, sizeof(m->mv[l])); memset(m->mvd[l], 0, sizeof(m->mvd[l])); memset(m->refIdx[l], -1, 256); memset(m->mvpIdx[l], -1, 256); memset(m->mvpNum[l], -1, 256); }
     }
     if (a == 0) cabac_init(&e->slot[0][CI_CURR_BEST], cfg->qp);
     else if (e->ctuX == 0 && cfg->wpp) {
@@ -1616,7 +1769,7 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
     }
     e->cur = e->slot[0][CI_CURR_BEST];
     double cost; uint32_t bits, dist;
-    compress_cu(e, 0, 0, &cost, &bits, &dist);
+    compress_cu(e, 0, 0, SIZE_NONE, &cost, &bits, &dist);
     hmo_ctu *o = ctus + a;
     o->total_cost = cost; o->total_bits = bits; o->total_dist = dist;
     /* TEncCu::encodeCtu on m_pppcRDSbacCoder[0][CI_CURR_BEST], TEncSlice.cpp:818-825 */
@@ -1632,17 +1785,30 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
     memcpy(o->coeff_y, e->coef[0] + (size_t)a * 4096, sizeof(TCoeff) * 4096);
     memcpy(o->coeff_cb, e->coef[1] + (size_t)a * 1024, sizeof(TCoeff) * 1024);
     memcpy(o->coeff_cr, e->coef[2] + (size_t)a * 1024, sizeof(TCoeff) * 1024);
+    if (ictus) {
+      hmo_ctu_inter *io = ictus + a;
+      memcpy(io->skip, m->skip, 256); memcpy(io->merge_flag, m->mrg, 256); memcpy(io->merge_idx, m->mrgIdx, 256); memcpy(io->inter_dir, m->interDir, 256);
+      for (int l = 0; l < 2; l++) {
+        for (int z = 0; z < 256; z++) { io->mv[l][z][0] = m->mv[l][z].x; io->mv[l][z][1] = m->mv[l][z].y; io->mvd[l][z][0] = m->mvd[l][z].x; io->mvd[l][z][1] = m->mvd[l][z].y; }
+        memcpy(io->ref_idx[l], m->refIdx[l], 256); memcpy(io->mvp_idx[l], m->mvpIdx[l], 256); memcpy(io->mvp_num[l], m->mvpNum[l], 256);
+      }
+    }
   }
   for (int c = 0; c < 3; c++) {
     const int w = cfg->width >> (c ? 1 : 0), h = cfg->height >> (c ? 1 : 0);
     for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) rec[c][y * w + x] = (uint16_t)e->rec[c][y * e->stride[c] + x];
     free(e->org[c]); free(e->rec[c]); free(e->coef[c]);
   }
+  for (int k = 0; k < numRefPics; k++) for (int c = 0; c < 3; c++) free(refPics[k].buf[c]);
+  g_slice_type = I_SLICE;
   free(e->meta); free(e);
   return 0;
 }
 
 int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus)
-{ return compress_impl(cfg, org, rec, ctus, 0); }
+{ return compress_impl(cfg, org, rec, ctus, 0, NULL, NULL); }
 int hmo_compress_rows(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus, int max_ctus)
-{ return compress_impl(cfg, org, rec, ctus, max_ctus); }
+{ return compress_impl(cfg, org, rec, ctus, max_ctus, NULL, NULL); }
+int hmo_compress_slice_inter(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],
+                             hmo_ctu *ctus, hmo_ctu_inter *ictus)
+{ return slice ? compress_impl(cfg, org, rec, ctus, 0, slice, ictus) : -1; }

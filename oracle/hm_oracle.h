@@ -53,6 +53,32 @@ int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_
 int hmo_compress_rows(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus,
                       int max_ctus);
 
+/* ---- P slices (rows a2 inter, a4-a7, a12, a14 of SURVEY.md section 8): reference pictures and slice parameters are inputs,
+ * exactly what TEncSlice::compressSlice finds in the slice header / decoded picture buffer ---- */
+typedef struct {
+  int poc, slice_type, long_term;
+  const uint16_t *plane[3];          /* final reconstruction (after the loop filters), tightly packed */
+  const uint8_t *pred_mode;          /* motion field after TComPic::compressMotion: [numCtus*256] */
+  const int16_t *mv[2];              /* [numCtus*256*2] (x, y) */
+  const int8_t *ref_idx[2];          /* [numCtus*256] */
+  int num_ref[2], ref_poc[2][16], ref_lt[2][16];    /* the reference lists that picture was coded with */
+} hmo_ref_pic;
+typedef struct {
+  int slice_type, poc;               /* 1 = P (B slices: not restated yet) */
+  int cabac_init_type;               /* context table actually used (TEncSbac::resetEntropy :106-115): 0 = B, 1 = P */
+  int num_ref_idx[2];
+  const hmo_ref_pic *ref[2][16];
+  int col_from_l0, col_ref_idx, tmvp, mvd_l1_zero, max_merge_cand, check_ldc;
+  uint32_t lambda_motion_sad, lambda_motion_sse;    /* TComRdCost::m_uiLambdaMotionSAD/SSE[0] */
+} hmo_inter_slice;
+typedef struct {
+  uint8_t skip[256], merge_flag[256], merge_idx[256], inter_dir[256];
+  int16_t mv[2][256][2], mvd[2][256][2];
+  int8_t ref_idx[2][256], mvp_idx[2][256], mvp_num[2][256];
+} hmo_ctu_inter;
+int hmo_compress_slice_inter(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],
+                             hmo_ctu *ctus, hmo_ctu_inter *ictus);
+
 /* ---- primitives, exported for the known-answer tests (TComRdCost.cpp / TComTrQuant.cpp) ---- */
 uint32_t hmo_sad(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int sub_shift, int bit_depth);
 uint32_t hmo_sse(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int bit_depth);

@@ -70,3 +70,74 @@ def transform(inverse, block, bit_depth, use_dst=0):
     f = L.hmo_inv_transform if inverse else L.hmo_fwd_transform
     f(bit_depth, b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), n, use_dst)
     return out
+
+
+# ---- P slices -------------------------------------------------------------------------------------------------
+class RefPic(C.Structure):
+    _fields_ = [("poc", C.c_int), ("slice_type", C.c_int), ("long_term", C.c_int), ("plane", C.c_void_p * 3),
+                ("pred_mode", C.c_void_p), ("mv", C.c_void_p * 2), ("ref_idx", C.c_void_p * 2),
+                ("num_ref", C.c_int * 2), ("ref_poc", (C.c_int * 16) * 2), ("ref_lt", (C.c_int * 16) * 2)]
+
+
+class InterSlice(C.Structure):
+    _fields_ = [("slice_type", C.c_int), ("poc", C.c_int), ("cabac_init_type", C.c_int), ("num_ref_idx", C.c_int * 2),
+                ("ref", (C.POINTER(RefPic) * 16) * 2),
+                ("col_from_l0", C.c_int), ("col_ref_idx", C.c_int), ("tmvp", C.c_int), ("mvd_l1_zero", C.c_int),
+                ("max_merge_cand", C.c_int), ("check_ldc", C.c_int),
+                ("lambda_motion_sad", C.c_uint32), ("lambda_motion_sse", C.c_uint32)]
+
+
+CTU_INTER_DTYPE = np.dtype([("skip", "u1", 256), ("merge_flag", "u1", 256), ("merge_idx", "u1", 256), ("inter_dir", "u1", 256),
+                            ("mv", "<i2", (2, 256, 2)), ("mvd", "<i2", (2, 256, 2)),
+                            ("ref_idx", "i1", (2, 256)), ("mvp_idx", "i1", (2, 256)), ("mvp_num", "i1", (2, 256))])
+
+
+def compress_inter(planes, bit_depth, srec, finals, trace=None):
+    """One P slice.  srec: an 'S' record of tests/hmd2.py (slice parameters as the reference used them);
+    finals: {poc: 'F' record} of the pictures it references.  Returns (rec planes, ctus, inter ctus)."""
+    L = lib()
+    h, w = planes[0].shape
+    cfg = Cfg(w, h, bit_depth, int(srec["qp"]), 0, float(srec["lambda"]), float(srec["weight_cb"]))
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    keep, refs = [], {}
+    for poc in set(int(srec["ref_poc"][l][i]) for l in range(2) for i in range(srec["num_ref_idx"][l])):
+        f = finals[poc]
+        pl = [np.ascontiguousarray(p, np.uint16) for p in f["rec"]]
+        mot = f["motion"]
+        pm = np.ascontiguousarray(mot["pred_mode"]); mv = [np.ascontiguousarray(mot["mv0"]), np.ascontiguousarray(mot["mv1"])]
+        ri = [np.ascontiguousarray(mot["ref_idx0"]), np.ascontiguousarray(mot["ref_idx1"])]
+        keep += pl + [pm] + mv + ri
+        r = RefPic()
+        r.poc, r.slice_type, r.long_term = poc, int(f["slice_type"]), 0
+        for c in range(3):
+            r.plane[c] = pl[c].ctypes.data
+        r.pred_mode = pm.ctypes.data
+        for l in range(2):
+            r.mv[l] = mv[l].ctypes.data; r.ref_idx[l] = ri[l].ctypes.data; r.num_ref[l] = int(f["num_ref_idx"][l])
+            for i in range(16):
+                r.ref_poc[l][i] = int(f["ref_poc"][l][i]); r.ref_lt[l][i] = int(f["ref_long_term"][l][i])
+        refs[poc] = r
+    s = InterSlice()
+    s.slice_type, s.poc, s.cabac_init_type = int(srec["slice_type"]), int(srec["poc"]), int(srec["cabac_init_type"])
+    for l in range(2):
+        s.num_ref_idx[l] = int(srec["num_ref_idx"][l])
+        for i in range(s.num_ref_idx[l]):
+            s.ref[l][i] = C.pointer(refs[int(srec["ref_poc"][l][i])])
+    s.col_from_l0, s.col_ref_idx, s.tmvp = int(srec["col_from_l0"]), int(srec["col_ref_idx"]), int(srec["tmvp"])
+    s.mvd_l1_zero, s.max_merge_cand, s.check_ldc = int(srec["mvd_l1_zero"]), int(srec["max_merge_cand"]), int(srec["check_ldc"])
+    s.lambda_motion_sad, s.lambda_motion_sse = int(srec["lambda_motion_sad"]), int(srec["lambda_motion_sse"])
+    org = [np.ascontiguousarray(p, np.uint16) for p in planes]
+    rec = [np.zeros_like(p) for p in org]
+    ctus, ictus = np.zeros(n, CTU_DTYPE), np.zeros(n, CTU_INTER_DTYPE)
+    po = (C.c_void_p * 3)(*[p.ctypes.data for p in org])
+    pr = (C.c_void_p * 3)(*[p.ctypes.data for p in rec])
+    L.hmo_compress_slice_inter.argtypes = [C.POINTER(Cfg), C.POINTER(InterSlice), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hmo_set_trace.argtypes = [C.c_char_p]
+    if trace:
+        L.hmo_set_trace(trace.encode())
+    rc = L.hmo_compress_slice_inter(C.byref(cfg), C.byref(s), po, pr, ctus.ctypes.data, ictus.ctypes.data)
+    if trace:
+        L.hmo_set_trace(None)
+    if rc != 0:
+        raise RuntimeError(f"oracle (inter) failed rc={rc}")
+    return rec, ctus, ictus

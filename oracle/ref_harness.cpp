@@ -39,6 +39,7 @@
 #include "TLibCommon/TComRdCost.h"
 #include "TLibCommon/TComTrQuant.h"
 #include "TLibCommon/TComPic.h"
+#include "TLibEncoder/TEncSlice.h"
 #undef private
 #undef protected
 
@@ -118,6 +119,128 @@ static void dumpPic(FILE *f, TComPic *pic)
       for (Int x = 0; x < w; x++) row[x] = (uint16_t)p[y * s + x];
       fwrite(&row[0], 2, w, f);
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// inter dump (HMD2): link-time wraps around TEncSlice::compressSlice (TEncSlice.cpp:640) and
+// TComPic::compressMotion (TComPic.cpp, called at the end of each picture, TEncGOP.cpp:1660).
+// Record stream (little endian), in encoding order:
+//   'S' : one slice as compressSlice sees and leaves it
+//         i32 poc, sliceType, sliceQp, tLayer, depth; f64 lambda, sqrtLambda, weightCb, weightCr;
+//         u32 lambdaMotionSAD, lambdaMotionSSE; i32 numRefIdx[2]; i32 refPOC[2][16]; i32 refIsLongTerm[2][16];
+//         i32 colFromL0, colRefIdx, enableTMVP, mvdL1Zero, maxNumMergeCand, checkLDC, cabacInitType; i32 list1ToList0[16]
+//         u32 numCtus; per CTU: f64 cost, u32 bits, u32 dist, u8[12][256] (as HMD1), u8[4][256] skip, mergeFlag,
+//         mergeIndex, interDir; per list l: i16[256][2] mv, i16[256][2] mvd, i8[256] refIdx, i8[256] mvpIdx, i8[256] mvpNum;
+//         i32[6144] coefficients; then the pre-deblocking reconstruction planes (u16)
+//   'F' : the finished picture as later pictures reference it
+//         i32 poc; final reconstruction planes (u16, after deblocking + SAO); i32 sliceType; i32 numRefIdx[2];
+//         i32 refPOC[2][16]; i32 refIsLongTerm[2][16]; u32 numCtus; per CTU: u8[256] predMode and, per list, i16[256][2] mv,
+//         i8[256] refIdx -- the motion field after compressMotion (16x16 granularity)
+// ---------------------------------------------------------------------------------------------
+static FILE *g_dump2 = NULL;
+static void putPlanes(FILE *f, TComPicYuv *rec)
+{
+  for (int c = 0; c < 3; c++)
+  {
+    ComponentID id = ComponentID(c);
+    const Int w = rec->getWidth(id), h = rec->getHeight(id), s = rec->getStride(id);
+    const Pel *p = rec->getAddr(id);
+    std::vector<uint16_t> row(w);
+    for (Int y = 0; y < h; y++) { for (Int x = 0; x < w; x++) row[x] = (uint16_t)p[y * s + x]; fwrite(&row[0], 2, w, f); }
+  }
+}
+static void putRefLists(FILE *f, TComSlice *sl)
+{
+  int32_t n[2] = { sl->getSliceType() == I_SLICE ? 0 : sl->getNumRefIdx(REF_PIC_LIST_0), sl->getSliceType() == B_SLICE ? sl->getNumRefIdx(REF_PIC_LIST_1) : 0 };
+  fwrite(n, 4, 2, f);
+  int32_t poc[2][16], lt[2][16];
+  memset(poc, 0, sizeof(poc)); memset(lt, 0, sizeof(lt));
+  for (int l = 0; l < 2; l++) for (int i = 0; i < n[l]; i++)
+  { poc[l][i] = sl->getRefPOC(RefPicList(l), i); lt[l][i] = sl->getRefPic(RefPicList(l), i)->getIsLongTerm() ? 1 : 0; }
+  fwrite(poc, 4, 32, f); fwrite(lt, 4, 32, f);
+}
+static void putMotion(FILE *f, TComDataCU *ctu, int l, bool full)
+{
+  TComCUMvField *mf = ctu->getCUMvField(RefPicList(l));
+  int16_t mv[256][2], mvd[256][2]; int8_t ri[256], mi[256], mn[256];
+  for (int i = 0; i < 256; i++)
+  {
+    mv[i][0] = (int16_t)mf->getMv(i).getHor(); mv[i][1] = (int16_t)mf->getMv(i).getVer();
+    mvd[i][0] = (int16_t)mf->getMvd(i).getHor(); mvd[i][1] = (int16_t)mf->getMvd(i).getVer();
+    ri[i] = (int8_t)mf->getRefIdx(i); mi[i] = (int8_t)ctu->getMVPIdx(RefPicList(l), i); mn[i] = (int8_t)ctu->getMVPNum(RefPicList(l), i);
+  }
+  fwrite(mv, 2, 512, f);
+  if (full) fwrite(mvd, 2, 512, f);
+  fwrite(ri, 1, 256, f);
+  if (full) { fwrite(mi, 1, 256, f); fwrite(mn, 1, 256, f); }
+}
+extern "C" void __real__ZN9TEncSlice13compressSliceEP7TComPic(TEncSlice *self, TComPic *pic);
+extern "C" void __wrap__ZN9TEncSlice13compressSliceEP7TComPic(TEncSlice *self, TComPic *pic)
+{
+  __real__ZN9TEncSlice13compressSliceEP7TComPic(self, pic);
+  if (!g_dump2) return;
+  FILE *f = g_dump2;
+  TComSlice *sl = pic->getSlice(self->getSliceIdx());
+  fputc('S', f);
+  int32_t hdr[5] = { sl->getPOC(), (int32_t)sl->getSliceType(), sl->getSliceQp(), (int32_t)sl->getTLayer(), sl->getDepth() };
+  fwrite(hdr, 4, 5, f);
+  double d[4] = { self->m_pcRdCost->m_dLambda, self->m_pcRdCost->m_sqrtLambda, self->m_pcRdCost->m_distortionWeight[COMPONENT_Cb], self->m_pcRdCost->m_distortionWeight[COMPONENT_Cr] };
+  fwrite(d, 8, 4, f);
+  put32(f, self->m_pcRdCost->m_uiLambdaMotionSAD[0]); put32(f, self->m_pcRdCost->m_uiLambdaMotionSSE[0]);
+  putRefLists(f, sl);
+  // context initialisation table the estimator used (TEncSbac::resetEntropy, TEncSbac.cpp:106-115)
+  int32_t initType = (int32_t)sl->getSliceType();
+  { const Int idx = sl->getPPS()->getEncCABACTableIdx();
+    if (!sl->isIntra() && (idx == B_SLICE || idx == P_SLICE) && sl->getPPS()->getCabacInitPresentFlag()) initType = idx; }
+  int32_t misc[7] = { (int32_t)sl->getColFromL0Flag(), (int32_t)sl->getColRefIdx(), sl->getEnableTMVPFlag() ? 1 : 0, sl->getMvdL1ZeroFlag() ? 1 : 0,
+                      (int32_t)sl->getMaxNumMergeCand(), sl->getCheckLDC() ? 1 : 0, initType };
+  fwrite(misc, 4, 7, f);
+  int32_t l1l0[16]; for (int i = 0; i < 16; i++) l1l0[i] = sl->getList1IdxToList0Idx(i);
+  fwrite(l1l0, 4, 16, f);
+  const UInt numCtus = pic->getPicSym()->getNumberOfCtusInFrame();
+  put32(f, numCtus);
+  for (UInt a = 0; a < numCtus; a++)
+  {
+    TComDataCU *ctu = pic->getCtu(a);
+    double cost = ctu->getTotalCost();
+    fwrite(&cost, 8, 1, f); put32(f, ctu->getTotalBits()); put32(f, (uint32_t)ctu->getTotalDistortion());
+    uint8_t buf[16][256];
+    for (UInt i = 0; i < 256; i++)
+    {
+      buf[0][i] = ctu->getDepth(i); buf[1][i] = (uint8_t)ctu->getPartitionSize(i); buf[2][i] = (uint8_t)ctu->getPredictionMode(i);
+      buf[3][i] = ctu->getIntraDir(CHANNEL_TYPE_LUMA, i); buf[4][i] = ctu->getIntraDir(CHANNEL_TYPE_CHROMA, i); buf[5][i] = ctu->getTransformIdx(i);
+      buf[6][i] = ctu->getCbf(COMPONENT_Y)[i]; buf[7][i] = ctu->getCbf(COMPONENT_Cb)[i]; buf[8][i] = ctu->getCbf(COMPONENT_Cr)[i];
+      buf[9][i] = ctu->getTransformSkip(COMPONENT_Y)[i]; buf[10][i] = ctu->getTransformSkip(COMPONENT_Cb)[i]; buf[11][i] = ctu->getTransformSkip(COMPONENT_Cr)[i];
+      buf[12][i] = ctu->getSkipFlag(i) ? 1 : 0; buf[13][i] = ctu->getMergeFlag(i) ? 1 : 0; buf[14][i] = ctu->getMergeIndex(i); buf[15][i] = ctu->getInterDir(i);
+    }
+    fwrite(buf, 1, sizeof(buf), f);
+    putMotion(f, ctu, 0, true); putMotion(f, ctu, 1, true);
+    fwrite(ctu->getCoeff(COMPONENT_Y), 4, 4096, f); fwrite(ctu->getCoeff(COMPONENT_Cb), 4, 1024, f); fwrite(ctu->getCoeff(COMPONENT_Cr), 4, 1024, f);
+  }
+  putPlanes(f, pic->getPicYuvRec());
+}
+extern "C" void __real__ZN7TComPic14compressMotionEv(TComPic *self);
+extern "C" void __wrap__ZN7TComPic14compressMotionEv(TComPic *self)
+{
+  __real__ZN7TComPic14compressMotionEv(self);
+  if (!g_dump2) return;
+  FILE *f = g_dump2;
+  TComSlice *sl = self->getSlice(0);
+  fputc('F', f);
+  int32_t poc = self->getPOC(); fwrite(&poc, 4, 1, f);
+  putPlanes(f, self->getPicYuvRec());
+  int32_t st = (int32_t)sl->getSliceType(); fwrite(&st, 4, 1, f);
+  putRefLists(f, sl);
+  const UInt numCtus = self->getPicSym()->getNumberOfCtusInFrame();
+  put32(f, numCtus);
+  for (UInt a = 0; a < numCtus; a++)
+  {
+    TComDataCU *ctu = self->getCtu(a);
+    uint8_t pm[256]; for (int i = 0; i < 256; i++) pm[i] = (uint8_t)ctu->getPredictionMode(i);
+    fwrite(pm, 1, 256, f);
+    putMotion(f, ctu, 0, false); putMotion(f, ctu, 1, false);
   }
 }
 
@@ -285,6 +408,21 @@ int main(int argc, char **argv)
 {
   if (getenv("HM_TRACE")) g_trace = fopen(getenv("HM_TRACE"), "w");
   if (argc >= 4 && !strcmp(argv[1], "kat")) return runKat(argv[2], (uint32_t)atoi(argv[3]));
+  if (argc >= 4 && !strcmp(argv[1], "enc2"))
+  { // hm_dump enc2 <HM options...> -- dump2.bin : the HMD2 record stream (inter-capable)
+    int sep = -1;
+    for (int i = 2; i < argc; i++) if (!strcmp(argv[i], "--")) sep = i;
+    if (sep < 0 || sep + 1 >= argc) { fprintf(stderr, "usage: hm_dump enc2 <HM options> -- <dump2.bin>\n"); return 2; }
+    std::vector<char*> av; av.push_back(argv[0]);
+    for (int i = 2; i < sep; i++) av.push_back(argv[i]);
+    g_dump2 = fopen(argv[sep + 1], "wb");
+    if (!g_dump2) { perror(argv[sep + 1]); return 1; }
+    fwrite("HMD2", 1, 4, g_dump2);
+    int rc = runEnc((int)av.size(), &av[0], "/dev/null");
+    fclose(g_dump2);
+    if (g_trace) fclose(g_trace);
+    return rc;
+  }
   if (argc >= 4 && !strcmp(argv[1], "enc"))
   {
     // argv: hm_dump enc <HM options...> -- dump.bin

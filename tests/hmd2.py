@@ -1,0 +1,63 @@
+"""Reader of the HMD2 record stream written by `oracle/_ref/hm_dump enc2` (oracle/ref_harness.cpp):
+'S' records = one slice as TEncSlice::compressSlice saw and left it, 'F' records = the finished picture
+as later pictures reference it (final reconstruction + compressed motion field)."""
+import struct
+
+import numpy as np
+
+CTU_DT = np.dtype([("total_cost", "<f8"), ("total_bits", "<u4"), ("total_dist", "<u4"),
+                   ("depth", "u1", 256), ("part_size", "u1", 256), ("pred_mode", "u1", 256),
+                   ("intra_dir_luma", "u1", 256), ("intra_dir_chroma", "u1", 256), ("tr_idx", "u1", 256),
+                   ("cbf", "u1", (3, 256)), ("tskip", "u1", (3, 256)),
+                   ("skip", "u1", 256), ("merge_flag", "u1", 256), ("merge_idx", "u1", 256), ("inter_dir", "u1", 256),
+                   ("mv0", "<i2", (256, 2)), ("mvd0", "<i2", (256, 2)), ("ref_idx0", "i1", 256), ("mvp_idx0", "i1", 256), ("mvp_num0", "i1", 256),
+                   ("mv1", "<i2", (256, 2)), ("mvd1", "<i2", (256, 2)), ("ref_idx1", "i1", 256), ("mvp_idx1", "i1", 256), ("mvp_num1", "i1", 256),
+                   ("coeff_y", "<i4", 4096), ("coeff_cb", "<i4", 1024), ("coeff_cr", "<i4", 1024)])
+MOT_DT = np.dtype([("pred_mode", "u1", 256), ("mv0", "<i2", (256, 2)), ("ref_idx0", "i1", 256), ("mv1", "<i2", (256, 2)), ("ref_idx1", "i1", 256)])
+
+
+def _planes(buf, off, w, h):
+    out = []
+    for c in range(3):
+        cw, ch = (w, h) if c == 0 else (w // 2, h // 2)
+        out.append(np.frombuffer(buf, "<u2", cw * ch, off).reshape(ch, cw).copy())
+        off += 2 * cw * ch
+    return out, off
+
+
+def _ref_lists(buf, off):
+    n = struct.unpack_from("<2i", buf, off); off += 8
+    poc = np.frombuffer(buf, "<i4", 32, off).reshape(2, 16).copy(); off += 128
+    lt = np.frombuffer(buf, "<i4", 32, off).reshape(2, 16).copy(); off += 128
+    return {"num_ref_idx": n, "ref_poc": poc, "ref_long_term": lt}, off
+
+
+def parse(path, width, height):
+    buf = open(path, "rb").read()
+    assert buf[:4] == b"HMD2"
+    off, recs = 4, []
+    while off < len(buf):
+        tag = buf[off:off + 1]; off += 1
+        if tag == b"S":
+            r = {"tag": "S"}
+            r["poc"], r["slice_type"], r["qp"], r["tlayer"], r["depth"] = struct.unpack_from("<5i", buf, off); off += 20
+            r["lambda"], r["sqrt_lambda"], r["weight_cb"], r["weight_cr"] = struct.unpack_from("<4d", buf, off); off += 32
+            r["lambda_motion_sad"], r["lambda_motion_sse"] = struct.unpack_from("<2I", buf, off); off += 8
+            rl, off = _ref_lists(buf, off); r.update(rl)
+            (r["col_from_l0"], r["col_ref_idx"], r["tmvp"], r["mvd_l1_zero"], r["max_merge_cand"], r["check_ldc"], r["cabac_init_type"]) = struct.unpack_from("<7i", buf, off); off += 28
+            r["l1_to_l0"] = np.frombuffer(buf, "<i4", 16, off).copy(); off += 64
+            n, = struct.unpack_from("<I", buf, off); off += 4
+            r["ctus"] = np.frombuffer(buf, CTU_DT, n, off).copy(); off += n * CTU_DT.itemsize
+            r["rec"], off = _planes(buf, off, width, height)
+        elif tag == b"F":
+            r = {"tag": "F"}
+            r["poc"], = struct.unpack_from("<i", buf, off); off += 4
+            r["rec"], off = _planes(buf, off, width, height)
+            r["slice_type"], = struct.unpack_from("<i", buf, off); off += 4
+            rl, off = _ref_lists(buf, off); r.update(rl)
+            n, = struct.unpack_from("<I", buf, off); off += 4
+            r["motion"] = np.frombuffer(buf, MOT_DT, n, off).copy(); off += n * MOT_DT.itemsize
+        else:
+            raise ValueError(f"bad record tag {tag!r} at {off - 1}")
+        recs.append(r)
+    return recs
