@@ -67,3 +67,42 @@ def assert_rec_equal(got_planes, want_flat, w, h, what):
     want = split_rec(want_flat, w, h)
     for k in range(3):
         assert np.array_equal(got_planes[k], want[k]), f"{what}: reconstruction plane {k} differs at {np.count_nonzero(got_planes[k] != want[k])} samples"
+
+
+LDP_CASES = ["ldp_192x128_8b_qp32", "ldp_200x136_8b_qp24"]
+_S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
+           "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
+
+
+def load_ldp_case(name):
+    """-> (cfg dict, list of 'S' records, {poc: 'F' record}) in the layout of tests/hmd2.py"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = {k: int(g[k]) for k in ("width", "height", "bit_depth", "frames", "seed")}
+    slices, finals = [], {}
+    for i in range(int(g["num_records"])):
+        r = {"tag": chr(int(g[f"r{i}_tag"])), "num_ref_idx": tuple(int(v) for v in g[f"r{i}_num_ref_idx"]),
+             "ref_poc": g[f"r{i}_ref_poc"], "ref_long_term": g[f"r{i}_ref_long_term"], "rec": [g[f"r{i}_rec{c}"] for c in range(3)]}
+        if r["tag"] == "S":
+            for k in _S_KEYS:
+                r[k] = g[f"r{i}_{k}"][()]
+            r["ctus"] = g[f"r{i}_ctus"]
+            slices.append(r)
+        else:
+            r["poc"] = int(g[f"r{i}_poc"]); r["slice_type"] = int(g[f"r{i}_slice_type"]); r["motion"] = g[f"r{i}_motion"]
+            finals[r["poc"]] = r
+    return cfg, slices, finals
+
+
+INTER_PAIRS = [("skip", "skip"), ("merge_flag", "merge_flag"), ("merge_idx", "merge_idx"), ("inter_dir", "inter_dir")]
+
+
+def assert_inter_ctus_equal(ctus, ictus, want, what):
+    """bit-exact comparison of a P slice: everything assert_ctus_equal checks plus the motion data"""
+    for f in ("total_bits", "total_dist", "total_cost", "depth", "part_size", "pred_mode", "intra_dir_luma", "intra_dir_chroma", "tr_idx",
+              "cbf", "tskip", "coeff_y", "coeff_cb", "coeff_cr"):
+        assert np.array_equal(ctus[f], want[f]), f"{what}: {f} differs in CTUs {np.nonzero((ctus[f] != want[f]).reshape(len(ctus), -1).any(axis=1))[0][:8]}"
+    for f, g in INTER_PAIRS:
+        assert np.array_equal(ictus[f], want[g]), f"{what}: {f} differs"
+    for l in range(2):
+        for f, g in (("mv", "mv%d"), ("mvd", "mvd%d"), ("ref_idx", "ref_idx%d"), ("mvp_idx", "mvp_idx%d"), ("mvp_num", "mvp_num%d")):
+            assert np.array_equal(ictus[f][:, l], want[g % l]), f"{what}: {g % l} differs"

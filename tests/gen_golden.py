@@ -104,9 +104,51 @@ def gen_kat():
     print("kat ok", len(recs["dist_out"]), "distortion records,", len(recs["tr_out"]), "transform records")
 
 
+# inter (low-delay P) cases: name, width, height, bit depth, frames, qp, seed.  encoder_lowdelay_P_main.cfg as is (4 references,
+# deblocking + SAO on): the reference pictures a P slice sees are inputs of compressSlice, so they are part of the fixture.
+LDP_CASES = [
+    ("ldp_192x128_8b_qp32", 192, 128, 8, 6, 32, 1234),
+    ("ldp_200x136_8b_qp24", 200, 136, 8, 5, 24, 5),           # picture not a multiple of the CTU size
+]
+S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
+          "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
+
+
+def run_ldp_case(name, w, h, bd, nf, qp, seed):
+    import hmd2
+    with tempfile.TemporaryDirectory() as td:
+        yuv = os.path.join(td, "in.yuv")
+        synth.write_yuv(yuv, w, h, bd, nf, seed)
+        dump = os.path.join(td, "dump2.bin")
+        cmd = [HM_DUMP, "enc2", "-c", os.path.join(REF_CFG, "encoder_lowdelay_P_main.cfg"), "-i", yuv, "-wdt", str(w), "-hgt", str(h),
+               "-fr", "50", "-f", str(nf), f"--InputBitDepth={bd}", "-q", str(qp), "-b", os.path.join(td, "o.bin"),
+               "-o", os.path.join(td, "r.yuv"), "--", dump]
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        recs = hmd2.parse(dump, w, h)
+    out = {"width": w, "height": h, "bit_depth": bd, "frames": nf, "seed": seed, "num_records": len(recs)}
+    for i, r in enumerate(recs):
+        out[f"r{i}_tag"] = np.array(ord(r["tag"]))
+        out[f"r{i}_num_ref_idx"] = np.array(r["num_ref_idx"]); out[f"r{i}_ref_poc"] = r["ref_poc"]; out[f"r{i}_ref_long_term"] = r["ref_long_term"]
+        for c in range(3):
+            out[f"r{i}_rec{c}"] = r["rec"][c]
+        if r["tag"] == "S":
+            for k in S_KEYS:
+                out[f"r{i}_{k}"] = np.array(r[k])
+            out[f"r{i}_ctus"] = r["ctus"]
+        else:
+            out[f"r{i}_poc"] = np.array(r["poc"]); out[f"r{i}_slice_type"] = np.array(r["slice_type"]); out[f"r{i}_motion"] = r["motion"]
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "ok", len(recs), "records")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    gen_kat()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if "--ldp-only" not in sys.argv:
+        gen_kat()
     if "--kat-only" not in sys.argv:
-        for c in CASES:
-            run_case(*c)
+        if "--ldp-only" not in sys.argv:
+            for c in CASES:
+                run_case(*c)
+        for c in LDP_CASES:
+            run_ldp_case(*c)

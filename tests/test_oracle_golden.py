@@ -51,3 +51,23 @@ def test_oracle_transform_kats(built):
         want = k["tr_out"][ooff[r]:ooff[r + 1]].reshape(n, n)
         got = oracle.transform(tag == 5, blk, bd, dst)
         assert np.array_equal(got, want), f"record {r} tag {tag} n {n} bd {bd} dst {dst}"
+
+
+@pytest.mark.parametrize("name", common.LDP_CASES)
+def test_oracle_matches_reference_p_slices(built, name):
+    """encoder_lowdelay_P_main.cfg: every P slice of the clip, with the reference pictures (final reconstruction + motion
+    field) and slice parameters exactly as the reference's compressSlice saw them; decisions, motion, coefficients,
+    costs and the pre-deblocking reconstruction must match bit for bit."""
+    import oracle
+    cfg, slices, finals = common.load_ldp_case(name)
+    n_p = 0
+    for r in slices:
+        if int(r["slice_type"]) != 1:
+            continue
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"])
+        rec, ctus, ictus = oracle.compress_inter(planes, cfg["bit_depth"], r, finals)
+        common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], f"{name} POC {int(r['poc'])}")
+        for c in range(3):
+            assert np.array_equal(rec[c], r["rec"][c]), f"{name} POC {int(r['poc'])}: reconstruction plane {c}"
+        n_p += 1
+    assert n_p >= 4
