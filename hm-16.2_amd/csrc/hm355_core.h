@@ -194,14 +194,60 @@ HM_CONST int32_t HM_ENTROPY_BITS[128] = {
   0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f, 0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb };
 // I-slice context initialisation values, ContextTables.h:170-502 (our context order, see hm355_types.h)
 HM_CONST uint8_t HM_CTX_INIT_I[HM_NUM_CTX] = {
-  139, 141, 157,   184, 154, 154, 154,   184,   63, 139,   153, 138, 138,
-  111, 141, 154, 154, 154, 94, 138, 182, 154, 154,   91, 171, 134, 141,
-  111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 141,
-  140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 111,
-  110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
-  110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
-  140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
-  138, 153, 136, 167, 152, 152,   139, 139 };
+  /* split */ 139, 141, 157,
+  /* part size */ 184, 154, 154, 154,
+  /* intra luma */ 184,
+  /* chroma pred */ 63, 139,
+  /* trans subdiv */ 153, 138, 138,
+  /* qt cbf */ 111, 141, 154, 154, 154,   94, 138, 182, 154, 154,
+  /* sig cg */ 91, 171, 134, 141,
+  /* sig luma 28 */ 111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 141,
+  /* sig chroma 16 */ 140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 111,
+  /* last x: luma 15, chroma 15 */ 110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79,  108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* last y */ 110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79,  108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* one: luma 16, chroma 8 */ 140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152,  140, 179, 166, 182, 140, 227, 122, 197,
+  /* abs: luma 4, chroma 2 */ 138, 153, 136, 167, 152, 152,
+  /* transform skip */ 139, 139,
+  /* skip */ 154, 154, 154, /* merge flag, idx */ 154, 154, /* pred mode */ 154, /* inter dir */ 154, 154, 154, 154, 154, /* mvd */ 154, 154,
+  /* ref idx */ 154, 154, /* root cbf */ 154, /* mvp idx */ 154
+};
+// P- and B-slice rows of the same tables
+HM_CONST uint8_t HM_CTX_INIT_P[HM_NUM_CTX] = {
+  /* split */ 107, 139, 126,
+  /* part size */ 154, 139, 154, 154,
+  /* intra luma */ 154,
+  /* chroma pred */ 152, 139,
+  /* trans subdiv */ 124, 138, 94,
+  /* qt cbf */ 153, 111, 154, 154, 154,   149, 107, 167, 154, 154,
+  /* sig cg */ 121, 140, 61, 154,
+  /* sig luma 28 */ 155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 140,
+  /* sig chroma 16 */ 170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140, 140,
+  /* last x */ 125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94,  108, 123, 108, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* last y */ 125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94,  108, 123, 108, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* one: luma 16, chroma 8 */ 154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137,  169, 194, 166, 167, 154, 167, 137, 182,
+  /* abs: luma 4, chroma 2 */ 107, 167, 91, 122, 107, 167,
+  /* transform skip */ 139, 139,
+  /* skip */ 197, 185, 201, /* merge flag, idx */ 110, 122, /* pred mode */ 149, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 140, 198,
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
+};
+HM_CONST uint8_t HM_CTX_INIT_B[HM_NUM_CTX] = {
+  /* split */ 107, 139, 126,
+  /* part size */ 154, 139, 154, 154,
+  /* intra luma */ 183,
+  /* chroma pred */ 152, 139,
+  /* trans subdiv */ 224, 167, 122,
+  /* qt cbf */ 153, 111, 154, 154, 154,   149, 92, 167, 154, 154,
+  /* sig cg */ 121, 140, 61, 154,
+  /* sig luma 28 */ 170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 140,
+  /* sig chroma 16 */ 170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140, 140,
+  /* last x */ 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79,  108, 123, 93, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* last y */ 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79,  108, 123, 93, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+  /* one: luma 16, chroma 8 */ 154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122,  169, 208, 166, 167, 154, 152, 167, 182,
+  /* abs: luma 4, chroma 2 */ 107, 167, 91, 107, 107, 167,
+  /* transform skip */ 139, 139,
+  /* skip */ 197, 185, 201, /* merge flag, idx */ 154, 137, /* pred mode */ 134, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 169, 198,
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
+};
 // first column of the 32-point core transform (TComRom.cpp:456-484); the matrix follows the cosine index law
 HM_CONST int8_t HM_DCT_C[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
 HM_CONST int8_t HM_DST4[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
@@ -227,7 +273,15 @@ struct TuWalk { TU node[5]; int8_t next[5]; int sp; };
 struct RqtFrame {
   TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf; double singleCost, splitCost;
 };
-struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
+struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary, parentPart; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
+// inter (P slice) helpers kept in LDS
+struct MvFieldD { MvD mv; int ref; };
+struct MergeList { MvFieldD f[5]; uint8_t dir[5]; int num; };      // list 0 only (P slice)
+struct AmvpInfo { MvD cand[3]; int n; };
+struct IrqFrame {                      // one level of the inter residual quadtree (xEstimateResidualQT)
+  TU t; int8_t phase, child, checkFull, checkSplit, zero; uint8_t bestTS[3];
+  uint32_t absSum[3], bestCBF[3], singleBits, singleDist, subBits, subDist; double singleCost, subCost;
+};
 
 #define HM_TSTRIDE 33
 #define HM_RQ_LDS 256                  // RDOQ per-position arrays live in LDS up to 16x16, in HBM scratch for 32x32
@@ -272,6 +326,12 @@ struct Shared {
   double outCost; uint32_t outBits, outDist; double outRdCost; uint32_t outDistY;
   uint32_t satd[36];                   // SATD of the 35 intra modes of the PU under test
   int32_t mpmZ, mpmNum, mpmPreds[3];   // most-probable-mode list of the PU under test (same for all its candidates)
+  // inter (P slice) state
+  InterMeta *im;                       // motion arrays of the CTU under search (HBM)
+  uint32_t mcost; MvD mvPredictor; int32_t costScale;   // TComRdCost motion-cost state
+  MvD intMv[16];                       // TEncSearch::m_integerMv2Nx2N[list 0][refIdx]
+  MvD outMv; MergeList ml; AmvpInfo amvp; MvFieldD mrgField; int32_t mrgDir, mrgIdx; uint32_t mrgCost, irqZeroDist;
+  IrqFrame irq[4];
   // uniform per-CTU context
   int32_t width, height, bitDepth, wCtu, stride[3];
   const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
@@ -327,11 +387,11 @@ HM_DEV inline void cabac_copy(Cabac *d, const Cabac *s)
   HM_PAR_FOR(i, (int)(sizeof(Cabac) / 8)) dp[i] = sp[i];
   HM_SYNC();
 }
-HM_DEV inline void cabac_init(Cabac *c, int qp)
+HM_DEV inline void cabac_init(Cabac *c, int qp, int initType = 2)
 { // ContextModel::init, ContextModel.cpp:55-64; TEncSbac::resetEntropy, TEncSbac.cpp:106-161
   qp = hm_clip3(0, 51, qp);
   HM_PAR_FOR(i, HM_NUM_CTX) {
-    const int iv = HM_CTX_INIT_I[i];
+    const int iv = initType == 2 ? HM_CTX_INIT_I[i] : (initType == 1 ? HM_CTX_INIT_P[i] : HM_CTX_INIT_B[i]);
     const int slope = (iv >> 4) * 5 - 45, offset = ((iv & 15) << 3) - 16;
     int st = ((slope * qp) >> 4) + offset; st = st < 1 ? 1 : (st > 126 ? 126 : st);
     const int mps = st >= 64;
@@ -359,6 +419,9 @@ HM_DEV inline double calc_rd_cost(const Shared *e, uint32_t bits, uint32_t dist)
   const double u = (double)dist + t;
   return floor(u + 0.5);
 }
+
+struct Rect;
+template <class C> HM_DEV inline void code_skip_flag(Shared *e, C *c, int z);   // hm355_inter.h
 
 // ------------------------------------------------------------------------------------------------
 // distortion (TComRdCost.cpp): lanes split the samples / the Hadamard blocks, butterfly-reduce
@@ -848,7 +911,8 @@ HM_DEV HM_NOINLINE void satd_all_modes_small(Shared *e, const Pel *org, int so, 
 // coefficient coding parameters
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline int coef_scan_idx(const CtuMeta *m, int z, int n, int comp)
-{ // TComDataCU::getCoefScanIdx, TComDataCU.cpp:3340-3380
+{
+  if (m->pred[z] != MODE_INTRA) return SCAN_DIAG; // TComDataCU::getCoefScanIdx, TComDataCU.cpp:3340-3380
   if (n > (comp ? 4 : 8)) return SCAN_DIAG;
   int dir = comp ? m->dirC[z] : m->dirL[z];
   if (dir == DM_CHROMA_IDX) dir = m->dirL[z & ~3];
@@ -998,7 +1062,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     HM_LVK(tSig, k) = c < (chroma ? 16 : 28) ? HM_ENTROPY_BITS[cb->s[sigOff + c] ^ bin] : 0;
     HM_LVK(tOne, k) = c < 30 ? HM_ENTROPY_BITS[cb->s[C_ONE + c] ^ bin] : 0;                   // C_ABS follows C_ONE
     HM_LVK(tLast, k) = c < 30 ? HM_ENTROPY_BITS[cb->s[(c < 15 ? C_LASTX + c : C_LASTY + c - 15) + (chroma ? 15 : 0)] ^ bin] : 0;
-    HM_LVK(tMisc, k) = c < 14 ? HM_ENTROPY_BITS[cb->s[c < 4 ? C_SIG_CG + c : C_QT_CBF + c - 4] ^ bin] : 0;
+    HM_LVK(tMisc, k) = c < 15 ? HM_ENTROPY_BITS[cb->s[c < 4 ? C_SIG_CG + c : (c < 14 ? C_QT_CBF + c - 4 : C_ROOT_CBF)] ^ bin] : 0;   // cbfCtx 10 = root cbf
     HM_LVK(tLastCost, k) = 0;
     HM_LVK(vCGSig, k) = 0;
   }
@@ -1284,7 +1348,7 @@ struct CabacR { HM_LV(int32_t, st); HM_LV(int32_t, eb0); HM_LV(int32_t, eb1); HM
 HM_DEV inline void cabr_load(CabacR &r, const Cabac *c)
 {
   HM_WAVE_FOR(k) {
-    HM_LVK(r.st, k) = k < 42 ? ((const int32_t *)c->s)[k] : 0;
+    HM_LVK(r.st, k) = k < (int)(sizeof(c->s) / 4) ? ((const int32_t *)c->s)[k] : 0;
     HM_LVK(r.eb0, k) = HM_ENTROPY_BITS[k]; HM_LVK(r.eb1, k) = HM_ENTROPY_BITS[64 + k];
     HM_LVK(r.lps, k) = ((const int32_t *)HM_NEXT_LPS)[k & 31];
   }
@@ -1292,7 +1356,7 @@ HM_DEV inline void cabr_load(CabacR &r, const Cabac *c)
 }
 HM_DEV inline void cabr_store(const CabacR &r, Cabac *c)
 {
-  HM_WAVE_FOR(k) { if (k < 42) ((int32_t *)c->s)[k] = HM_LVK(r.st, k); }
+  HM_WAVE_FOR(k) { if (k < (int)(sizeof(c->s) / 4)) ((int32_t *)c->s)[k] = HM_LVK(r.st, k); }
   c->frac = r.frac;
   HM_SYNC();
 }
@@ -1528,6 +1592,7 @@ template <class C> HM_DEV inline void enc_intra_header(Shared *e, C *c, const TU
 {
   const CtuMeta *m = (&e->meta); const int relZ = t->relZ;
   if (bLuma) {
+    if (relZ == 0 && e->im) { code_skip_flag(e, c, t->cuZ); enc_bin(e, c, C_PRED_MODE, 1); }   // P slices: skip flag + pred mode, TEncSearch.cpp:975-984
     if (relZ == 0 && t->cuDepth == 3) enc_bin(e, c, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
     if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, c, t->cuZ, 0); }
     else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ & (q - 1)) == 0) code_intra_dir_luma(e, c, t->cuZ + relZ, 0); }
@@ -1985,6 +2050,7 @@ HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDep
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); c = hm_uni_ptr(c); HM_ASSUME_LDS(c); // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
   const CtuMeta *m = (&e->meta);
+  if (e->im) { code_skip_flag(e, c, cuZ); enc_bin(e, c, C_PRED_MODE, 1); }
   if (cuDepth == 3) enc_bin(e, c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
   code_intra_dir_luma(e, c, cuZ, 1);
   code_intra_dir_chroma(e, c, cuZ);
@@ -2023,6 +2089,8 @@ HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDep
 // ------------------------------------------------------------------------------------------------
 // CU quadtree (TEncCu::xCompressCU :466-1122, xCheckRDCostIntra :1574-1646), explicit stack
 // ------------------------------------------------------------------------------------------------
+#include "hm355_inter.h"
+
 HM_DEV inline void init_est_data(Shared *e, int cuZ, int cuDepth)
 { // TComDataCU::initEstData, TComDataCU.cpp:484-552
   CtuMeta *m = (&e->meta); const int parts = 256 >> (2 * cuDepth);
@@ -2034,6 +2102,7 @@ HM_DEV inline void init_est_data(Shared *e, int cuZ, int cuDepth)
   HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = 0;
   HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = 0; e->cc[5120 + cuZ * 4 + i] = 0; }
   HM_SYNC();
+  if (e->im) init_est_data_inter(e, cuZ, cuDepth);
 }
 HM_DEV inline void meta_copy_range(CtuMeta *d, const CtuMeta *s, int z0, int parts)
 {
@@ -2049,6 +2118,7 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
   HM_PROF_BEGIN(e, PR_SAVE);
   Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
   meta_copy_range(&b->m, (&e->meta), cuZ, parts);
+  if (e->im) imeta_copy_range(&b->im, e->im, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) b->coef[cuZ * 16 + i] = e->cc[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { b->coef[4096 + cuZ * 4 + i] = e->cc[4096 + cuZ * 4 + i]; b->coef[5120 + cuZ * 4 + i] = e->cc[5120 + cuZ * 4 + i]; }
   const int r = hm_z2r(cuZ), x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
@@ -2065,6 +2135,7 @@ HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
   const Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
   meta_copy_range((&e->meta), &b->m, cuZ, parts);
+  if (e->im) imeta_copy_range(e->im, &b->im, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = b->coef[cuZ * 16 + i];
   HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = b->coef[4096 + cuZ * 4 + i]; e->cc[5120 + cuZ * 4 + i] = b->coef[5120 + cuZ * 4 + i]; }
   const int r = hm_z2r(cuZ), x = (r & 15) * 4, y = (r >> 4) * 4, n = 64 >> cuDepth, l2 = 6 - cuDepth;
@@ -2103,13 +2174,15 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
 }
 
 
+#include "hm355_inter_cu.h"
+
 // TEncCu::compressCtu -> xCompressCU recursion as a 4-level state machine
 HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 {
   HM_ENTRY(e);
   CtuMeta *m = (&e->meta);
   CuFrame *fr = e->cuf; int sp = 0;
-  fr[0].cuZ = 0; fr[0].phase = 0;
+  fr[0].cuZ = 0; fr[0].phase = 0; fr[0].parentPart = SIZE_NONE;
   double retCost = 0; uint32_t retBits = 0, retDist = 0;
   while (sp >= 0) {
     CuFrame *f = &fr[sp]; const int cuDepth = sp, cuZ = f->cuZ;
@@ -2119,7 +2192,13 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
       const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
       f->boundary = !((lx + size - 1 < e->width) && (ty + size - 1 < e->height));
       f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
-      if (!f->boundary) {
+      if (!f->boundary && e->im) { // P slice: TEncCu.cpp:628-836
+        compress_cu_inter_modes(e, cuZ, cuDepth, sp);
+        reset_bits(&e->cur);
+        if (cuDepth != 3) enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
+        f->bestBits += num_bits(&e->cur);
+        f->bestCost = calc_rd_cost(e, f->bestBits, f->bestDist);
+      } else if (!f->boundary) {
         check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N);
         double c = e->outCost; uint32_t b = e->outBits, d = e->outDist;
         if (c < f->bestCost) { f->bestCost = c; f->bestBits = b; f->bestDist = d; save_best(e, cuZ, cuDepth); cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]); }
@@ -2150,6 +2229,8 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
           if (s == 0) cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
           else cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
           fr[sp + 1].cuZ = (int16_t)subZ; fr[sp + 1].phase = 0;
+          // AMP speed-up: the part size of this depth's best mode when it is inter (rpcBestCU->isInter(0), TEncCu.cpp:1026)
+          fr[sp + 1].parentPart = (int8_t)((e->im && !f->boundary && e->ws->best[cuDepth].m.pred[cuZ] == MODE_INTER) ? e->ws->best[cuDepth].m.part[cuZ] : SIZE_NONE);
           f->phase = 2; sp++; continue;
         }
         continue;
@@ -2189,7 +2270,7 @@ HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
     if (stackNext[sp] < 0) {
       if (inside && depth != 3) enc_bin(e, c, C_SPLIT + ctx_split_flag(e, z, depth), m->depth[z] > depth);
       if (!((depth < m->depth[z] && depth < 3) || !inside)) {
-        encode_cu_syntax(e, c, z, depth);
+        if (m->pred[z] == MODE_INTER) encode_cu_syntax_inter(e, c, z, depth); else encode_cu_syntax(e, c, z, depth);
         // finishCU, TEncCu.cpp:1130-1147
         const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->height);
         if (lastX && lastY && !lastCtuOfSlice) enc_trm(e, c, 0);
@@ -2216,7 +2297,9 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   for (int c = 0; c < 3; c++) e->stride[c] = P->stride[c];
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
   e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
+  e->im = e->fb.imeta ? e->fb.imeta + e->ctuAddr : (InterMeta *)0;
   HM_SYNC();
+  if (e->im) { HM_PAR_FOR(i, 16) e->intMv[i] = e->fb.ip->integerMv2Nx2N[0][i]; HM_SYNC(); }
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   for (int i = 0; i < HM_PROF_N; i++) { e->prof[i] = 0; e->profCnt[i] = 0; }
 #endif
@@ -2230,12 +2313,14 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
       for (int c = 0; c < 3; c++) { m->cbf[c][z] = 0; m->ts[c][z] = 0; }
     }
     HM_SYNC();
+    if (e->im) init_est_data_inter(e, 0, 0);
   }
   // CABAC state hand-off (TEncSlice.cpp:733-761)
   Cabac *cb0 = &e->ws->slot[HM_SLOT(0, CI_CURR_BEST)];
-  if (a == 0) cabac_init(cb0, e->fb.qp);
+  const int initType = e->im ? e->fb.ip->cabacInitType : 2;   // context table of the slice type (TEncSbac::resetEntropy :106-115)
+  if (a == 0) cabac_init(cb0, e->fb.qp, initType);
   else if (e->ctuX == 0 && P->wpp) {
-    cabac_init(cb0, e->fb.qp);
+    cabac_init(cb0, e->fb.qp, initType);
     if (e->ctuY > 0 && P->wCtu > 1) { // contexts of the 2nd CTU of the row above, fresh bit accumulator
       const Cabac *src = e->fb.endState + ((e->ctuY - 1) * P->wCtu + 1);
       HM_PAR_FOR(i, HM_NUM_CTX) cb0->s[i] = src->s[i];
@@ -2251,6 +2336,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   reset_bits(&e->cur);
   encode_ctu(e, &e->cur, a == numCtus - 1);
   cabac_copy(e->fb.endState + a, &e->cur);
+  if (e->im) { HM_PAR_FOR(i, 16) e->fb.ip->integerMv2Nx2N[0][i] = e->intMv[i]; HM_SYNC(); }   // carried to the next CTU in coding order
   { // decision arrays back to HBM (TComDataCU::copyToPic of the whole CTU)
     const uint32_t *src = (const uint32_t *)&e->meta; uint32_t *dst = (uint32_t *)(e->fb.meta + a);
     HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];

@@ -1,0 +1,1156 @@
+// hm355 -- inter (P slice) part of the CTU search: merge / AMVP / temporal candidates, TZ integer search, fractional
+// refinement, motion compensation, inter residual quadtree and inter syntax.  Included by hm355_core.h; same execution
+// model (one wavefront per CTU, wave-uniform decisions, lane-parallel sample work).  Reference file:line as in the rest.
+#pragma once
+
+#define SIZE_2NxN 1
+#define SIZE_Nx2N 2
+#define SIZE_2NxnU 4
+#define SIZE_2NxnD 5
+#define SIZE_nLx2N 6
+#define SIZE_nRx2N 7
+#define MODE_INTER 0
+#define HM_P_SLICE 1
+
+// ------------------------------------------------------------------------------------------------
+// interpolation (TComInterpolationFilter.cpp:55-260) and motion compensation (TComPrediction.cpp:586-697)
+// ------------------------------------------------------------------------------------------------
+HM_CONST int8_t HM_LUMA_FILTER[4][8] = { {0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1} };
+HM_CONST int8_t HM_CHROMA_FILTER[8][4] = { {0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2} };
+#define HM_IF_PREC 14
+#define HM_IF_OFFS (1 << (HM_IF_PREC - 1))
+
+// one output sample of TComInterpolationFilter::filter<N, isVertical, isFirst, isLast> / filterCopy; src points at the
+// sample the filter is centred on (tap N/2-1), cs = distance between taps
+HM_DEV inline Pel if_sample(int bitDepth, const Pel *src, int cs, int frac, int chroma, int isFirst, int isLast)
+{
+  const int headRoom = (HM_IF_PREC - bitDepth) > 2 ? (HM_IF_PREC - bitDepth) : 2;
+  if (frac == 0) { // filterCopy :86-150
+    if (isFirst == isLast) return src[0];
+    if (isFirst) return (Pel)((Pel)(src[0] << headRoom) - (Pel)HM_IF_OFFS);
+    Pel v = (Pel)((src[0] + HM_IF_OFFS + (1 << (headRoom - 1))) >> headRoom);
+    const int maxv = (1 << bitDepth) - 1;
+    return v < 0 ? (Pel)0 : (v > maxv ? (Pel)maxv : v);
+  }
+  int sum = 0;
+  if (!chroma) { const Pel *p = src - 3 * cs;
+#pragma unroll
+    for (int t = 0; t < 8; t++) sum += p[t * cs] * HM_LUMA_FILTER[frac][t]; }
+  else { const Pel *p = src - cs;
+#pragma unroll
+    for (int t = 0; t < 4; t++) sum += p[t * cs] * HM_CHROMA_FILTER[frac][t]; }
+  int shift = 6, offset;
+  if (isLast) { shift += isFirst ? 0 : headRoom; offset = 1 << (shift - 1); offset += isFirst ? 0 : HM_IF_OFFS << 6; }
+  else { shift -= isFirst ? headRoom : 0; offset = isFirst ? -HM_IF_OFFS << shift : 0; }
+  Pel val = (Pel)((sum + offset) >> shift);
+  if (isLast) { const int maxv = (1 << bitDepth) - 1; val = val < 0 ? (Pel)0 : (val > maxv ? (Pel)maxv : val); }
+  return val;
+}
+// block prediction at a (possibly fractional) displacement; r = reference sample of the block's top-left at the integer
+// part of the motion vector; cw x ch samples; always two-stage when twoStage != 0 (the fractional search planes)
+HM_DEV inline void interp_block(Shared *e, int chroma, const Pel *r, int refStride, int xFrac, int yFrac, int cw, int ch, Pel *dst, int dstStride, int twoStage)
+{
+  const int bd = e->bitDepth;
+  if (!twoStage && yFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, 1, xFrac, chroma, 1, 1); } HM_SYNC(); return; }
+  if (!twoStage && xFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, refStride, yFrac, chroma, 1, 1); } HM_SYNC(); return; }
+  Pel *tmp = e->ws->mcTmp; const int half = chroma ? 1 : 3, rows = ch + (chroma ? 3 : 7);
+  HM_PAR_FOR(i, cw * rows) { const int y = i / cw, x = i - y * cw; tmp[y * 64 + x] = if_sample(bd, r + (y - half) * refStride + x, 1, xFrac, chroma, 1, 0); }
+  HM_SYNC();
+  HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, tmp + (y + half) * 64 + x, 64, yFrac, chroma, 0, 1); }
+  HM_SYNC();
+}
+HM_DEV inline MvD clip_mv(const Shared *e, MvD mv, int cuX, int cuY)
+{ // TComDataCU::clipMv, TComDataCU.cpp:2917-2932
+  const int off = 8;
+  const int horMax = (e->width + off - cuX - 1) << 2, horMin = (-64 - off - cuX + 1) << 2;
+  const int verMax = (e->height + off - cuY - 1) << 2, verMin = (-64 - off - cuY + 1) << 2;
+  int x = mv.x, y = mv.y;
+  x = x < horMin ? horMin : x; x = x > horMax ? horMax : x;
+  y = y < verMin ? verMin : y; y = y > verMax ? verMax : y;
+  MvD r; r.x = (int16_t)x; r.y = (int16_t)y;
+  return r;
+}
+// TComPrediction::xPredInterBlk :660-697 (uni-directional): (px,py) luma position in the picture, w x h luma size
+HM_DEV inline void pred_inter_blk(Shared *e, int comp, const RefPicDev *ref, int px, int py, MvD mv, int w, int h, Pel *dst, int dstStride)
+{
+  const int sh = comp ? 1 : 0, shift = 2 + sh;
+  const int refStride = ref->stride[comp];
+  const Pel *r = ref->plane[comp] + (ptrdiff_t)((py >> sh) + (mv.y >> shift)) * refStride + (px >> sh) + (mv.x >> shift);
+  interp_block(e, comp != 0, r, refStride, mv.x & ((1 << shift) - 1), mv.y & ((1 << shift) - 1), w >> sh, h >> sh, dst, dstStride, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rectangular distortion (AMP shapes): SAD with row sub-sampling, SATD by 8x8 / 4x4 blocks
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline uint32_t dist_sad_rect(const Pel *org, int so, const Pel *cur, int sc, int w, int h, int subShift, int bitDepth)
+{
+  const int rows = h >> subShift;
+  uint32_t sum = 0;
+  HM_PAR_FOR(i, rows * w) { const int yy = i / w, x = i - yy * w, y = yy << subShift; sum += (uint32_t)hm_abs(org[y * so + x] - cur[y * sc + x]); }
+  return (hm_wave_sum(sum) << subShift) >> (bitDepth - 8);
+}
+HM_DEV inline uint32_t dist_hads_rect(const Pel *org, int so, const Pel *cur, int sc, int w, int h, int bitDepth)
+{ // xGetHADs, TComRdCost.cpp:1537-1606
+  uint32_t sum = 0;
+  if ((w & 7) == 0 && (h & 7) == 0) { const int nbx = w >> 3, nb = nbx * (h >> 3); HM_PAR_FOR(b, nb) { const int by = b / nbx, bx = b - by * nbx; sum += had8(org + by * 8 * so + bx * 8, so, cur + by * 8 * sc + bx * 8, sc); } }
+  else { const int nbx = w >> 2, nb = nbx * (h >> 2); HM_PAR_FOR(b, nb) { const int by = b / nbx, bx = b - by * nbx; sum += had4(org + by * 4 * so + bx * 4, so, cur + by * 4 * sc + bx * 4, sc); } }
+  return hm_wave_sum(sum) >> (bitDepth - 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// partition geometry (TComDataCU::getPartIndexAndSize :1993)
+// ------------------------------------------------------------------------------------------------
+struct Rect { int x, y, w, h; };       // luma samples, relative to the CTU
+HM_DEV inline int num_parts_of(int partSize) { return partSize == SIZE_2Nx2N ? 1 : (partSize == SIZE_NxN ? 4 : 2); }
+HM_DEV inline Rect pu_rect(int cuZ, int cuDepth, int partSize, int partIdx)
+{
+  const int n = 64 >> cuDepth, rz = hm_z2r(cuZ);
+  Rect r; r.x = (rz & 15) * 4; r.y = (rz >> 4) * 4; r.w = n; r.h = n;
+  switch (partSize) {
+    case SIZE_2NxN:  r.h = n >> 1; if (partIdx) r.y += n >> 1; break;
+    case SIZE_Nx2N:  r.w = n >> 1; if (partIdx) r.x += n >> 1; break;
+    case SIZE_NxN:   r.w = r.h = n >> 1; r.x += (partIdx & 1) * (n >> 1); r.y += (partIdx >> 1) * (n >> 1); break;
+    case SIZE_2NxnU: if (partIdx == 0) r.h = n >> 2; else { r.y += n >> 2; r.h = (n >> 2) + (n >> 1); } break;
+    case SIZE_2NxnD: if (partIdx == 0) r.h = (n >> 2) + (n >> 1); else { r.y += (n >> 2) + (n >> 1); r.h = n >> 2; } break;
+    case SIZE_nLx2N: if (partIdx == 0) r.w = n >> 2; else { r.x += n >> 2; r.w = (n >> 2) + (n >> 1); } break;
+    case SIZE_nRx2N: if (partIdx == 0) r.w = (n >> 2) + (n >> 1); else { r.x += (n >> 2) + (n >> 1); r.w = n >> 2; } break;
+    default: break;
+  }
+  return r;
+}
+HM_DEV inline int rect_z(Rect r) { return hm_r2z((r.y >> 2) * 16 + (r.x >> 2)); }
+// lane-parallel loop over the 4x4 partitions of a PU
+#define HM_PU_FOR(r, z) HM_PAR_FOR(pi_, ((r).w >> 2) * ((r).h >> 2)) for (int z = hm_r2z((((r).y >> 2) + pi_ / ((r).w >> 2)) * 16 + ((r).x >> 2) + pi_ % ((r).w >> 2)), once_ = 1; once_; once_ = 0)
+
+HM_DEV inline void pu_set_motion(Shared *e, Rect r, int list, MvD mv, int refIdx)
+{ InterMeta *m = e->im; HM_PU_FOR(r, z) { m->mv[list][z] = mv; m->refIdx[list][z] = (int8_t)refIdx; } HM_SYNC(); }
+HM_DEV inline void pu_set_mvd(Shared *e, Rect r, int list, MvD mvd) { InterMeta *m = e->im; HM_PU_FOR(r, z) m->mvd[list][z] = mvd; HM_SYNC(); }
+HM_DEV inline void pu_set_mvp(Shared *e, Rect r, int list, int idx, int num) { InterMeta *m = e->im; HM_PU_FOR(r, z) { m->mvpIdx[list][z] = (int8_t)idx; m->mvpNum[list][z] = (int8_t)num; } HM_SYNC(); }
+HM_DEV inline void pu_set_u8(uint8_t *arr, Rect r, int v) { HM_PU_FOR(r, z) arr[z] = (uint8_t)v; HM_SYNC(); }
+
+// ------------------------------------------------------------------------------------------------
+// neighbour access (TComDataCU::getPULeft/Above/AboveLeft/AboveRight/BelowLeft, TComDataCU.cpp:1043-1290)
+// ------------------------------------------------------------------------------------------------
+enum { NB_LEFT, NB_ABOVE, NB_ABOVE_LEFT, NB_ABOVE_RIGHT, NB_BELOW_LEFT };
+// returns the raster address of the CTU holding the neighbour (or -1) and its z index
+HM_DEV inline int nb_at(const Shared *e, int x4, int y4, int dir, int curZ, int *z)
+{
+  int nx = x4, ny = y4;
+  switch (dir) {
+    case NB_LEFT: nx--; break;
+    case NB_ABOVE: ny--; break;
+    case NB_ABOVE_LEFT: nx--; ny--; break;
+    case NB_ABOVE_RIGHT: nx++; ny--; break;
+    default: nx--; ny++; break;
+  }
+  const int gx = e->ctuX * 16 + nx, gy = e->ctuY * 16 + ny;
+  if (gx < 0 || gy < 0) return -1;
+  if (gx * 4 >= e->width || gy * 4 >= e->height) return -1;
+  const int cx = gx >> 4, cy = gy >> 4;
+  if (cy > e->ctuY) return -1;
+  if (cy == e->ctuY && cx > e->ctuX) return -1;
+  if (cy < e->ctuY && cx > e->ctuX + 1) return -1;
+  *z = hm_r2z((gy & 15) * 16 + (gx & 15));
+  if (cx == e->ctuX && cy == e->ctuY && (dir == NB_ABOVE_RIGHT || dir == NB_BELOW_LEFT) && !(curZ > *z)) return -1;
+  return cy * e->wCtu + cx;
+}
+HM_DEV inline const CtuMeta *cmeta_of(const Shared *e, int ca) { return ca == e->ctuAddr ? &e->meta : e->fb.meta + ca; }
+HM_DEV inline const InterMeta *imeta_of(const Shared *e, int ca) { return e->fb.imeta + ca; }
+HM_DEV inline int nb_is_inter(const Shared *e, int ca, int z) { return cmeta_of(e, ca)->pred[z] == MODE_INTER; }
+
+// ------------------------------------------------------------------------------------------------
+// temporal candidate (xGetColMVP :3196, xGetDistScaleFactor :3290)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline int dist_scale_factor(int currPOC, int currRefPOC, int colPOC, int colRefPOC)
+{
+  const int diffD = colPOC - colRefPOC, diffB = currPOC - currRefPOC;
+  if (diffD == diffB) return 4096;
+  const int tdb = hm_clip3(-128, 127, diffB), tdd = hm_clip3(-128, 127, diffD);
+  const int x = (0x4000 + hm_abs(tdd / 2)) / tdd;
+  return hm_clip3(-4096, 4095, (tdb * x + 32) >> 6);
+}
+HM_DEV inline MvD scale_mv(MvD mv, int scale)
+{
+  MvD r;
+  r.x = (int16_t)hm_clip3(-32768, 32767, (scale * mv.x + 127 + (scale * mv.x < 0)) >> 8);
+  r.y = (int16_t)hm_clip3(-32768, 32767, (scale * mv.y + 127 + (scale * mv.y < 0)) >> 8);
+  return r;
+}
+HM_DEV inline int get_col_mvp(const Shared *e, int list, int ctuAddr, int z, MvD *out, int refIdx)
+{
+  const InterPic *s = e->fb.ip;
+  const RefPicDev *col = &s->ref[0][s->colRefIdx];              // P slice: collocated picture from list 0
+  const size_t p = (size_t)ctuAddr * 256 + z;
+  if (col->predMode[p] != MODE_INTER) return 0;
+  int colList = s->checkLDC ? list : s->colFromL0;
+  int colRefIdx = col->refIdx[colList][p];
+  if (colRefIdx < 0) { colList = 1 - colList; colRefIdx = col->refIdx[colList][p]; if (colRefIdx < 0) return 0; }
+  const int colRefPOC = col->refPoc[colList][colRefIdx];
+  const MvD colMv = col->mv[colList][p];
+  const RefPicDev *cur = &s->ref[list][refIdx];
+  const int curLT = cur->isLongTerm, colLT = col->refLT[colList][colRefIdx];
+  if (curLT != colLT) return 0;
+  if (curLT || colLT) *out = colMv;
+  else { const int scale = dist_scale_factor(s->poc, cur->poc, col->poc, colRefPOC); *out = scale == 4096 ? colMv : scale_mv(colMv, scale); }
+  return 1;
+}
+HM_DEV inline int temporal_mv(const Shared *e, Rect r, int list, int refIdx, MvD *out)
+{
+  const int rbx = (r.x + r.w - 4) >> 2, rby = (r.y + r.h - 4) >> 2;
+  int ctuAddr = -1, z = 0;
+  if ((e->ctuX * 64 + rbx * 4 + 4) < e->width && (e->ctuY * 64 + rby * 4 + 4) < e->height) {
+    if (rbx < 15 && rby < 15) { z = hm_r2z((rby + 1) * 16 + rbx + 1); ctuAddr = e->ctuAddr; }
+    else if (rbx < 15) { }
+    else if (rby < 15) { z = hm_r2z((rby + 1) * 16); ctuAddr = e->ctuAddr + 1; }
+  }
+  if (ctuAddr >= 0 && get_col_mvp(e, list, ctuAddr, z, out, refIdx)) return 1;
+  const int cx = (r.x >> 2) + ((r.w >> 2) / 2), cy = (r.y >> 2) + ((r.h >> 2) / 2);
+  return get_col_mvp(e, list, e->ctuAddr, hm_r2z(cy * 16 + cx), out, refIdx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// merge candidates (getInterMergeCandidates :2309-2662), P slice
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline int equal_motion(const Shared *e, int ca, int za, int cb, int zb)
+{ // hasEqualMotion :2278
+  const InterMeta *a = imeta_of(e, ca), *b = imeta_of(e, cb);
+  if (a->interDir[za] != b->interDir[zb]) return 0;
+  for (int l = 0; l < 2; l++)
+    if (a->interDir[za] & (1 << l))
+      if (a->mv[l][za].x != b->mv[l][zb].x || a->mv[l][za].y != b->mv[l][zb].y || a->refIdx[l][za] != b->refIdx[l][zb]) return 0;
+  return 1;
+}
+HM_DEV inline void merge_take(const Shared *e, MergeList *ml, int cnt, int ca, int z)
+{ const InterMeta *m = imeta_of(e, ca); ml->dir[cnt] = m->interDir[z]; ml->f[cnt].mv = m->mv[0][z]; ml->f[cnt].ref = m->refIdx[0][z]; }
+HM_DEV HM_NOINLINE void merge_candidates(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, MergeList *ml)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); ml = hm_uni_ptr(ml);
+  const InterPic *s = e->fb.ip; const int maxC = s->maxMergeCand;
+  const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
+  for (int i = 0; i < 5; i++) { ml->dir[i] = 0; ml->f[i].mv.x = ml->f[i].mv.y = 0; ml->f[i].ref = -1; }
+  ml->num = maxC;
+  int cnt = 0;
+  const int ltx = r.x >> 2, lty = r.y >> 2, rtx = (r.x + r.w - 4) >> 2, lbx = ltx, lby = (r.y + r.h - 4) >> 2;
+  const int zLT = hm_r2z(lty * 16 + ltx), zRT = hm_r2z(lty * 16 + rtx), zLB = hm_r2z(lby * 16 + lbx);
+  int zl = 0, za = 0, zt = 0;
+  const int cL = nb_at(e, lbx, lby, NB_LEFT, zLB, &zl);
+  const int availA1 = cL >= 0 && !(puIdx == 1 && (partSize == SIZE_Nx2N || partSize == SIZE_nLx2N || partSize == SIZE_nRx2N)) && nb_is_inter(e, cL, zl);
+  if (availA1) { merge_take(e, ml, cnt, cL, zl); cnt++; }
+  if (cnt == maxC) return;
+  const int cA = nb_at(e, rtx, lty, NB_ABOVE, zRT, &za);
+  const int availB1 = cA >= 0 && !(puIdx == 1 && (partSize == SIZE_2NxN || partSize == SIZE_2NxnU || partSize == SIZE_2NxnD)) && nb_is_inter(e, cA, za);
+  if (availB1 && (!availA1 || !equal_motion(e, cL, zl, cA, za))) { merge_take(e, ml, cnt, cA, za); cnt++; }
+  if (cnt == maxC) return;
+  int cT = nb_at(e, rtx, lty, NB_ABOVE_RIGHT, zRT, &zt);
+  const int availB0 = cT >= 0 && nb_is_inter(e, cT, zt);
+  if (availB0 && (!availB1 || !equal_motion(e, cA, za, cT, zt))) { merge_take(e, ml, cnt, cT, zt); cnt++; }
+  if (cnt == maxC) return;
+  cT = nb_at(e, lbx, lby, NB_BELOW_LEFT, zLB, &zt);
+  const int availA0 = cT >= 0 && nb_is_inter(e, cT, zt);
+  if (availA0 && (!availA1 || !equal_motion(e, cL, zl, cT, zt))) { merge_take(e, ml, cnt, cT, zt); cnt++; }
+  if (cnt == maxC) return;
+  if (cnt < 4) {
+    cT = nb_at(e, ltx, lty, NB_ABOVE_LEFT, zLT, &zt);
+    const int availB2 = cT >= 0 && nb_is_inter(e, cT, zt);
+    if (availB2 && (!availA1 || !equal_motion(e, cL, zl, cT, zt)) && (!availB1 || !equal_motion(e, cA, za, cT, zt))) { merge_take(e, ml, cnt, cT, zt); cnt++; }
+  }
+  if (cnt == maxC) return;
+  if (s->tmvp) { MvD cm; if (temporal_mv(e, r, 0, 0, &cm)) { ml->dir[cnt] = 1; ml->f[cnt].mv = cm; ml->f[cnt].ref = 0; cnt++; } }
+  if (cnt == maxC) return;
+  int arr = cnt, rr = 0, refcnt = 0;
+  const int numRef = s->numRefIdx[0];
+  while (arr < maxC) {
+    ml->dir[arr] = 1; ml->f[arr].mv.x = ml->f[arr].mv.y = 0; ml->f[arr].ref = rr;
+    arr++;
+    if (refcnt == numRef - 1) rr = 0; else { ++rr; ++refcnt; }
+  }
+  ml->num = arr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AMVP candidates (fillMvpCand :2752, xAddMVPCand :2978, xAddMVPCandOrder :3064)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline int add_mvp_cand(const Shared *e, AmvpInfo *info, int list, int refIdx, int x4, int y4, int curZ, int dir)
+{
+  const InterPic *s = e->fb.ip; int z;
+  const int ca = nb_at(e, x4, y4, dir, curZ, &z);
+  if (ca < 0) return 0;
+  const InterMeta *m = imeta_of(e, ca);
+  const int curRefPOC = s->ref[list][refIdx].poc;
+  if (m->refIdx[list][z] >= 0 && curRefPOC == s->ref[list][m->refIdx[list][z]].poc) { info->cand[info->n++] = m->mv[list][z]; return 1; }
+  const int l2 = 1 - list;
+  if (m->refIdx[l2][z] >= 0 && s->ref[l2][m->refIdx[l2][z]].poc == curRefPOC) { info->cand[info->n++] = m->mv[l2][z]; return 1; }
+  return 0;
+}
+HM_DEV inline int add_mvp_cand_order(const Shared *e, AmvpInfo *info, int list, int refIdx, int x4, int y4, int curZ, int dir)
+{
+  const InterPic *s = e->fb.ip; int z;
+  const int ca = nb_at(e, x4, y4, dir, curZ, &z);
+  if (ca < 0) return 0;
+  const InterMeta *m = imeta_of(e, ca);
+  const int curRefPOC = s->ref[list][refIdx].poc, curLT = s->ref[list][refIdx].isLongTerm;
+  for (int k = 0; k < 2; k++) {
+    const int l = k ? 1 - list : list;
+    if (m->refIdx[l][z] >= 0) {
+      const RefPicDev *nr = &s->ref[l][m->refIdx[l][z]];
+      if (curLT == nr->isLongTerm) {
+        MvD mv = m->mv[l][z];
+        if (!curLT) { const int scale = dist_scale_factor(s->poc, curRefPOC, s->poc, nr->poc); if (scale != 4096) mv = scale_mv(mv, scale); }
+        info->cand[info->n++] = mv;
+        return 1;
+      }
+    }
+  }
+  return 0;
+}
+HM_DEV HM_NOINLINE void fill_mvp_cand(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int refIdx, AmvpInfo *info)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); refIdx = HM_UNI(refIdx); info = hm_uni_ptr(info);
+  const InterPic *s = e->fb.ip; const int list = 0;
+  info->n = 0;
+  if (refIdx < 0) return;
+  const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
+  const int ltx = r.x >> 2, lty = r.y >> 2, rtx = (r.x + r.w - 4) >> 2, lbx = ltx, lby = (r.y + r.h - 4) >> 2;
+  const int zLT = hm_r2z(lty * 16 + ltx), zRT = hm_r2z(lty * 16 + rtx), zLB = hm_r2z(lby * 16 + lbx);
+  int z, added, addedSmvp;
+  int ca = nb_at(e, lbx, lby, NB_BELOW_LEFT, zLB, &z);
+  addedSmvp = ca >= 0 && nb_is_inter(e, ca, z);
+  if (!addedSmvp) { ca = nb_at(e, lbx, lby, NB_LEFT, zLB, &z); addedSmvp = ca >= 0 && nb_is_inter(e, ca, z); }
+  added = add_mvp_cand(e, info, list, refIdx, lbx, lby, zLB, NB_BELOW_LEFT);
+  if (!added) added = add_mvp_cand(e, info, list, refIdx, lbx, lby, zLB, NB_LEFT);
+  if (!added) { added = add_mvp_cand_order(e, info, list, refIdx, lbx, lby, zLB, NB_BELOW_LEFT); if (!added) add_mvp_cand_order(e, info, list, refIdx, lbx, lby, zLB, NB_LEFT); }
+  added = add_mvp_cand(e, info, list, refIdx, rtx, lty, zRT, NB_ABOVE_RIGHT);
+  if (!added) added = add_mvp_cand(e, info, list, refIdx, rtx, lty, zRT, NB_ABOVE);
+  if (!added) add_mvp_cand(e, info, list, refIdx, ltx, lty, zLT, NB_ABOVE_LEFT);
+  if (!addedSmvp) {
+    added = add_mvp_cand_order(e, info, list, refIdx, rtx, lty, zRT, NB_ABOVE_RIGHT);
+    if (!added) added = add_mvp_cand_order(e, info, list, refIdx, rtx, lty, zRT, NB_ABOVE);
+    if (!added) add_mvp_cand_order(e, info, list, refIdx, ltx, lty, zLT, NB_ABOVE_LEFT);
+  }
+  if (info->n == 2 && info->cand[0].x == info->cand[1].x && info->cand[0].y == info->cand[1].y) info->n = 1;
+  if (s->tmvp) { MvD cm; if (temporal_mv(e, r, list, refIdx, &cm)) info->cand[info->n++] = cm; }
+  if (info->n > 2) info->n = 2;
+  while (info->n < 2) { info->cand[info->n].x = info->cand[info->n].y = 0; info->n++; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// motion cost (TComRdCost.h:160-189)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline uint32_t mv_comp_bits(int val)
+{
+  uint32_t len = 1, tmp = (val <= 0) ? (uint32_t)((-val << 1) + 1) : (uint32_t)(val << 1);
+  while (tmp != 1) { tmp >>= 1; len += 2; }
+  return len;
+}
+HM_DEV inline uint32_t mc_bits(const Shared *e, int x, int y)
+{ return mv_comp_bits((x << e->costScale) - e->mvPredictor.x) + mv_comp_bits((y << e->costScale) - e->mvPredictor.y); }
+HM_DEV inline uint32_t mc_cost32(const Shared *e, uint32_t b) { return (uint32_t)(e->mcost * b) >> 16; }
+
+// ------------------------------------------------------------------------------------------------
+// integer search: TZ (xTZSearch :4027-4228, helpers :333-795)
+// ------------------------------------------------------------------------------------------------
+struct TZ {
+  const Pel *org; int orgStride, w, h;
+  const Pel *ref; int refStride;
+  uint32_t bestSad; int bestX, bestY, bestDist, bestRound, pointNr;
+  int l, r, t, b;
+  int subShift;
+};
+HM_DEV inline void tz_help(Shared *e, TZ *z, int sx, int sy, int pointNr, int dist)
+{
+  uint32_t sad = dist_sad_rect(z->org, z->orgStride, z->ref + (ptrdiff_t)sy * z->refStride + sx, z->refStride, z->w, z->h, z->subShift, e->bitDepth);
+  sad += mc_cost32(e, mc_bits(e, sx, sy));
+  if (sad < z->bestSad) { z->bestSad = sad; z->bestX = sx; z->bestY = sy; z->bestDist = dist; z->bestRound = 0; z->pointNr = pointNr; }
+}
+HM_DEV inline void tz_2point(Shared *e, TZ *z)
+{
+  const int x = z->bestX, y = z->bestY;
+  switch (z->pointNr) {
+    case 1: if (x - 1 >= z->l) tz_help(e, z, x - 1, y, 0, 2); if (y - 1 >= z->t) tz_help(e, z, x, y - 1, 0, 2); break;
+    case 2: if (y - 1 >= z->t) { if (x - 1 >= z->l) tz_help(e, z, x - 1, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, z, x + 1, y - 1, 0, 2); } break;
+    case 3: if (y - 1 >= z->t) tz_help(e, z, x, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, z, x + 1, y, 0, 2); break;
+    case 4: if (x - 1 >= z->l) { if (y + 1 <= z->b) tz_help(e, z, x - 1, y + 1, 0, 2); if (y - 1 >= z->t) tz_help(e, z, x - 1, y - 1, 0, 2); } break;
+    case 5: if (x + 1 <= z->r) { if (y - 1 >= z->t) tz_help(e, z, x + 1, y - 1, 0, 2); if (y + 1 <= z->b) tz_help(e, z, x + 1, y + 1, 0, 2); } break;
+    case 6: if (x - 1 >= z->l) tz_help(e, z, x - 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, z, x, y + 1, 0, 2); break;
+    case 7: if (y + 1 <= z->b) { if (x - 1 >= z->l) tz_help(e, z, x - 1, y + 1, 0, 2); if (x + 1 <= z->r) tz_help(e, z, x + 1, y + 1, 0, 2); } break;
+    case 8: if (x + 1 <= z->r) tz_help(e, z, x + 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, z, x, y + 1, 0, 2); break;
+    default: break;
+  }
+}
+HM_DEV inline void tz_diamond(Shared *e, TZ *z, int sx, int sy, int d)
+{
+  const int top = sy - d, bot = sy + d, lef = sx - d, rig = sx + d;
+  z->bestRound += 1;
+  if (d == 1) {
+    if (top >= z->t) tz_help(e, z, sx, top, 2, d);
+    if (lef >= z->l) tz_help(e, z, lef, sy, 4, d);
+    if (rig <= z->r) tz_help(e, z, rig, sy, 5, d);
+    if (bot <= z->b) tz_help(e, z, sx, bot, 7, d);
+  } else if (d <= 8) {
+    const int top2 = sy - (d >> 1), bot2 = sy + (d >> 1), lef2 = sx - (d >> 1), rig2 = sx + (d >> 1);
+    if (top >= z->t && lef >= z->l && rig <= z->r && bot <= z->b) {
+      tz_help(e, z, sx, top, 2, d); tz_help(e, z, lef2, top2, 1, d >> 1); tz_help(e, z, rig2, top2, 3, d >> 1); tz_help(e, z, lef, sy, 4, d);
+      tz_help(e, z, rig, sy, 5, d); tz_help(e, z, lef2, bot2, 6, d >> 1); tz_help(e, z, rig2, bot2, 8, d >> 1); tz_help(e, z, sx, bot, 7, d);
+    } else {
+      if (top >= z->t) tz_help(e, z, sx, top, 2, d);
+      if (top2 >= z->t) { if (lef2 >= z->l) tz_help(e, z, lef2, top2, 1, d >> 1); if (rig2 <= z->r) tz_help(e, z, rig2, top2, 3, d >> 1); }
+      if (lef >= z->l) tz_help(e, z, lef, sy, 4, d);
+      if (rig <= z->r) tz_help(e, z, rig, sy, 5, d);
+      if (bot2 <= z->b) { if (lef2 >= z->l) tz_help(e, z, lef2, bot2, 6, d >> 1); if (rig2 <= z->r) tz_help(e, z, rig2, bot2, 8, d >> 1); }
+      if (bot <= z->b) tz_help(e, z, sx, bot, 7, d);
+    }
+  } else {
+    if (top >= z->t && lef >= z->l && rig <= z->r && bot <= z->b) {
+      tz_help(e, z, sx, top, 0, d); tz_help(e, z, lef, sy, 0, d); tz_help(e, z, rig, sy, 0, d); tz_help(e, z, sx, bot, 0, d);
+      for (int i = 1; i < 4; i++) {
+        const int yt = top + ((d >> 2) * i), yb = bot - ((d >> 2) * i), xl = sx - ((d >> 2) * i), xr = sx + ((d >> 2) * i);
+        tz_help(e, z, xl, yt, 0, d); tz_help(e, z, xr, yt, 0, d); tz_help(e, z, xl, yb, 0, d); tz_help(e, z, xr, yb, 0, d);
+      }
+    } else {
+      if (top >= z->t) tz_help(e, z, sx, top, 0, d);
+      if (lef >= z->l) tz_help(e, z, lef, sy, 0, d);
+      if (rig <= z->r) tz_help(e, z, rig, sy, 0, d);
+      if (bot <= z->b) tz_help(e, z, sx, bot, 0, d);
+      for (int i = 1; i < 4; i++) {
+        const int yt = top + ((d >> 2) * i), yb = bot - ((d >> 2) * i), xl = sx - ((d >> 2) * i), xr = sx + ((d >> 2) * i);
+        if (yt >= z->t) { if (xl >= z->l) tz_help(e, z, xl, yt, 0, d); if (xr <= z->r) tz_help(e, z, xr, yt, 0, d); }
+        if (yb <= z->b) { if (xl >= z->l) tz_help(e, z, xl, yb, 0, d); if (xr <= z->r) tz_help(e, z, xr, yb, 0, d); }
+      }
+    }
+  }
+}
+HM_DEV inline void set_search_range(const Shared *e, MvD pred, int rng, int cuX, int cuY, MvD *lt, MvD *rb)
+{ // xSetSearchRange :3911
+  const MvD p = clip_mv(e, pred, cuX, cuY);
+  MvD a, b; a.x = (int16_t)(p.x - (rng << 2)); a.y = (int16_t)(p.y - (rng << 2)); b.x = (int16_t)(p.x + (rng << 2)); b.y = (int16_t)(p.y + (rng << 2));
+  a = clip_mv(e, a, cuX, cuY); b = clip_mv(e, b, cuX, cuY);
+  lt->x = a.x >> 2; lt->y = a.y >> 2; rb->x = b.x >> 2; rb->y = b.y >> 2;
+}
+HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, MvD lt, MvD rb, const MvD *intMv2Nx2N)
+{
+  const int searchRange = 64, raster = 5;
+  int rl = lt.x, rr = rb.x, rt = lt.y, rbm = rb.y;
+  z->l = lt.x; z->r = rb.x; z->t = lt.y; z->b = rb.y;
+  MvD c = clip_mv(e, *mv, cuX, cuY); c.x >>= 2; c.y >>= 2;
+  z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0;
+  tz_help(e, z, c.x, c.y, 0, 0);
+  tz_help(e, z, 0, 0, 0, 0);
+  if (intMv2Nx2N) {
+    MvD im; im.x = (int16_t)(intMv2Nx2N->x << 2); im.y = (int16_t)(intMv2Nx2N->y << 2);
+    im = clip_mv(e, im, cuX, cuY); im.x >>= 2; im.y >>= 2;
+    tz_help(e, z, im.x, im.y, 0, 0);
+    MvD nb, nlt, nrb; nb.x = (int16_t)(z->bestX << 2); nb.y = (int16_t)(z->bestY << 2);
+    set_search_range(e, nb, searchRange, cuX, cuY, &nlt, &nrb);
+    rl = nlt.x; rr = nrb.x; rt = nlt.y; rbm = nrb.y;
+  }
+  int sx = z->bestX, sy = z->bestY, d;
+  for (d = 1; d <= searchRange; d *= 2) { tz_diamond(e, z, sx, sy, d); if (z->bestRound >= 3) break; }
+  if (z->bestDist == 1) { z->bestDist = 0; tz_2point(e, z); }
+  if (z->bestDist > raster) {
+    z->bestDist = raster;
+    for (sy = rt; sy <= rbm; sy += raster) for (sx = rl; sx <= rr; sx += raster) tz_help(e, z, sx, sy, 0, raster);
+  }
+  while (z->bestDist > 0) {
+    sx = z->bestX; sy = z->bestY;
+    z->bestDist = 0; z->pointNr = 0;
+    for (d = 1; d < searchRange + 1; d *= 2) tz_diamond(e, z, sx, sy, d);
+    if (z->bestDist == 1) { z->bestDist = 0; if (z->pointNr != 0) tz_2point(e, z); }
+  }
+  mv->x = (int16_t)z->bestX; mv->y = (int16_t)z->bestY;
+  return z->bestSad - mc_cost32(e, mc_bits(e, z->bestX, z->bestY));
+}
+
+// ------------------------------------------------------------------------------------------------
+// fractional refinement (xPatternSearchFracDIF :4386, xPatternRefinement :799): the candidate block at a quarter-sample
+// displacement is the two-stage interpolation of the reference, compared with SATD (HadamardME)
+// ------------------------------------------------------------------------------------------------
+HM_CONST int8_t HM_MV_REFINE_H[9][2] = { {0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1} };
+HM_CONST int8_t HM_MV_REFINE_Q[9][2] = { {0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1} };
+HM_DEV inline uint32_t pattern_refinement(Shared *e, TZ *z, const Pel *refAtInt, MvD base, int frac, MvD *mvFrac)
+{
+  uint32_t best = 0xffffffffu; int bestDir = 0;
+  Pel *blk = e->ws->mcBlk;
+  for (int i = 0; i < 9; i++) {
+    const int tx = frac == 2 ? HM_MV_REFINE_H[i][0] : HM_MV_REFINE_Q[i][0], ty = frac == 2 ? HM_MV_REFINE_H[i][1] : HM_MV_REFINE_Q[i][1];
+    const int hx = (tx + base.x) * frac, vy = (ty + base.y) * frac;
+    interp_block(e, 0, refAtInt + (ptrdiff_t)(vy >> 2) * z->refStride + (hx >> 2), z->refStride, hx & 3, vy & 3, z->w, z->h, blk, 64, 1);
+    uint32_t d = dist_hads_rect(z->org, z->orgStride, blk, 64, z->w, z->h, e->bitDepth);
+    d += mc_cost32(e, mc_bits(e, tx + mvFrac->x, ty + mvFrac->y));
+    if (d < best) { best = d; bestDir = i; }
+  }
+  mvFrac->x = frac == 2 ? HM_MV_REFINE_H[bestDir][0] : HM_MV_REFINE_Q[bestDir][0];
+  mvFrac->y = frac == 2 ? HM_MV_REFINE_H[bestDir][1] : HM_MV_REFINE_Q[bestDir][1];
+  return best;
+}
+
+// xMotionEstimation :3816-3906 (uni-directional, list 0); results in e->outMv / e->outBits / e->outDist(cost)
+HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int predX, int predY, int refIdx, uint32_t bitsIn)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); predX = HM_UNI(predX); predY = HM_UNI(predY); refIdx = HM_UNI(refIdx); bitsIn = HM_UCALL(bitsIn);
+  InterPic *s = e->fb.ip;
+  const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
+  const int rz = hm_z2r(cuZ), cuX = e->ctuX * 64 + (rz & 15) * 4, cuY = e->ctuY * 64 + (rz >> 4) * 4;
+  const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
+  const RefPicDev *ref = &s->ref[0][refIdx];
+  MvD mvPred; mvPred.x = (int16_t)predX; mvPred.y = (int16_t)predY;
+  TZ z;
+  z.org = e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px; z.orgStride = e->stride[0]; z.w = r.w; z.h = r.h;
+  z.ref = ref->plane[0] + (ptrdiff_t)py * ref->stride[0] + px; z.refStride = ref->stride[0];
+  z.subShift = r.h > 8 ? 1 : 0;
+  MvD lt, rb;
+  set_search_range(e, mvPred, 64, cuX, cuY, &lt, &rb);
+  e->mcost = s->lambdaMotionSAD; e->mvPredictor = mvPred; e->costScale = 2;
+  MvD mv = mvPred;
+  const int useInt = (partSize != SIZE_2Nx2N || cuDepth != 0);
+  MvD im = e->intMv[refIdx];
+  uint32_t c = tz_search(e, &z, &mv, cuX, cuY, lt, rb, useInt ? &im : (const MvD *)0);
+  if (partSize == SIZE_2Nx2N) e->intMv[refIdx] = mv;
+  e->costScale = 1;
+  const Pel *refAtInt = z.ref + (ptrdiff_t)mv.y * z.refStride + mv.x;
+  MvD half, base, qter; half.x = (int16_t)(mv.x << 1); half.y = (int16_t)(mv.y << 1); base.x = base.y = 0;
+  c = pattern_refinement(e, &z, refAtInt, base, 2, &half);
+  e->costScale = 0;
+  base.x = (int16_t)(half.x << 1); base.y = (int16_t)(half.y << 1);
+  qter.x = (int16_t)(((mv.x << 1) + half.x) << 1); qter.y = (int16_t)(((mv.y << 1) + half.y) << 1);
+  c = pattern_refinement(e, &z, refAtInt, base, 1, &qter);
+  mv.x = (int16_t)((mv.x << 2) + (half.x << 1) + qter.x); mv.y = (int16_t)((mv.y << 2) + (half.y << 1) + qter.y);
+  const uint32_t mvBits = mc_bits(e, mv.x, mv.y);
+  const uint32_t bits = bitsIn + mvBits;
+  e->outMv = mv; e->outBits = bits;
+  e->outDist = (uint32_t)(floor(1.0 * ((double)c - (double)mc_cost32(e, mvBits))) + (double)mc_cost32(e, bits));
+}
+
+// TComPrediction::motionCompensation of one PU (P slice: list 0) into a CTU-relative scratch picture
+HM_DEV inline void motion_compensation_pu(Shared *e, int cuZ, Rect r, Pel *dst)
+{
+  const InterPic *s = e->fb.ip; const InterMeta *m = e->im;
+  const int z = rect_z(r), rz = hm_z2r(cuZ), cuX = e->ctuX * 64 + (rz & 15) * 4, cuY = e->ctuY * 64 + (rz >> 4) * 4;
+  const int refIdx = m->refIdx[0][z];
+  const MvD mv = clip_mv(e, m->mv[0][z], cuX, cuY);
+  for (int c = 0; c < 3; c++) {
+    const int st = HM_PLANE_STRIDE(c), sh = c ? 1 : 0;
+    pred_inter_blk(e, c, &s->ref[0][refIdx], e->ctuX * 64 + r.x, e->ctuY * 64 + r.y, mv, r.w, r.h, dst + HM_PLANE_OFF(c) + (r.y >> sh) * st + (r.x >> sh), st);
+  }
+}
+
+// AMVP predictor choice (xEstimateMvPredAMVP :3571, xGetTemplateCost :3771, xCheckBestMVP :3725)
+HM_DEV inline uint32_t template_cost(Shared *e, int cuZ, Rect r, MvD cand, int refIdx)
+{
+  const InterPic *s = e->fb.ip;
+  const int rz = hm_z2r(cuZ), cuX = e->ctuX * 64 + (rz & 15) * 4, cuY = e->ctuY * 64 + (rz >> 4) * 4;
+  const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
+  Pel *blk = e->ws->mcBlk;
+  pred_inter_blk(e, 0, &s->ref[0][refIdx], px, py, clip_mv(e, cand, cuX, cuY), r.w, r.h, blk, 64);
+  const uint32_t sad = dist_sad_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], blk, 64, r.w, r.h, 0, e->bitDepth);
+  const double t = floor(((double)1 * (double)s->lambdaMotionSAD) + 0.5) / 65536.0;
+  return (uint32_t)floor((double)sad + t);
+}
+HM_DEV inline MvD estimate_mvp_amvp(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int refIdx, AmvpInfo *info, int *bestIdx)
+{
+  const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
+  fill_mvp_cand(e, cuZ, cuDepth, partSize, puIdx, refIdx, info);
+  *bestIdx = 0;
+  MvD best = info->cand[0];
+  if (info->n > 1) {
+    uint32_t bestCost = 0xffffffffu;
+    for (int i = 0; i < info->n; i++) {
+      const uint32_t c = template_cost(e, cuZ, r, info->cand[i], refIdx);
+      if (bestCost > c) { bestCost = c; best = info->cand[i]; *bestIdx = i; }
+    }
+  }
+  pu_set_mvp(e, r, 0, *bestIdx, info->n);
+  return best;
+}
+HM_DEV inline void check_best_mvp(Shared *e, const AmvpInfo *info, MvD mv, MvD *mvPred, int *mvpIdx, uint32_t *bits, uint32_t *cost)
+{
+  if (info->n < 2) return;
+  e->mcost = e->fb.ip->lambdaMotionSAD; e->costScale = 0;
+  int bestIdx = *mvpIdx;
+  e->mvPredictor = *mvPred;
+  const int orgBits = (int)mc_bits(e, mv.x, mv.y) + 1;
+  int bestBits = orgBits;
+  for (int i = 0; i < info->n; i++) {
+    if (i == *mvpIdx) continue;
+    e->mvPredictor = info->cand[i];
+    const int b = (int)mc_bits(e, mv.x, mv.y) + 1;
+    if (b < bestBits) { bestBits = b; bestIdx = i; }
+  }
+  if (bestIdx != *mvpIdx) {
+    *mvPred = info->cand[bestIdx]; *mvpIdx = bestIdx;
+    const uint32_t org = *bits;
+    *bits = org - orgBits + bestBits;
+    *cost = (*cost - mc_cost32(e, org)) + mc_cost32(e, *bits);
+  }
+}
+
+// xMergeEstimation :2987 (+ xGetInterPredictionError :2952); result in e->mrg*
+HM_DEV HM_NOINLINE void merge_estimation(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx);
+  const InterPic *s = e->fb.ip;
+  const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
+  MergeList *ml = &e->ml;
+  merge_candidates(e, cuZ, cuDepth, partSize, puIdx, ml);
+  // xRestrictBipredMergeCand: no bi-predictive candidates in a P slice
+  uint32_t cost = 0xffffffffu;
+  const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
+  MvD zero; zero.x = zero.y = 0;
+  for (int c = 0; c < ml->num; c++) {
+    pu_set_motion(e, r, 0, ml->f[c].mv, ml->f[c].ref);
+    pu_set_motion(e, r, 1, zero, -1);
+    motion_compensation_pu(e, cuZ, r, e->ws->tmpPred);
+    uint32_t d = dist_hads_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], e->ws->tmpPred + r.y * 64 + r.x, 64, r.w, r.h, e->bitDepth);
+    uint32_t b = (uint32_t)c + 1;
+    if (c == s->maxMergeCand - 1) b--;
+    d += mc_cost32(e, b);
+    if (d < cost) { cost = d; e->mrgField = ml->f[c]; e->mrgDir = ml->dir[c]; e->mrgIdx = c; }
+  }
+  e->mrgCost = cost;
+}
+
+// TEncSearch::predInterSearch :3075-3567, P slice
+HM_DEV HM_NOINLINE void pred_inter_search(Shared *e, int cuZ, int cuDepth, int partSize, int useMRG)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); useMRG = HM_UNI(useMRG);
+  const InterPic *s = e->fb.ip; InterMeta *m = e->im;
+  const int numPart = num_parts_of(partSize), cuW = 64 >> cuDepth;
+  MvD zero; zero.x = zero.y = 0;
+  for (int puIdx = 0; puIdx < numPart; puIdx++) {
+    const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
+    uint32_t costL0 = 0xffffffffu, bitsL0 = 0;
+    MvD mvL0 = zero, predL0 = zero; int refL0 = 0, mvpIdxL0 = 0, mvpNumL0 = 0;
+    const uint32_t mbBits = (partSize == SIZE_2Nx2N || partSize == SIZE_NxN) ? 1 : 3;
+    const int testNormalMC = !(useMRG && cuW > 8 && numPart == 2);
+    if (testNormalMC) {
+      for (int refIdx = 0; refIdx < s->numRefIdx[0]; refIdx++) {
+        uint32_t bitsTemp = mbBits, costTemp;
+        if (s->numRefIdx[0] > 1) { bitsTemp += refIdx + 1; if (refIdx == s->numRefIdx[0] - 1) bitsTemp--; }
+        AmvpInfo *info = &e->amvp; int mvpIdx;
+        MvD mvPred = estimate_mvp_amvp(e, cuZ, cuDepth, partSize, puIdx, refIdx, info, &mvpIdx);
+        const int mvpNum = info->n;
+        bitsTemp += 1;
+        motion_estimation(e, cuZ, cuDepth, partSize, puIdx, mvPred.x, mvPred.y, refIdx, bitsTemp);
+        const MvD mvTemp = e->outMv; bitsTemp = e->outBits; costTemp = e->outDist;
+        check_best_mvp(e, info, mvTemp, &mvPred, &mvpIdx, &bitsTemp, &costTemp);
+        if (costTemp < costL0) { costL0 = costTemp; bitsL0 = bitsTemp; mvL0 = mvTemp; refL0 = refIdx; predL0 = mvPred; mvpIdxL0 = mvpIdx; mvpNumL0 = mvpNum; }
+      }
+    }
+    pu_set_motion(e, r, 0, zero, -1); pu_set_motion(e, r, 1, zero, -1);
+    pu_set_mvd(e, r, 0, zero); pu_set_mvd(e, r, 1, zero);
+    pu_set_mvp(e, r, 0, -1, -1); pu_set_mvp(e, r, 1, -1, -1);
+    uint32_t meBits = 0;
+    if (testNormalMC) {
+      pu_set_motion(e, r, 0, mvL0, refL0);
+      MvD mvd; mvd.x = (int16_t)(mvL0.x - predL0.x); mvd.y = (int16_t)(mvL0.y - predL0.y);
+      pu_set_mvd(e, r, 0, mvd);
+      pu_set_u8(m->interDir, r, 1);
+      pu_set_mvp(e, r, 0, mvpIdxL0, mvpNumL0);
+      meBits = bitsL0;
+    }
+    if (partSize != SIZE_2Nx2N) {
+      e->mcost = s->lambdaMotionSAD;
+      uint32_t meCost = 0xffffffffu;
+      if (testNormalMC) {
+        motion_compensation_pu(e, cuZ, r, e->ws->tmpPred);
+        const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
+        const uint32_t err = dist_hads_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], e->ws->tmpPred + r.y * 64 + r.x, 64, r.w, r.h, e->bitDepth);
+        meCost = err + mc_cost32(e, meBits);
+      }
+      const int z0 = rect_z(r);
+      const int meDir = m->interDir[z0];
+      const MvD meMv = m->mv[0][z0]; const int meRef = m->refIdx[0][z0];
+      merge_estimation(e, cuZ, cuDepth, partSize, puIdx);
+      if (e->mrgCost < meCost) {
+        pu_set_u8(m->mrg, r, 1); pu_set_u8(m->mrgIdx, r, e->mrgIdx); pu_set_u8(m->interDir, r, e->mrgDir);
+        pu_set_motion(e, r, 0, e->mrgField.mv, e->mrgField.ref); pu_set_motion(e, r, 1, zero, -1);
+        pu_set_mvd(e, r, 0, zero); pu_set_mvd(e, r, 1, zero);
+        pu_set_mvp(e, r, 0, -1, -1); pu_set_mvp(e, r, 1, -1, -1);
+      } else {
+        pu_set_u8(m->mrg, r, 0); pu_set_u8(m->interDir, r, meDir);
+        pu_set_motion(e, r, 0, meMv, meRef); pu_set_motion(e, r, 1, zero, -1);
+      }
+    }
+    motion_compensation_pu(e, cuZ, r, e->ws->pred);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inter syntax on the estimator (TEncSbac.cpp:423-640,721-800; TEncEntropy.cpp:440-700)
+// ------------------------------------------------------------------------------------------------
+template <class C> HM_DEV inline void code_skip_flag(Shared *e, C *c, int z)
+{ // codeSkipFlag :524, getCtxSkipFlag TComDataCU.cpp:1645
+  int zz, ctx = 0;
+  const int rz = hm_z2r(z), x4 = rz & 15, y4 = rz >> 4;
+  int ca = nb_at(e, x4, y4, NB_LEFT, z, &zz); ctx = ca >= 0 ? imeta_of(e, ca)->skip[zz] : 0;
+  ca = nb_at(e, x4, y4, NB_ABOVE, z, &zz); ctx += ca >= 0 ? imeta_of(e, ca)->skip[zz] : 0;
+  enc_bin(e, c, C_SKIP + ctx, e->im->skip[z] ? 1 : 0);
+}
+HM_DEV inline void code_merge_index(Shared *e, Cabac *c, int z)
+{ // codeMergeIndex :555
+  const int idx = e->im->mrgIdx[z], num = e->fb.ip->maxMergeCand;
+  if (num > 1)
+    for (int ui = 0; ui < num - 1; ui++) {
+      const int sym = ui == idx ? 0 : 1;
+      if (ui == 0) enc_bin(e, c, C_MRG_IDX, sym); else enc_ep(c, 1);
+      if (sym == 0) break;
+    }
+}
+HM_DEV inline void code_part_size_inter(Shared *e, Cabac *c, int z, int depth)
+{ // codePartSize :431-520, inter branch; AMP below the maximum depth
+  const int size = e->meta.part[z], amp = depth < 3;
+  switch (size) {
+    case SIZE_2Nx2N: enc_bin(e, c, C_PART, 1); break;
+    case SIZE_2NxN: case SIZE_2NxnU: case SIZE_2NxnD:
+      enc_bin(e, c, C_PART, 0); enc_bin(e, c, C_PART + 1, 1);
+      if (amp) { if (size == SIZE_2NxN) enc_bin(e, c, C_PART + 3, 1); else { enc_bin(e, c, C_PART + 3, 0); enc_ep(c, 1); } }
+      break;
+    case SIZE_Nx2N: case SIZE_nLx2N: case SIZE_nRx2N:
+      enc_bin(e, c, C_PART, 0); enc_bin(e, c, C_PART + 1, 0);
+      if (amp) { if (size == SIZE_Nx2N) enc_bin(e, c, C_PART + 3, 1); else { enc_bin(e, c, C_PART + 3, 0); enc_ep(c, 1); } }
+      break;
+    default: break;
+  }
+}
+HM_DEV inline void write_ep_ex_golomb(Cabac *c, uint32_t symbol, uint32_t count)
+{ // xWriteEpExGolomb :270-290: only the number of bypass bins matters to the estimator
+  uint32_t numBins = 0;
+  while (symbol >= (1u << count)) { numBins++; symbol -= 1u << count; count++; }
+  numBins++; numBins += count;
+  enc_ep(c, (int)numBins);
+}
+HM_DEV inline void code_mvd(Shared *e, Cabac *c, int z, int list)
+{ // codeMvd :757
+  const int hor = e->im->mvd[list][z].x, ver = e->im->mvd[list][z].y;
+  enc_bin(e, c, C_MVD, hor != 0); enc_bin(e, c, C_MVD, ver != 0);
+  const uint32_t ha = (uint32_t)hm_abs(hor), va = (uint32_t)hm_abs(ver);
+  if (hor != 0) enc_bin(e, c, C_MVD + 1, ha > 1);
+  if (ver != 0) enc_bin(e, c, C_MVD + 1, va > 1);
+  if (hor != 0) { if (ha > 1) write_ep_ex_golomb(c, ha - 2, 1); enc_ep(c, 1); }
+  if (ver != 0) { if (va > 1) write_ep_ex_golomb(c, va - 2, 1); enc_ep(c, 1); }
+}
+HM_DEV inline void code_ref_idx(Shared *e, Cabac *c, int z, int list)
+{ // codeRefFrmIdx :737
+  int ref = e->im->refIdx[list][z];
+  enc_bin(e, c, C_REF, ref == 0 ? 0 : 1);
+  if (ref > 0) {
+    const int num = e->fb.ip->numRefIdx[list] - 2;
+    ref--;
+    for (int ui = 0; ui < num; ui++) {
+      const int sym = ui == ref ? 0 : 1;
+      if (ui == 0) enc_bin(e, c, C_REF + 1, sym); else enc_ep(c, 1);
+      if (sym == 0) break;
+    }
+  }
+}
+HM_DEV inline void code_pu_wise(Shared *e, Cabac *c, int cuZ, int cuDepth)
+{ // TEncEntropy::encodePUWise :477 (P slice: no inter_pred_idc)
+  const InterMeta *m = e->im; const int partSize = e->meta.part[cuZ], np = num_parts_of(partSize);
+  for (int p = 0; p < np; p++) {
+    const int z = rect_z(pu_rect(cuZ, cuDepth, partSize, p));
+    enc_bin(e, c, C_MRG_FLAG, m->mrg[z] ? 1 : 0);
+    if (m->mrg[z]) code_merge_index(e, c, z);
+    else {
+      for (int l = 0; l < 2; l++) {
+        if (e->fb.ip->numRefIdx[l] > 0) {
+          if (e->fb.ip->numRefIdx[l] > 1 && (m->interDir[z] & (1 << l))) code_ref_idx(e, c, z, l);
+          if (m->interDir[z] & (1 << l)) { code_mvd(e, c, z, l); enc_bin(e, c, C_MVP_IDX, m->mvpIdx[l][z]); }
+        }
+      }
+    }
+  }
+}
+HM_DEV inline int qt_root_cbf(const CtuMeta *m, int z) { return (m->cbf[0][z] & 1) || (m->cbf[1][z] & 1) || (m->cbf[2][z] & 1); }
+
+// TEncEntropy::xEncodeTransform :222-412 for an inter CU (coefficients from the CTU arrays)
+HM_DEV inline void encode_transform_inter(Shared *e, Cabac *c, const TU *root)
+{
+  const CtuMeta *m = &e->meta;
+  TuWalk &w = e->walkOuter; walk_begin(&w, root);
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ;
+    const int subdiv = m->tr[z] > t->trDepth;
+    if (w.next[w.sp] < 0) {
+      if (t->log2 > 5) { }
+      else if (t->log2 == 2) { }
+      else if (t->log2 == tr_min_size_in_cu(6 - t->cuDepth, 0)) { }
+      else enc_bin(e, c, C_SUBDIV + (5 - t->log2), subdiv);
+      const int first = t->trDepth == 0;
+      for (int comp = 1; comp < 3; comp++)
+        if (first || t->cCodeAll)
+          if (first || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)) code_qt_cbf(e, c, t, comp, subdiv == 0);
+      if (!subdiv) {
+        if (!(first && !(m->cbf[1][z] & 1) && !(m->cbf[2][z] & 1))) code_qt_cbf(e, c, t, 0, 1);
+        for (int comp = 0; comp < 3; comp++) {
+          if (comp && !t->cW) continue;
+          if (!((m->cbf[comp][z] >> t->trDepth) & 1)) continue;
+          const int n = comp ? t->cW : (1 << t->log2);
+          const int zc = t->cuZ + (comp ? t->cRelZ : t->relZ);
+          const TCoeff *coef = e->cc + HM_PLANE_OFF(comp) + (comp ? t->cOff : z * 16);
+          code_coeff_nxn(e, c, coef, n, comp, SCAN_DIAG, m->ts[comp][zc]);
+        }
+        w.sp--; continue;
+      }
+      w.next[w.sp] = 0;
+    }
+    if (w.next[w.sp] == 4) { w.sp--; continue; }
+    const int s = w.next[w.sp]++;
+    w.node[w.sp + 1] = tu_child(t, s, 1); w.next[w.sp + 1] = -1; w.sp++;
+  }
+}
+// the whole inter CU: xAddSymbolBitsInter :5517 and xEncodeCU :1246-1290
+HM_DEV HM_NOINLINE void encode_cu_syntax_inter(Shared *e, Cabac *c, int cuZ, int cuDepth)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); c = hm_uni_ptr(c); HM_ASSUME_LDS(c);
+  const CtuMeta *m = &e->meta; const InterMeta *im = e->im;
+  code_skip_flag(e, c, cuZ);
+  if (im->skip[cuZ]) { code_merge_index(e, c, cuZ); return; }
+  enc_bin(e, c, C_PRED_MODE, 0);
+  code_part_size_inter(e, c, cuZ, cuDepth);
+  code_pu_wise(e, c, cuZ, cuDepth);
+  if (!(im->mrg[cuZ] && m->part[cuZ] == SIZE_2Nx2N)) enc_bin(e, c, C_ROOT_CBF, qt_root_cbf(m, cuZ));
+  if (!qt_root_cbf(m, cuZ)) return;
+  const TU root = tu_root(e, cuZ, cuDepth);
+  encode_transform_inter(e, c, &root);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inter residual quadtree (xEstimateResidualQT :4680-5306, xEncodeResidualQT :5308, xSetResidualQTData :5391)
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline void encode_residual_qt(Shared *e, const TU *root, int comp /* 3 = flags pass */)
+{
+  const CtuMeta *m = &e->meta;
+  TuWalk &w = e->walkInner; walk_begin(&w, root);
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ, trMode = m->tr[z], subdiv = t->trDepth != trMode;
+    if (w.next[w.sp] < 0) {
+      if (comp == 3) {
+        if (t->log2 <= 5 && t->log2 > tr_min_size_in_cu(6 - t->cuDepth, 0)) enc_bin(e, &e->cur, C_SUBDIV + (5 - t->log2), subdiv);
+        const int first = t->trDepth == 0;
+        for (int ch = 1; ch < 3; ch++)
+          if (first || t->cCodeAll)
+            if (first || ((m->cbf[ch][z] >> (t->trDepth - 1)) & 1)) code_qt_cbf(e, &e->cur, t, ch, !subdiv);
+        if (!subdiv) code_qt_cbf(e, &e->cur, t, 0, 1);
+      }
+      if (!subdiv) {
+        if (comp != 3 && !(comp && !t->cW)) {
+          const int zc = t->cuZ + (comp ? t->cRelZ : t->relZ);
+          if ((m->cbf[comp][z] >> trMode) & 1) {
+            const int n = comp ? t->cW : (1 << t->log2);
+            const TCoeff *coef = e->ws->qtCoef[5 - t->log2] + HM_PLANE_OFF(comp) + (comp ? t->cOff : z * 16);
+            code_coeff_nxn(e, &e->cur, coef, n, comp, SCAN_DIAG, m->ts[comp][zc]);
+          }
+        }
+        w.sp--; continue;
+      }
+      if (!(comp == 3 || ((m->cbf[comp][z] >> t->trDepth) & 1))) { w.sp--; continue; }
+      w.next[w.sp] = 0;
+    }
+    if (w.next[w.sp] == 4) { w.sp--; continue; }
+    const int s = w.next[w.sp]++;
+    w.node[w.sp + 1] = tu_child(t, s, 0); w.next[w.sp + 1] = -1; w.sp++;
+  }
+}
+HM_DEV inline void set_residual_qt_data(Shared *e, const TU *root, int spatial)
+{
+  const CtuMeta *m = &e->meta;
+  TuWalk &w = e->walkInner; walk_begin(&w, root);
+  while (w.sp >= 0) {
+    TU *t = &w.node[w.sp];
+    const int z = t->cuZ + t->relZ;
+    if (w.next[w.sp] < 0) {
+      if (t->trDepth == m->tr[z]) {
+        const int layer = 5 - t->log2;
+        for (int comp = 0; comp < 3; comp++) {
+          if (comp && !t->cW) continue;
+          const int n = comp ? t->cW : (1 << t->log2), l2 = hm_log2(n), st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp), bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
+          if (spatial) { HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); e->ws->resiBest[po + (by + y) * st + bx + x] = e->ws->qtRec[layer][po + (by + y) * st + bx + x]; } }
+          else { const int off = po + (comp ? t->cOff : z * 16); HM_PAR_FOR(i, n * n) e->cc[off + i] = e->ws->qtCoef[layer][off + i]; }
+        }
+        HM_SYNC();
+        w.sp--; continue;
+      }
+      w.next[w.sp] = 0;
+    }
+    if (w.next[w.sp] == 4) { w.sp--; continue; }
+    const int s = w.next[w.sp]++;
+    w.node[w.sp + 1] = tu_child(t, s, 0); w.next[w.sp + 1] = -1; w.sp++;
+  }
+}
+
+// full (unsplit) evaluation of one TU: every component, transform-skip trial for 4x4 blocks (:4725-5106)
+HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
+{
+  HM_ENTRY(e); sp = HM_UNI(sp);
+  IrqFrame *f = &e->irq[sp]; const TU *t = &f->t;
+  CtuMeta *m = &e->meta; WorkSpace *ws = e->ws;
+  const int z = t->cuZ + t->relZ, fullDepth = t->cuDepth + t->trDepth, trMode = t->trDepth, layer = 5 - t->log2;
+  const int minLog2 = tr_min_size_in_cu(6 - t->cuDepth, 0), bd = e->bitDepth;
+  uint32_t singleDist = 0;
+  par_set8(m->tr + z, trMode, t->parts);
+  for (int comp = 0; comp < 3; comp++) {
+    f->absSum[comp] = 0; f->bestTS[comp] = 0;
+    if (comp && !t->cW) continue;
+    const int n = comp ? t->cW : (1 << t->log2), l2 = hm_log2(n), st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp);
+    const int zc = t->cuZ + (comp ? t->cRelZ : t->relZ), parts = comp ? t->cParts : t->parts;
+    const int bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
+    const Pel *resi = ws->resi + po + by * st + bx;
+    Pel *rq = ws->qtRec[layer] + po + by * st + bx;
+    TCoeff *coef = ws->qtCoef[layer] + po + (comp ? t->cOff : z * 16);
+    const int cbfCtx = comp ? 5 + t->trDepth : (t->trDepth == 0 ? 10 : 0);      // 10: the root-cbf slot of rdoq's table (:2301)
+    const int nModes = (n == 4) ? 2 : 1, tshift = 15 - bd - l2;
+    double minCost = HM_MAX_DOUBLE; uint32_t compDist = 0;
+    for (int tsMode = 0; tsMode < nModes; tsMode++) {
+      const int isFirst = tsMode == 0, isOne = nModes == 1;
+      par_set8(m->ts[comp] + zc, tsMode, parts);
+      cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+      reset_bits(&e->cur);
+      uint32_t currBits = 0, currDist = 0, nonCoeffBits = 0, nonCoeffDist = 0; double currCost = 0, nonCoeffCost = 0;
+      if (!isOne && !isFirst) { HM_PAR_FOR(i, 16) { e->tsCoef[comp][i] = coef[i]; e->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; } HM_SYNC(); }
+      HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int r = resi[y * st + x]; e->bufA[y * HM_TSTRIDE + x] = tsMode ? (r << tshift) : r; }
+      HM_SYNC();
+      if (!tsMode) fwd_transform(e, n, 0, bd);
+      int absSum = (int)HM_UCALL(rdoq(e, coef, n, comp, SCAN_DIAG, cbfCtx));
+      par_set8(m->cbf[comp] + zc, (absSum > 0 ? 1 : 0) << trMode, parts);
+      if (isFirst || absSum == 0) {
+        const int shiftSse = (bd - 8) << 1; uint32_t sq = 0;
+        HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int d = resi[y * st + x]; sq += (uint32_t)((d * d) >> shiftSse); }
+        uint32_t d = hm_wave_sum(sq);
+        if (comp) d = (uint32_t)(e->fb.chromaWeight * (double)d);
+        nonCoeffDist = d;
+        enc_bin(e, &e->cur, C_QT_CBF + (comp ? 5 : 0) + (comp ? t->trDepth : (t->trDepth == 0 ? 1 : 0)), 0);
+        nonCoeffBits = num_bits(&e->cur);
+        nonCoeffCost = calc_rd_cost(e, nonCoeffBits, nonCoeffDist);
+      }
+      if (f->zero && isFirst) e->irqZeroDist += nonCoeffDist;
+      if (absSum > 0) {
+        if (isFirst) { cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); reset_bits(&e->cur); }
+        code_qt_cbf(e, &e->cur, t, comp, 1);
+        code_coeff_nxn(e, &e->cur, coef, n, comp, SCAN_DIAG, tsMode);
+        currBits = num_bits(&e->cur);
+        { // xDeQuant + inverse transform (:1423-1545)
+          const int rightShift = 6 - (tshift + e->fb.qpPer[comp != 0]);
+          const int scale = HM_INV_QUANT_SCALES[e->fb.qpRem[comp != 0]];
+          int tgt = 25 + rightShift; if (tgt > 16) tgt = 16;
+          const int imin = -(1 << (tgt - 1)), imax = (1 << (tgt - 1)) - 1;
+          HM_PAR_FOR(i, n * n) {
+            const int y = i >> l2, x = i & (n - 1);
+            const int cq = hm_clip3(imin, imax, coef[i]);
+            int v;
+            if (rightShift > 0) v = (cq * scale + (1 << (rightShift - 1))) >> rightShift;
+            else v = (int)((unsigned)(cq * scale) << (-rightShift));
+            e->bufA[y * HM_TSTRIDE + x] = hm_clip3(-32768, 32767, v);
+          }
+          HM_SYNC();
+          if (!tsMode) inv_transform(e, n, 0, bd);
+          const int off = tshift == 0 ? 0 : (1 << (tshift - 1));
+          HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int v = e->bufA[y * HM_TSTRIDE + x]; rq[y * st + x] = (Pel)(tsMode ? ((v + off) >> tshift) : v); }
+          HM_SYNC();
+        }
+        uint32_t d = dist_sse(rq, st, resi, st, n, bd);
+        if (comp) d = (uint32_t)(e->fb.chromaWeight * (double)d);
+        currDist = d;
+        currCost = calc_rd_cost(e, currBits, currDist);
+      } else if (tsMode == 1) currCost = HM_MAX_DOUBLE;
+      else { currBits = nonCoeffBits; currDist = nonCoeffDist; currCost = nonCoeffCost; }
+      if (currCost < minCost || (tsMode == 1 && currCost == minCost)) {
+        if (isFirst && (nonCoeffCost < currCost || absSum == 0)) {
+          HM_PAR_FOR(i, n * n) coef[i] = 0;
+          absSum = 0; currBits = nonCoeffBits; currDist = nonCoeffDist; currCost = nonCoeffCost;
+        }
+        f->absSum[comp] = (uint32_t)absSum; compDist = currDist; minCost = currCost; f->bestTS[comp] = (uint8_t)tsMode;
+        if (absSum == 0) { HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); rq[y * st + x] = 0; } }
+        HM_SYNC();
+      } else {
+        HM_PAR_FOR(i, 16) { coef[i] = e->tsCoef[comp][i]; rq[(i >> 2) * st + (i & 3)] = e->tsRec[comp][i]; }
+        HM_SYNC();
+      }
+      (void)currBits;
+    }
+    par_set8(m->ts[comp] + zc, f->bestTS[comp], parts);
+    par_set8(m->cbf[comp] + zc, (f->absSum[comp] > 0 ? 1 : 0) << trMode, parts);
+    singleDist += compDist;
+  }
+  cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+  reset_bits(&e->cur);
+  if (t->log2 > minLog2) enc_bin(e, &e->cur, C_SUBDIV + (5 - t->log2), 0);
+  for (int ch = 0; ch < 3; ch++) { const int comp = (ch + 1 == 3) ? 0 : ch + 1; if (!(comp && !t->cW)) code_qt_cbf(e, &e->cur, t, comp, 1); }
+  for (int comp = 0; comp < 3; comp++) {
+    if (comp && !t->cW) continue;
+    const int n = comp ? t->cW : (1 << t->log2), zc = t->cuZ + (comp ? t->cRelZ : t->relZ);
+    if ((m->cbf[comp][zc] >> trMode) & 1) code_coeff_nxn(e, &e->cur, ws->qtCoef[layer] + HM_PLANE_OFF(comp) + (comp ? t->cOff : z * 16), n, comp, SCAN_DIAG, m->ts[comp][zc]);
+  }
+  f->singleDist = singleDist;
+  f->singleBits = num_bits(&e->cur);
+  f->singleCost = calc_rd_cost(e, f->singleBits, f->singleDist);
+}
+
+// results in e->outRdCost (sum of costs), e->outBits, e->outDist, e->irqZeroDist
+HM_DEV HM_NOINLINE void estimate_residual_qt(Shared *e, TU rootv)
+{
+  HM_ENTRY(e); rootv = hm_uni_struct(rootv);
+  CtuMeta *m = &e->meta; WorkSpace *ws = e->ws;
+  IrqFrame *fr = e->irq; int sp = 0;
+  fr[0].t = rootv; fr[0].phase = 0; fr[0].zero = 1;
+  e->irqZeroDist = 0;
+  double retCost = 0; uint32_t retBits = 0, retDist = 0;
+  while (sp >= 0) {
+    IrqFrame *f = &fr[sp]; const TU *t = &f->t;
+    const int z = t->cuZ + t->relZ, fullDepth = t->cuDepth + t->trDepth, trMode = t->trDepth;
+    if (f->phase == 0) {
+      const int minLog2 = tr_min_size_in_cu(6 - t->cuDepth, 0);
+      f->checkFull = t->log2 <= 5; f->checkSplit = t->log2 > minLog2;
+      f->singleCost = HM_MAX_DOUBLE; f->singleBits = 0; f->singleDist = 0;
+      cabac_copy(&ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+      if (f->checkFull) irq_check_full(e, sp);
+      if (!f->checkSplit) { retCost = f->singleCost; retBits = f->singleBits; retDist = f->singleDist; sp--; continue; }
+      if (f->checkFull) { cabac_copy(&ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); }
+      f->subCost = 0.0; f->subBits = 0; f->subDist = 0; f->child = 0;
+      for (int comp = 0; comp < 3; comp++) f->bestCBF[comp] = (comp && !t->cW) ? 0 : ((m->cbf[comp][z] >> trMode) & 1);
+      f->phase = 1;
+    }
+    if (f->phase == 1) {
+      if (f->child < 4) {
+        fr[sp + 1].t = tu_child(t, f->child, 0); fr[sp + 1].phase = 0; fr[sp + 1].zero = f->checkFull ? 0 : f->zero;
+        f->child++; f->phase = 2; sp++; continue;
+      }
+      const int q = t->parts >> 2;
+      uint32_t cbfAny = 0;
+      for (int comp = 0; comp < 3; comp++) {
+        uint32_t yuv = 0;
+        for (int ui = 0; ui < 4; ui++) yuv |= (m->cbf[comp][z + ui * q] >> (trMode + 1)) & 1;
+        HM_PAR_FOR(ui, 4 * q) m->cbf[comp][z + ui] |= (uint8_t)(yuv << trMode);
+        cbfAny |= yuv;
+      }
+      HM_SYNC();
+      cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+      reset_bits(&e->cur);
+      encode_residual_qt(e, t, 3);
+      for (int comp = 0; comp < 3; comp++) encode_residual_qt(e, t, comp);
+      const uint32_t subdivBits = num_bits(&e->cur);
+      const double subdivCost = calc_rd_cost(e, subdivBits, f->subDist);
+      if (!f->checkFull || (cbfAny && subdivCost < f->singleCost)) { retCost = subdivCost; retBits = subdivBits; retDist = f->subDist; }
+      else {
+        retCost = f->singleCost; retBits = f->singleBits; retDist = f->singleDist;
+        par_set8(m->tr + z, trMode, t->parts);
+        for (int comp = 0; comp < 3; comp++) {
+          if (comp && !t->cW) continue;
+          const int zc = t->cuZ + (comp ? t->cRelZ : t->relZ), parts = comp ? t->cParts : t->parts;
+          par_set8(m->cbf[comp] + zc, (int)(f->bestCBF[comp] << trMode), parts);
+          par_set8(m->ts[comp] + zc, f->bestTS[comp], parts);
+        }
+        cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)]);
+      }
+      sp--; continue;
+    }
+    if (f->phase == 2) { f->subCost += retCost; f->subBits += retBits; f->subDist += retDist; f->phase = 1; continue; }
+  }
+  e->outRdCost = retCost; e->outBits = retBits; e->outDist = retDist;
+}
+
+// TEncSearch::encodeResAndCalcRdInterCU :4435-4676; results in e->outCost / outBits / outDist
+HM_DEV HM_NOINLINE void encode_res_and_calc_rd_inter(Shared *e, int cuZ, int cuDepth, int skipRes)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); skipRes = HM_UNI(skipRes);
+  CtuMeta *m = &e->meta; InterMeta *im = e->im; WorkSpace *ws = e->ws;
+  const int n = 64 >> cuDepth, l2 = 6 - cuDepth, parts = 256 >> (2 * cuDepth), bd = e->bitDepth;
+  const int rz = hm_z2r(cuZ), x0 = (rz & 15) * 4, y0 = (rz >> 4) * 4;
+  uint32_t bits = 0, dist = 0;
+  if (skipRes) {
+    par_set8(im->skip + cuZ, 1, parts);
+    for (int c = 0; c < 3; c++) {
+      const int sh = c ? 1 : 0, st = HM_PLANE_STRIDE(c), po = HM_PLANE_OFF(c), nn = n >> sh, ll = l2 - sh;
+      const Pel *org = e->fb.org[c] + (e->ctuY * st + (y0 >> sh)) * e->stride[c] + e->ctuX * st + (x0 >> sh);
+      const int o0 = po + (y0 >> sh) * st + (x0 >> sh);
+      HM_PAR_FOR(i, nn * nn) { const int y = i >> ll, x = i & (nn - 1); ws->reco[o0 + y * st + x] = ws->pred[o0 + y * st + x]; }
+      HM_SYNC();
+      uint32_t d = dist_sse(ws->reco + o0, st, org, e->stride[c], nn, bd);
+      if (c) d = (uint32_t)(e->fb.chromaWeight * (double)d);
+      dist += d;
+    }
+    cabac_copy(&e->cur, &ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+    reset_bits(&e->cur);
+    code_skip_flag(e, &e->cur, cuZ);
+    code_merge_index(e, &e->cur, cuZ);
+    bits = num_bits(&e->cur);
+    e->outBits = bits; e->outDist = dist; e->outCost = calc_rd_cost(e, bits, dist);
+    cabac_copy(&ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
+    for (int c = 0; c < 3; c++) par_set8(m->cbf[c] + cuZ, 0, parts);
+    par_set8(m->tr + cuZ, 0, parts);
+    return;
+  }
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, st = HM_PLANE_STRIDE(c), po = HM_PLANE_OFF(c), nn = n >> sh, ll = l2 - sh;
+    const Pel *org = e->fb.org[c] + (e->ctuY * st + (y0 >> sh)) * e->stride[c] + e->ctuX * st + (x0 >> sh);
+    const int o0 = po + (y0 >> sh) * st + (x0 >> sh);
+    HM_PAR_FOR(i, nn * nn) { const int y = i >> ll, x = i & (nn - 1); ws->resi[o0 + y * st + x] = (Pel)(org[y * e->stride[c] + x] - ws->pred[o0 + y * st + x]); }
+  }
+  HM_SYNC();
+  const TU root = tu_root(e, cuZ, cuDepth);
+  cabac_copy(&e->cur, &ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+  estimate_residual_qt(e, root);
+  const double dCost = e->outRdCost; dist = e->outDist;
+  const uint32_t zeroDist = e->irqZeroDist;
+  reset_bits(&e->cur);
+  enc_bin(e, &e->cur, C_ROOT_CBF, 0);
+  const uint32_t zeroResiBits = num_bits(&e->cur);
+  const double zeroCost = calc_rd_cost(e, zeroResiBits, zeroDist);
+  if (zeroCost < dCost) {
+    dist = zeroDist;
+    par_set8(m->tr + cuZ, 0, parts);
+    for (int c = 0; c < 3; c++) { par_set8(m->cbf[c] + cuZ, 0, parts); par_set8(m->ts[c] + cuZ, 0, parts); }
+    HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = 0;
+    HM_PAR_FOR(i, parts * 4) { e->cc[4096 + cuZ * 4 + i] = 0; e->cc[5120 + cuZ * 4 + i] = 0; }
+    HM_SYNC();
+  } else set_residual_qt_data(e, &root, 0);
+  cabac_copy(&e->cur, &ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+  if (im->mrg[cuZ] && m->part[cuZ] == SIZE_2Nx2N && !qt_root_cbf(m, cuZ)) par_set8(im->skip + cuZ, 1, parts);
+  reset_bits(&e->cur);
+  encode_cu_syntax_inter(e, &e->cur, cuZ, cuDepth);
+  bits = num_bits(&e->cur);
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, st = HM_PLANE_STRIDE(c), po = HM_PLANE_OFF(c), nn = n >> sh, ll = l2 - sh, o0 = po + (y0 >> sh) * st + (x0 >> sh);
+    HM_PAR_FOR(i, nn * nn) { const int y = i >> ll, x = i & (nn - 1); ws->resiBest[o0 + y * st + x] = 0; }
+  }
+  HM_SYNC();
+  if (qt_root_cbf(m, cuZ)) set_residual_qt_data(e, &root, 1);
+  cabac_copy(&ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
+  const int maxv = (1 << bd) - 1;
+  uint32_t distBest = 0;
+  for (int c = 0; c < 3; c++) {
+    const int sh = c ? 1 : 0, st = HM_PLANE_STRIDE(c), po = HM_PLANE_OFF(c), nn = n >> sh, ll = l2 - sh, o0 = po + (y0 >> sh) * st + (x0 >> sh);
+    const Pel *org = e->fb.org[c] + (e->ctuY * st + (y0 >> sh)) * e->stride[c] + e->ctuX * st + (x0 >> sh);
+    HM_PAR_FOR(i, nn * nn) { const int y = i >> ll, x = i & (nn - 1), o = o0 + y * st + x; ws->reco[o] = (Pel)hm_clip3(0, maxv, ws->pred[o] + ws->resiBest[o]); }
+    HM_SYNC();
+    uint32_t d = dist_sse(ws->reco + o0, st, org, e->stride[c], nn, bd);
+    if (c) d = (uint32_t)(e->fb.chromaWeight * (double)d);
+    distBest += d;
+  }
+  e->outCost = calc_rd_cost(e, bits, distBest); e->outBits = bits; e->outDist = distBest;
+  if (im->skip[cuZ]) for (int c = 0; c < 3; c++) par_set8(m->cbf[c] + cuZ, 0, parts);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CU level (TEncCu::xCheckRDCostMerge2Nx2N :1406, xCheckRDCostInter :1532, deriveTestModeAMP :386)
+// The caller's frame keeps the best cost; these leave the candidate result in e->outCost / outBits / outDist.
+// ------------------------------------------------------------------------------------------------
+HM_DEV inline void init_est_data_inter(Shared *e, int cuZ, int cuDepth)
+{ // the inter part of TComDataCU::initEstData
+  InterMeta *im = e->im; const int parts = 256 >> (2 * cuDepth);
+  HM_PAR_FOR(i, parts) {
+    const int z = cuZ + i;
+    im->skip[z] = 0; im->mrg[z] = 0; im->mrgIdx[z] = 0; im->interDir[z] = 0;
+    for (int l = 0; l < 2; l++) { im->mv[l][z].x = im->mv[l][z].y = 0; im->mvd[l][z].x = im->mvd[l][z].y = 0; im->refIdx[l][z] = -1; im->mvpIdx[l][z] = -1; im->mvpNum[l][z] = -1; }
+  }
+  HM_SYNC();
+}
+HM_DEV inline void imeta_copy_range(InterMeta *d, const InterMeta *s, int z0, int parts)
+{
+  HM_PAR_FOR(i, parts) {
+    const int z = z0 + i;
+    d->skip[z] = s->skip[z]; d->mrg[z] = s->mrg[z]; d->mrgIdx[z] = s->mrgIdx[z]; d->interDir[z] = s->interDir[z];
+    for (int l = 0; l < 2; l++) { d->mv[l][z] = s->mv[l][z]; d->mvd[l][z] = s->mvd[l][z]; d->refIdx[l][z] = s->refIdx[l][z]; d->mvpIdx[l][z] = s->mvpIdx[l][z]; d->mvpNum[l][z] = s->mvpNum[l][z]; }
+  }
+  HM_SYNC();
+}

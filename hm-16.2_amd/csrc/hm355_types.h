@@ -11,10 +11,12 @@ typedef int32_t TCoeff;   // TypeDef.h:693
 // context numbering is ours; group sizes follow ContextTables.h:51-161 (intra subset)
 enum {
   C_SPLIT = 0, C_PART = 3, C_INTRA_LUMA = 7, C_CHROMA_PRED = 8, C_SUBDIV = 10, C_QT_CBF = 13, C_SIG_CG = 23,
-  C_SIG = 27, C_LASTX = 71, C_LASTY = 101, C_ONE = 131, C_ABS = 155, C_TSKIP = 161, HM_NUM_CTX = 163
+  C_SIG = 27, C_LASTX = 71, C_LASTY = 101, C_ONE = 131, C_ABS = 155, C_TSKIP = 161,
+  /* inter syntax */ C_SKIP = 163, C_MRG_FLAG = 166, C_MRG_IDX = 167, C_PRED_MODE = 168, C_INTER_DIR = 169, C_MVD = 174, C_REF = 176,
+  C_ROOT_CBF = 178, C_MVP_IDX = 179, HM_NUM_CTX = 180
 };
 struct Cabac {
-  uint8_t s[168];          // HM_NUM_CTX used, padded to 8-byte multiple
+  uint8_t s[184];          // HM_NUM_CTX used, padded to 8-byte multiple
   uint64_t frac;           // TEncBinCABAC::m_fracBits
 };
 enum { CI_CURR_BEST = 0, CI_NEXT_BEST, CI_TEMP_BEST, CI_QT_TRAFO_TEST, CI_QT_TRAFO_ROOT, CI_NUM };   // TypeDef.h:477-486 minus the unused CI_CHROMA_INTRA
@@ -24,6 +26,31 @@ struct CtuMeta {
   uint8_t depth[256], part[256], pred[256], dirL[256], dirC[256], tr[256], cbf[3][256], ts[3][256];
 };
 struct CtuStat { double cost; uint32_t bits, dist; };
+// ---- inter (P slice) per-CTU arrays: TComDataCU m_skipFlag, m_pbMergeFlag, m_puhMergeIndex, m_puhInterDir, m_acCUMvField[2], m_apiMVPIdx/Num ----
+struct MvD { int16_t x, y; };
+struct InterMeta {
+  uint8_t skip[256], mrg[256], mrgIdx[256], interDir[256];
+  MvD mv[2][256], mvd[2][256];
+  int8_t refIdx[2][256], mvpIdx[2][256], mvpNum[2][256];
+};
+#define HM_REF_MARGIN 80              // TComPicYuv margin: max CU width + 16
+// one reference picture as the decoded picture buffer holds it
+struct RefPicDev {
+  const Pel *plane[3];                // border-extended planes, pointing at sample (0,0)
+  int32_t stride[3];
+  int32_t poc, isLongTerm;
+  const uint8_t *predMode;            // motion field after TComPic::compressMotion: [numCtus*256]
+  const MvD *mv[2]; const int8_t *refIdx[2];
+  int32_t refPoc[2][16], refLT[2][16];
+};
+// slice-level inter parameters of one picture slot
+struct InterPic {
+  int32_t sliceType, poc, numRefIdx[2];
+  RefPicDev ref[2][16];
+  int32_t colFromL0, colRefIdx, tmvp, mvdL1Zero, maxMergeCand, checkLDC, cabacInitType;
+  uint32_t lambdaMotionSAD, lambdaMotionSSE;
+  MvD integerMv2Nx2N[2][16];          // TEncSearch::m_integerMv2Nx2N, carried from CTU to CTU in coding order
+};
 
 // planes of one CTU-sized scratch picture: Y 64x64 at 0, Cb 32x32 at 4096, Cr 32x32 at 5120
 #define HM_PLANE_OFF(c) ((c) == 0 ? 0 : ((c) == 1 ? 4096 : 5120))
@@ -33,6 +60,7 @@ struct CtuStat { double cost; uint32_t bits, dist; };
 
 struct Best {              // best mode of one CU depth (the role of m_ppcBestCU[d] / m_ppcRecoYuvBest[d])
   CtuMeta m;
+  InterMeta im;
   TCoeff coef[HM_COEF_CTU];
   Pel reco[HM_COEF_CTU];
 };
@@ -47,6 +75,10 @@ struct WorkSpace {
   int32_t rqLvl[1024];               // RDOQ per-position state of 32x32 blocks (smaller blocks keep it in LDS)
   uint16_t rqPos[1024], rqDec[1024]; int16_t rqCur[1024]; uint8_t rqCtxSig[1024], rqCode[1024];
   Cabac slot[4 * CI_NUM + 3];        // m_pppcRDSbacCoder[depth][CI_*] snapshots (the live coder stays in LDS); depth 4 only holds TEMP_BEST/QT_TRAFO_*
+  Pel tmpPred[HM_COEF_CTU];          // m_tmpYuvPred (merge / ME prediction error)
+  Pel resiBest[HM_COEF_CTU];         // m_ppcResiYuvBest[depth]
+  Pel mcTmp[72 * 64];                // first interpolation stage of a block (m_filteredBlockTmp)
+  Pel mcBlk[64 * 64];                // interpolated candidate block of the fractional search
   uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
 };
 
@@ -65,6 +97,8 @@ struct FrameBuf {
   CtuStat *stat;                     // [numCtus]
   Cabac *endState;                   // [numCtus] estimator state after encodeCtu of that CTU
   uint32_t *done;                    // [numCtus] == run epoch once the CTU's results are published (persistent scheduler)
+  InterMeta *imeta;                  // [numCtus] (P slices; NULL for I slices)
+  InterPic *ip;                      // slice-level inter parameters (NULL for I slices)
   // slice parameters (TEncSlice::setUpLambda, TEncSlice.cpp:132-159)
   double lambda, sqrtLambda, lambdaC, chromaWeight;
   double errScale[2][4];             // [luma/chroma][log2-2]  TComTrQuant::setErrScaleCoeff :2933
