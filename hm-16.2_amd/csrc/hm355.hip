@@ -196,6 +196,8 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   P.tab = c->dTab; P.ws = c->dWs; P.frames = c->dFrames; P.prof = NULL;
 #ifdef HM355_PROFILE
   HM_CHECK(c, hipMalloc((void **)&P.prof, 64 * sizeof(unsigned long long))); HM_CHECK(c, hipMemset(P.prof, 0, 64 * sizeof(unsigned long long)));
+#elif defined(HM355_TRACE)
+  HM_CHECK(c, hipMalloc((void **)&P.prof, (1 + 3 * (size_t)HM_TRACE_CAP) * sizeof(unsigned long long))); HM_CHECK(c, hipMemset(P.prof, 0, sizeof(unsigned long long)));
 #endif
   HM_CHECK(c, hipMemcpy(c->dP, &P, sizeof(Params), hipMemcpyHostToDevice));
   return HM355_OK;
@@ -270,6 +272,19 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
   return HM355_OK;
 }
 
+#if defined(HM355_TRACE)
+// diagnostic build only: copies and resets the RD-evaluation trace (3 words per record), returns the record count
+extern "C" long long hm355_read_trace(hm355_ctx *c, unsigned long long *out, long long cap)
+{
+  unsigned long long n = 0;
+  if (hipMemcpy(&n, c->hp.prof, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (n > HM_TRACE_CAP) n = HM_TRACE_CAP;
+  if ((long long)n > cap) n = (unsigned long long)cap;
+  if (n && hipMemcpy(out, c->hp.prof + 1, n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  hipMemset(c->hp.prof, 0, sizeof(unsigned long long));
+  return (long long)n;
+}
+#endif
 #ifdef HM355_PROFILE
 extern "C" int hm355_read_profile(hm355_ctx *c, unsigned long long *out32)
 { return hipMemcpy(out32, c->hp.prof, 2 * HM_PROF_N * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : HM355_ERR_DEVICE; }
@@ -336,6 +351,82 @@ extern "C" int hm355_compress_slice(hm355_ctx *c, const hm355_slice_desc *slice,
 {
   hm355_ctu_out *cl[1] = { ctus };
   return hm355_compress_slices(c, 1, slice, org, rec, ctus ? cl : NULL, stats);
+}
+
+// ------------------------------------------------------------------------------------------------
+// P slice: reference pictures are uploaded per call (border-extended like TComPicYuv::extendPicBorder), slot 0 is used
+// ------------------------------------------------------------------------------------------------
+static_assert(sizeof(hm355_ctu_inter_out) == sizeof(InterMeta), "hm355_ctu_inter_out mirrors InterMeta");
+extern "C" int hm355_compress_slice_inter(hm355_ctx *c, const hm355_inter_slice_desc *sd, const hm355_planes *org,
+                                          hm355_planes *rec, hm355_ctu_out *ctus, hm355_ctu_inter_out *ictus, hm355_slice_stats *stats)
+{
+  if (!c || !sd || !org) return HM355_ERR_ARG;
+  const Params &P = c->hp;
+  if (sd->base.slice_type != 1) return fail(c, HM355_ERR_ARG, "hm355_compress_slice_inter: only P slices");
+  if (P.wpp) return fail(c, HM355_ERR_ARG, "P slices need WaveFrontSynchro=0 (the 2Nx2N integer-MV state is carried in coding order)");
+  if (sd->num_ref_idx[0] < 1 || sd->num_ref_idx[0] > 16 || sd->num_ref_idx[1] != 0 || sd->max_merge_cand < 1 || sd->max_merge_cand > 5 ||
+      (sd->cabac_init_type != 0 && sd->cabac_init_type != 1)) return fail(c, HM355_ERR_ARG, "bad P slice parameters");
+  int rc = hm355_upload(c, 0, org);
+  if (rc != HM355_OK) return rc;
+  std::vector<void *> toFree;
+  InterPic hip; memset(&hip, 0, sizeof(hip));
+  hip.sliceType = 1; hip.poc = sd->poc; hip.numRefIdx[0] = sd->num_ref_idx[0]; hip.numRefIdx[1] = 0;
+  hip.colFromL0 = sd->col_from_l0; hip.colRefIdx = sd->col_ref_idx; hip.tmvp = sd->tmvp; hip.mvdL1Zero = sd->mvd_l1_zero;
+  hip.maxMergeCand = sd->max_merge_cand; hip.checkLDC = sd->check_ldc; hip.cabacInitType = sd->cabac_init_type;
+  hip.lambdaMotionSAD = sd->lambda_motion_sad; hip.lambdaMotionSSE = sd->lambda_motion_sse;
+  std::vector<const hm355_ref_pic *> seen; std::vector<RefPicDev> devRefs;
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < sd->num_ref_idx[0] && e == hipSuccess; i++) {
+    const hm355_ref_pic *hp = sd->ref[0][i];
+    if (!hp || !hp->plane[0] || !hp->plane[1] || !hp->plane[2] || !hp->pred_mode || !hp->mv[0] || !hp->mv[1] || !hp->ref_idx[0] || !hp->ref_idx[1]) { rc = fail(c, HM355_ERR_ARG, "null reference picture data"); break; }
+    size_t k = 0; for (; k < seen.size(); k++) if (seen[k] == hp) break;
+    if (k == seen.size()) {
+      RefPicDev r; memset(&r, 0, sizeof(r));
+      for (int cc = 0; cc < 3 && e == hipSuccess; cc++) {
+        const int cw = P.width >> (cc ? 1 : 0), ch = P.height >> (cc ? 1 : 0), mg = HM_REF_MARGIN >> (cc ? 1 : 0), st = cw + 2 * mg;
+        std::vector<Pel> buf((size_t)st * (ch + 2 * mg));
+        for (int y = -mg; y < ch + mg; y++) {
+          const int sy = y < 0 ? 0 : (y >= ch ? ch - 1 : y);
+          Pel *d = buf.data() + (size_t)(y + mg) * st + mg;
+          for (int x = -mg; x < cw + mg; x++) { const int sx = x < 0 ? 0 : (x >= cw ? cw - 1 : x); d[x] = (Pel)hp->plane[cc][(size_t)sy * cw + sx]; }
+        }
+        Pel *dv = NULL; e = hipMalloc((void **)&dv, buf.size() * sizeof(Pel));
+        if (e == hipSuccess) { toFree.push_back(dv); e = hipMemcpy(dv, buf.data(), buf.size() * sizeof(Pel), hipMemcpyHostToDevice); }
+        r.plane[cc] = dv + (size_t)mg * st + mg; r.stride[cc] = st;
+      }
+      const size_t np = (size_t)c->numCtus * 256;
+      uint8_t *dpm = NULL; if (e == hipSuccess) e = hipMalloc((void **)&dpm, np);
+      if (e == hipSuccess) { toFree.push_back(dpm); e = hipMemcpy(dpm, hp->pred_mode, np, hipMemcpyHostToDevice); }
+      r.predMode = dpm;
+      for (int l = 0; l < 2 && e == hipSuccess; l++) {
+        MvD *dm = NULL; int8_t *dr = NULL;
+        e = hipMalloc((void **)&dm, np * sizeof(MvD)); if (e == hipSuccess) { toFree.push_back(dm); e = hipMemcpy(dm, hp->mv[l], np * sizeof(MvD), hipMemcpyHostToDevice); }
+        if (e == hipSuccess) e = hipMalloc((void **)&dr, np); if (e == hipSuccess) { toFree.push_back(dr); e = hipMemcpy(dr, hp->ref_idx[l], np, hipMemcpyHostToDevice); }
+        r.mv[l] = dm; r.refIdx[l] = dr;
+        memcpy(r.refPoc[l], hp->ref_poc[l], sizeof(r.refPoc[l])); memcpy(r.refLT[l], hp->ref_lt[l], sizeof(r.refLT[l]));
+      }
+      r.poc = hp->poc; r.isLongTerm = hp->long_term;
+      seen.push_back(hp); devRefs.push_back(r);
+    }
+    hip.ref[0][i] = devRefs[k];
+  }
+  FrameBuf &fb = c->slots[0].fb;
+  InterPic *dIp = NULL; InterMeta *dIm = NULL;
+  if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIp, sizeof(InterPic));
+  if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIp); e = hipMemcpy(dIp, &hip, sizeof(InterPic), hipMemcpyHostToDevice); }
+  if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIm, sizeof(InterMeta) * c->numCtus);
+  if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIm); e = hipMemset(dIm, 0, sizeof(InterMeta) * c->numCtus); }
+  if (rc == HM355_OK && e != hipSuccess) { c->err = std::string("reference picture upload: ") + hipGetErrorString(e); rc = HM355_ERR_DEVICE; }
+  if (rc == HM355_OK) {
+    fb.imeta = dIm; fb.ip = dIp;
+    hm355_slice_desc tmp = sd->base; tmp.slice_type = 2;          // hm355_run validates the common fields
+    rc = hm355_run(c, 1, &tmp);
+    if (rc == HM355_OK) rc = hm355_download(c, 0, rec, ctus, stats);
+    if (rc == HM355_OK && ictus && hipMemcpy(ictus, dIm, sizeof(InterMeta) * c->numCtus, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "motion download failed"; rc = HM355_ERR_DEVICE; }
+    fb.imeta = NULL; fb.ip = NULL;
+  }
+  for (size_t i = 0; i < toFree.size(); i++) hipFree(toFree[i]);
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -278,6 +278,13 @@ struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary, parentPart; double be
 struct MvFieldD { MvD mv; int ref; };
 struct MergeList { MvFieldD f[5]; uint8_t dir[5]; int num; };      // list 0 only (P slice)
 struct AmvpInfo { MvD cand[3]; int n; };
+struct TZ {                            // state of one integer motion search (IntTZSearchStruct, TEncSearch.h:121-133)
+  const Pel *org; int orgStride, w, h;
+  const Pel *ref; int refStride;
+  uint32_t bestSad; int bestX, bestY, bestDist, bestRound, pointNr;
+  int l, r, t, b;
+  int subShift;
+};
 struct IrqFrame {                      // one level of the inter residual quadtree (xEstimateResidualQT)
   TU t; int8_t phase, child, checkFull, checkSplit, zero; uint8_t bestTS[3];
   uint32_t absSum[3], bestCBF[3], singleBits, singleDist, subBits, subDist; double singleCost, subCost;
@@ -330,7 +337,7 @@ struct Shared {
   InterMeta *im;                       // motion arrays of the CTU under search (HBM)
   uint32_t mcost; MvD mvPredictor; int32_t costScale;   // TComRdCost motion-cost state
   MvD intMv[16];                       // TEncSearch::m_integerMv2Nx2N[list 0][refIdx]
-  MvD outMv; MergeList ml; AmvpInfo amvp; MvFieldD mrgField; int32_t mrgDir, mrgIdx; uint32_t mrgCost, irqZeroDist;
+  TZ tz; MvD outMv; MergeList ml; AmvpInfo amvp; MvFieldD mrgField; int32_t mrgDir, mrgIdx; uint32_t mrgCost, irqZeroDist;
   IrqFrame irq[4];
   // uniform per-CTU context
   int32_t width, height, bitDepth, wCtu, stride[3];
@@ -342,6 +349,25 @@ struct Shared {
   unsigned long long prof[HM_PROF_N]; unsigned long long profCnt[HM_PROF_N];
 #endif
 };
+
+// optional RD-evaluation trace (diagnostic builds only: -DHM355_TRACE; the host twin prints, the device appends to P->prof)
+#if defined(HM355_TRACE) && defined(HM355_HOSTSIM)
+#include <stdio.h>
+static FILE *g_hm_trace;
+#define HM_TRACE(e, tag, a, b, c) do { if (g_hm_trace) fprintf(g_hm_trace, "%d %d %u %u %.3f\n", (int)(tag), (e)->ctuAddr, (unsigned)(a), (unsigned)(b), (double)(c)); } while (0)
+#elif defined(HM355_TRACE)
+#define HM_TRACE_CAP (1u << 21)
+__device__ inline void hm_trace(Shared *e, int tag, uint32_t a, uint32_t b, double c)
+{
+  if (hm_lane() == 0) {
+    unsigned long long *t = e->P->prof; const unsigned long long n = atomicAdd(t, 1ull);
+    if (n < HM_TRACE_CAP) { t[1 + n * 3] = ((unsigned long long)(uint32_t)tag << 32) | (uint32_t)e->ctuAddr; t[2 + n * 3] = ((unsigned long long)a << 32) | b; t[3 + n * 3] = (unsigned long long)__double_as_longlong(c); }
+  }
+}
+#define HM_TRACE(e, tag, a, b, c) hm_trace((e), (tag), (uint32_t)(a), (uint32_t)(b), (double)(c))
+#else
+#define HM_TRACE(e, tag, a, b, c) ((void)0)
+#endif
 
 #ifndef HM355_HOSTSIM
 __shared__ Shared g_sh;                // the one CTU search of this workgroup (HM_ENTRY)

@@ -265,6 +265,7 @@ HM_DEV HM_NOINLINE void merge_candidates(Shared *e, int cuZ, int cuDepth, int pa
     if (refcnt == numRef - 1) rr = 0; else { ++rr; ++refcnt; }
   }
   ml->num = arr;
+  HM_TRACE(e, 5, ((uint32_t)(uint16_t)ml->f[0].mv.x << 16) | (uint16_t)ml->f[0].mv.y, ((uint32_t)(uint16_t)ml->f[1].mv.x << 16) | (uint16_t)ml->f[1].mv.y, (double)arr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,6 +332,7 @@ HM_DEV HM_NOINLINE void fill_mvp_cand(Shared *e, int cuZ, int cuDepth, int partS
   if (s->tmvp) { MvD cm; if (temporal_mv(e, r, list, refIdx, &cm)) info->cand[info->n++] = cm; }
   if (info->n > 2) info->n = 2;
   while (info->n < 2) { info->cand[info->n].x = info->cand[info->n].y = 0; info->n++; }
+  HM_TRACE(e, 4, ((uint32_t)(uint16_t)info->cand[0].x << 16) | (uint16_t)info->cand[0].y, ((uint32_t)(uint16_t)info->cand[1].x << 16) | (uint16_t)info->cand[1].y, (double)refIdx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -349,16 +351,14 @@ HM_DEV inline uint32_t mc_cost32(const Shared *e, uint32_t b) { return (uint32_t
 // ------------------------------------------------------------------------------------------------
 // integer search: TZ (xTZSearch :4027-4228, helpers :333-795)
 // ------------------------------------------------------------------------------------------------
-struct TZ {
-  const Pel *org; int orgStride, w, h;
-  const Pel *ref; int refStride;
-  uint32_t bestSad; int bestX, bestY, bestDist, bestRound, pointNr;
-  int l, r, t, b;
-  int subShift;
-};
-HM_DEV inline void tz_help(Shared *e, TZ *z, int sx, int sy, int pointNr, int dist)
+// one search point (xTZSearchHelp :333): not inlined -- the diamond / raster patterns call it from ~60 places
+HM_DEV HM_NOINLINE void tz_help(Shared *e, int sx, int sy, int pointNr, int dist)
 {
-  uint32_t sad = dist_sad_rect(z->org, z->orgStride, z->ref + (ptrdiff_t)sy * z->refStride + sx, z->refStride, z->w, z->h, z->subShift, e->bitDepth);
+  HM_ENTRY(e); sx = HM_UNI(sx); sy = HM_UNI(sy); pointNr = HM_UNI(pointNr); dist = HM_UNI(dist);
+  TZ *z = &e->tz;
+  const Pel *org = hm_uni_ptr(z->org), *ref = hm_uni_ptr(z->ref);
+  uint32_t sad = dist_sad_rect(org, z->orgStride, ref + (ptrdiff_t)sy * z->refStride + sx, z->refStride, z->w, z->h, z->subShift, e->bitDepth);
+  HM_TRACE(e, 11, ((uint32_t)(uint16_t)sx << 16) | (uint16_t)sy, sad, (double)z->bestSad);
   sad += mc_cost32(e, mc_bits(e, sx, sy));
   if (sad < z->bestSad) { z->bestSad = sad; z->bestX = sx; z->bestY = sy; z->bestDist = dist; z->bestRound = 0; z->pointNr = pointNr; }
 }
@@ -366,14 +366,14 @@ HM_DEV inline void tz_2point(Shared *e, TZ *z)
 {
   const int x = z->bestX, y = z->bestY;
   switch (z->pointNr) {
-    case 1: if (x - 1 >= z->l) tz_help(e, z, x - 1, y, 0, 2); if (y - 1 >= z->t) tz_help(e, z, x, y - 1, 0, 2); break;
-    case 2: if (y - 1 >= z->t) { if (x - 1 >= z->l) tz_help(e, z, x - 1, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, z, x + 1, y - 1, 0, 2); } break;
-    case 3: if (y - 1 >= z->t) tz_help(e, z, x, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, z, x + 1, y, 0, 2); break;
-    case 4: if (x - 1 >= z->l) { if (y + 1 <= z->b) tz_help(e, z, x - 1, y + 1, 0, 2); if (y - 1 >= z->t) tz_help(e, z, x - 1, y - 1, 0, 2); } break;
-    case 5: if (x + 1 <= z->r) { if (y - 1 >= z->t) tz_help(e, z, x + 1, y - 1, 0, 2); if (y + 1 <= z->b) tz_help(e, z, x + 1, y + 1, 0, 2); } break;
-    case 6: if (x - 1 >= z->l) tz_help(e, z, x - 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, z, x, y + 1, 0, 2); break;
-    case 7: if (y + 1 <= z->b) { if (x - 1 >= z->l) tz_help(e, z, x - 1, y + 1, 0, 2); if (x + 1 <= z->r) tz_help(e, z, x + 1, y + 1, 0, 2); } break;
-    case 8: if (x + 1 <= z->r) tz_help(e, z, x + 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, z, x, y + 1, 0, 2); break;
+    case 1: if (x - 1 >= z->l) tz_help(e, x - 1, y, 0, 2); if (y - 1 >= z->t) tz_help(e, x, y - 1, 0, 2); break;
+    case 2: if (y - 1 >= z->t) { if (x - 1 >= z->l) tz_help(e, x - 1, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, x + 1, y - 1, 0, 2); } break;
+    case 3: if (y - 1 >= z->t) tz_help(e, x, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, x + 1, y, 0, 2); break;
+    case 4: if (x - 1 >= z->l) { if (y + 1 <= z->b) tz_help(e, x - 1, y + 1, 0, 2); if (y - 1 >= z->t) tz_help(e, x - 1, y - 1, 0, 2); } break;
+    case 5: if (x + 1 <= z->r) { if (y - 1 >= z->t) tz_help(e, x + 1, y - 1, 0, 2); if (y + 1 <= z->b) tz_help(e, x + 1, y + 1, 0, 2); } break;
+    case 6: if (x - 1 >= z->l) tz_help(e, x - 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, x, y + 1, 0, 2); break;
+    case 7: if (y + 1 <= z->b) { if (x - 1 >= z->l) tz_help(e, x - 1, y + 1, 0, 2); if (x + 1 <= z->r) tz_help(e, x + 1, y + 1, 0, 2); } break;
+    case 8: if (x + 1 <= z->r) tz_help(e, x + 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, x, y + 1, 0, 2); break;
     default: break;
   }
 }
@@ -381,40 +381,41 @@ HM_DEV inline void tz_diamond(Shared *e, TZ *z, int sx, int sy, int d)
 {
   const int top = sy - d, bot = sy + d, lef = sx - d, rig = sx + d;
   z->bestRound += 1;
+  const int zl_ = HM_UNI(z->l), zr_ = HM_UNI(z->r), zt_ = HM_UNI(z->t), zb_ = HM_UNI(z->b);
   if (d == 1) {
-    if (top >= z->t) tz_help(e, z, sx, top, 2, d);
-    if (lef >= z->l) tz_help(e, z, lef, sy, 4, d);
-    if (rig <= z->r) tz_help(e, z, rig, sy, 5, d);
-    if (bot <= z->b) tz_help(e, z, sx, bot, 7, d);
+    if (top >= zt_) tz_help(e, sx, top, 2, d);
+    if (lef >= zl_) tz_help(e, lef, sy, 4, d);
+    if (rig <= zr_) tz_help(e, rig, sy, 5, d);
+    if (bot <= zb_) tz_help(e, sx, bot, 7, d);
   } else if (d <= 8) {
     const int top2 = sy - (d >> 1), bot2 = sy + (d >> 1), lef2 = sx - (d >> 1), rig2 = sx + (d >> 1);
-    if (top >= z->t && lef >= z->l && rig <= z->r && bot <= z->b) {
-      tz_help(e, z, sx, top, 2, d); tz_help(e, z, lef2, top2, 1, d >> 1); tz_help(e, z, rig2, top2, 3, d >> 1); tz_help(e, z, lef, sy, 4, d);
-      tz_help(e, z, rig, sy, 5, d); tz_help(e, z, lef2, bot2, 6, d >> 1); tz_help(e, z, rig2, bot2, 8, d >> 1); tz_help(e, z, sx, bot, 7, d);
+    if (top >= zt_ && lef >= zl_ && rig <= zr_ && bot <= zb_) {
+      tz_help(e, sx, top, 2, d); tz_help(e, lef2, top2, 1, d >> 1); tz_help(e, rig2, top2, 3, d >> 1); tz_help(e, lef, sy, 4, d);
+      tz_help(e, rig, sy, 5, d); tz_help(e, lef2, bot2, 6, d >> 1); tz_help(e, rig2, bot2, 8, d >> 1); tz_help(e, sx, bot, 7, d);
     } else {
-      if (top >= z->t) tz_help(e, z, sx, top, 2, d);
-      if (top2 >= z->t) { if (lef2 >= z->l) tz_help(e, z, lef2, top2, 1, d >> 1); if (rig2 <= z->r) tz_help(e, z, rig2, top2, 3, d >> 1); }
-      if (lef >= z->l) tz_help(e, z, lef, sy, 4, d);
-      if (rig <= z->r) tz_help(e, z, rig, sy, 5, d);
-      if (bot2 <= z->b) { if (lef2 >= z->l) tz_help(e, z, lef2, bot2, 6, d >> 1); if (rig2 <= z->r) tz_help(e, z, rig2, bot2, 8, d >> 1); }
-      if (bot <= z->b) tz_help(e, z, sx, bot, 7, d);
+      if (top >= zt_) tz_help(e, sx, top, 2, d);
+      if (top2 >= zt_) { if (lef2 >= zl_) tz_help(e, lef2, top2, 1, d >> 1); if (rig2 <= zr_) tz_help(e, rig2, top2, 3, d >> 1); }
+      if (lef >= zl_) tz_help(e, lef, sy, 4, d);
+      if (rig <= zr_) tz_help(e, rig, sy, 5, d);
+      if (bot2 <= zb_) { if (lef2 >= zl_) tz_help(e, lef2, bot2, 6, d >> 1); if (rig2 <= zr_) tz_help(e, rig2, bot2, 8, d >> 1); }
+      if (bot <= zb_) tz_help(e, sx, bot, 7, d);
     }
   } else {
-    if (top >= z->t && lef >= z->l && rig <= z->r && bot <= z->b) {
-      tz_help(e, z, sx, top, 0, d); tz_help(e, z, lef, sy, 0, d); tz_help(e, z, rig, sy, 0, d); tz_help(e, z, sx, bot, 0, d);
+    if (top >= zt_ && lef >= zl_ && rig <= zr_ && bot <= zb_) {
+      tz_help(e, sx, top, 0, d); tz_help(e, lef, sy, 0, d); tz_help(e, rig, sy, 0, d); tz_help(e, sx, bot, 0, d);
       for (int i = 1; i < 4; i++) {
         const int yt = top + ((d >> 2) * i), yb = bot - ((d >> 2) * i), xl = sx - ((d >> 2) * i), xr = sx + ((d >> 2) * i);
-        tz_help(e, z, xl, yt, 0, d); tz_help(e, z, xr, yt, 0, d); tz_help(e, z, xl, yb, 0, d); tz_help(e, z, xr, yb, 0, d);
+        tz_help(e, xl, yt, 0, d); tz_help(e, xr, yt, 0, d); tz_help(e, xl, yb, 0, d); tz_help(e, xr, yb, 0, d);
       }
     } else {
-      if (top >= z->t) tz_help(e, z, sx, top, 0, d);
-      if (lef >= z->l) tz_help(e, z, lef, sy, 0, d);
-      if (rig <= z->r) tz_help(e, z, rig, sy, 0, d);
-      if (bot <= z->b) tz_help(e, z, sx, bot, 0, d);
+      if (top >= zt_) tz_help(e, sx, top, 0, d);
+      if (lef >= zl_) tz_help(e, lef, sy, 0, d);
+      if (rig <= zr_) tz_help(e, rig, sy, 0, d);
+      if (bot <= zb_) tz_help(e, sx, bot, 0, d);
       for (int i = 1; i < 4; i++) {
         const int yt = top + ((d >> 2) * i), yb = bot - ((d >> 2) * i), xl = sx - ((d >> 2) * i), xr = sx + ((d >> 2) * i);
-        if (yt >= z->t) { if (xl >= z->l) tz_help(e, z, xl, yt, 0, d); if (xr <= z->r) tz_help(e, z, xr, yt, 0, d); }
-        if (yb <= z->b) { if (xl >= z->l) tz_help(e, z, xl, yb, 0, d); if (xr <= z->r) tz_help(e, z, xr, yb, 0, d); }
+        if (yt >= zt_) { if (xl >= zl_) tz_help(e, xl, yt, 0, d); if (xr <= zr_) tz_help(e, xr, yt, 0, d); }
+        if (yb <= zb_) { if (xl >= zl_) tz_help(e, xl, yb, 0, d); if (xr <= zr_) tz_help(e, xr, yb, 0, d); }
       }
     }
   }
@@ -426,19 +427,19 @@ HM_DEV inline void set_search_range(const Shared *e, MvD pred, int rng, int cuX,
   a = clip_mv(e, a, cuX, cuY); b = clip_mv(e, b, cuX, cuY);
   lt->x = a.x >> 2; lt->y = a.y >> 2; rb->x = b.x >> 2; rb->y = b.y >> 2;
 }
-HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, MvD lt, MvD rb, const MvD *intMv2Nx2N)
+HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, MvD lt, MvD rb, int useInt, MvD intMv2Nx2N)
 {
   const int searchRange = 64, raster = 5;
   int rl = lt.x, rr = rb.x, rt = lt.y, rbm = rb.y;
   z->l = lt.x; z->r = rb.x; z->t = lt.y; z->b = rb.y;
   MvD c = clip_mv(e, *mv, cuX, cuY); c.x >>= 2; c.y >>= 2;
   z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0;
-  tz_help(e, z, c.x, c.y, 0, 0);
-  tz_help(e, z, 0, 0, 0, 0);
-  if (intMv2Nx2N) {
-    MvD im; im.x = (int16_t)(intMv2Nx2N->x << 2); im.y = (int16_t)(intMv2Nx2N->y << 2);
+  tz_help(e, c.x, c.y, 0, 0);
+  tz_help(e, 0, 0, 0, 0);
+  if (useInt) {
+    MvD im; im.x = (int16_t)(intMv2Nx2N.x << 2); im.y = (int16_t)(intMv2Nx2N.y << 2);
     im = clip_mv(e, im, cuX, cuY); im.x >>= 2; im.y >>= 2;
-    tz_help(e, z, im.x, im.y, 0, 0);
+    tz_help(e, im.x, im.y, 0, 0);
     MvD nb, nlt, nrb; nb.x = (int16_t)(z->bestX << 2); nb.y = (int16_t)(z->bestY << 2);
     set_search_range(e, nb, searchRange, cuX, cuY, &nlt, &nrb);
     rl = nlt.x; rr = nrb.x; rt = nlt.y; rbm = nrb.y;
@@ -448,7 +449,7 @@ HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, Mv
   if (z->bestDist == 1) { z->bestDist = 0; tz_2point(e, z); }
   if (z->bestDist > raster) {
     z->bestDist = raster;
-    for (sy = rt; sy <= rbm; sy += raster) for (sx = rl; sx <= rr; sx += raster) tz_help(e, z, sx, sy, 0, raster);
+    for (sy = rt; sy <= rbm; sy += raster) for (sx = rl; sx <= rr; sx += raster) tz_help(e, sx, sy, 0, raster);
   }
   while (z->bestDist > 0) {
     sx = z->bestX; sy = z->bestY;
@@ -457,6 +458,7 @@ HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, Mv
     if (z->bestDist == 1) { z->bestDist = 0; if (z->pointNr != 0) tz_2point(e, z); }
   }
   mv->x = (int16_t)z->bestX; mv->y = (int16_t)z->bestY;
+  HM_TRACE(e, 10, ((uint32_t)(uint16_t)z->bestX << 16) | (uint16_t)z->bestY, z->bestSad, 0.0);
   return z->bestSad - mc_cost32(e, mc_bits(e, z->bestX, z->bestY));
 }
 
@@ -493,7 +495,8 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
   const RefPicDev *ref = &s->ref[0][refIdx];
   MvD mvPred; mvPred.x = (int16_t)predX; mvPred.y = (int16_t)predY;
-  TZ z;
+  TZ *zp = &e->tz;
+#define z (*zp)
   z.org = e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px; z.orgStride = e->stride[0]; z.w = r.w; z.h = r.h;
   z.ref = ref->plane[0] + (ptrdiff_t)py * ref->stride[0] + px; z.refStride = ref->stride[0];
   z.subShift = r.h > 8 ? 1 : 0;
@@ -503,7 +506,7 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   MvD mv = mvPred;
   const int useInt = (partSize != SIZE_2Nx2N || cuDepth != 0);
   MvD im = e->intMv[refIdx];
-  uint32_t c = tz_search(e, &z, &mv, cuX, cuY, lt, rb, useInt ? &im : (const MvD *)0);
+  uint32_t c = tz_search(e, &z, &mv, cuX, cuY, lt, rb, useInt, im);
   if (partSize == SIZE_2Nx2N) e->intMv[refIdx] = mv;
   e->costScale = 1;
   const Pel *refAtInt = z.ref + (ptrdiff_t)mv.y * z.refStride + mv.x;
@@ -518,6 +521,8 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   const uint32_t bits = bitsIn + mvBits;
   e->outMv = mv; e->outBits = bits;
   e->outDist = (uint32_t)(floor(1.0 * ((double)c - (double)mc_cost32(e, mvBits))) + (double)mc_cost32(e, bits));
+  HM_TRACE(e, 2, ((uint32_t)(uint16_t)mv.x << 16) | (uint16_t)mv.y, bits, (double)e->outDist);
+#undef z
 }
 
 // TComPrediction::motionCompensation of one PU (P slice: list 0) into a CTU-relative scratch picture
@@ -542,6 +547,7 @@ HM_DEV inline uint32_t template_cost(Shared *e, int cuZ, Rect r, MvD cand, int r
   Pel *blk = e->ws->mcBlk;
   pred_inter_blk(e, 0, &s->ref[0][refIdx], px, py, clip_mv(e, cand, cuX, cuY), r.w, r.h, blk, 64);
   const uint32_t sad = dist_sad_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], blk, 64, r.w, r.h, 0, e->bitDepth);
+  HM_TRACE(e, 9, ((uint32_t)(uint16_t)cand.x << 16) | (uint16_t)cand.y, sad, 0.0);
   const double t = floor(((double)1 * (double)s->lambdaMotionSAD) + 0.5) / 65536.0;
   return (uint32_t)floor((double)sad + t);
 }
@@ -606,6 +612,7 @@ HM_DEV HM_NOINLINE void merge_estimation(Shared *e, int cuZ, int cuDepth, int pa
     if (d < cost) { cost = d; e->mrgField = ml->f[c]; e->mrgDir = ml->dir[c]; e->mrgIdx = c; }
   }
   e->mrgCost = cost;
+  HM_TRACE(e, 3, e->mrgIdx, cost, (double)ml->num);
 }
 
 // TEncSearch::predInterSearch :3075-3567, P slice
@@ -984,6 +991,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
   f->singleDist = singleDist;
   f->singleBits = num_bits(&e->cur);
   f->singleCost = calc_rd_cost(e, f->singleBits, f->singleDist);
+  HM_TRACE(e, 8, f->singleBits, f->singleDist, f->singleCost);
 }
 
 // results in e->outRdCost (sum of costs), e->outBits, e->outDist, e->irqZeroDist
@@ -1091,6 +1099,7 @@ HM_DEV HM_NOINLINE void encode_res_and_calc_rd_inter(Shared *e, int cuZ, int cuD
   cabac_copy(&e->cur, &ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
   estimate_residual_qt(e, root);
   const double dCost = e->outRdCost; dist = e->outDist;
+  HM_TRACE(e, 6, e->outBits, e->outDist, dCost);
   const uint32_t zeroDist = e->irqZeroDist;
   reset_bits(&e->cur);
   enc_bin(e, &e->cur, C_ROOT_CBF, 0);

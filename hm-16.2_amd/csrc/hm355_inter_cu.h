@@ -3,6 +3,7 @@
 
 HM_DEV inline void check_best_mode(Shared *e, CuFrame *f, int cuZ, int cuDepth)
 { // xCheckBestMode :1702
+  HM_TRACE(e, 1, e->outBits, e->outDist, e->outCost);
   if (e->outCost < f->bestCost) {
     f->bestCost = e->outCost; f->bestBits = e->outBits; f->bestDist = e->outDist;
     save_best(e, cuZ, cuDepth);

@@ -89,6 +89,38 @@ int hm355_compress_slice(hm355_ctx *ctx, const hm355_slice_desc *slice, const hm
 int hm355_compress_slices(hm355_ctx *ctx, int n, const hm355_slice_desc *slices, const hm355_planes *org,
                           hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_slice_stats *stats);
 
+/* ---- P slices (encoder_lowdelay_P_main.cfg): the reference pictures and slice-header values that
+ * TEncSlice::compressSlice finds through pcSlice->getRefPic(list, idx) / TComSlice getters are inputs.
+ * Replaces the same member for P slices: merge / skip, AMVP, TZ integer search + fractional refinement
+ * (TEncSearch::predInterSearch / xMotionEstimation, TEncSearch.cpp:3075-3906), AMP, inter RQT
+ * (xEstimateResidualQT :4680) and the intra candidates of P slices.  B slices: not yet. ---- */
+typedef struct {
+  int32_t poc, slice_type, long_term;
+  const uint16_t *plane[3];           /* TComPic::getPicYuvRec() after the loop filters, tightly packed */
+  const uint8_t *pred_mode;           /* motion field after TComPic::compressMotion: [numCtus*256] */
+  const int16_t *mv[2];               /* [numCtus*256*2] (x, y), quarter samples */
+  const int8_t *ref_idx[2];           /* [numCtus*256] */
+  int32_t num_ref[2], ref_poc[2][16], ref_lt[2][16];   /* reference lists that picture was coded with (TMVP scaling) */
+} hm355_ref_pic;
+typedef struct {
+  hm355_slice_desc base;              /* slice_type 1 (P), qp, lambda, chroma weight */
+  int32_t poc;
+  int32_t cabac_init_type;            /* context table in use (TEncSbac::resetEntropy, TEncSbac.cpp:106-115): 0 = B, 1 = P */
+  int32_t num_ref_idx[2];
+  const hm355_ref_pic *ref[2][16];
+  int32_t col_from_l0, col_ref_idx, tmvp, mvd_l1_zero, max_merge_cand, check_ldc;
+  uint32_t lambda_motion_sad, lambda_motion_sse;       /* TComRdCost::m_uiLambdaMotionSAD / SSE[0] */
+} hm355_inter_slice_desc;
+/* per-CTU motion data: m_skipFlag, m_pbMergeFlag, m_puhMergeIndex, m_puhInterDir, m_acCUMvField[2] (mv, mvd, refIdx),
+ * m_apiMVPIdx / m_apiMVPNum (TComDataCU.h:86-157) */
+typedef struct {
+  uint8_t skip[256], merge_flag[256], merge_idx[256], inter_dir[256];
+  int16_t mv[2][256][2], mvd[2][256][2];
+  int8_t  ref_idx[2][256], mvp_idx[2][256], mvp_num[2][256];
+} hm355_ctu_inter_out;
+int hm355_compress_slice_inter(hm355_ctx *ctx, const hm355_inter_slice_desc *slice, const hm355_planes *org,
+                               hm355_planes *rec, hm355_ctu_out *ctus, hm355_ctu_inter_out *ictus, hm355_slice_stats *stats);
+
 /* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
  * Upload / run / download are separate so that a caller can keep pictures resident. */
 int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */

@@ -106,3 +106,17 @@ def assert_inter_ctus_equal(ctus, ictus, want, what):
     for l in range(2):
         for f, g in (("mv", "mv%d"), ("mvd", "mvd%d"), ("ref_idx", "ref_idx%d"), ("mvp_idx", "mvp_idx%d"), ("mvp_num", "mvp_num%d")):
             assert np.array_equal(ictus[f][:, l], want[g % l]), f"{what}: {g % l} differs"
+
+
+def ldp_slice_inputs(r, finals):
+    """(slice_params, ref_pics) in the form hm355.Encoder.compress_inter takes, from an 'S' record and the 'F' records"""
+    sp = {k: r[k] for k in ("qp", "lambda", "poc", "cabac_init_type", "num_ref_idx", "ref_poc", "col_from_l0", "col_ref_idx", "tmvp",
+                            "mvd_l1_zero", "max_merge_cand", "check_ldc", "lambda_motion_sad", "lambda_motion_sse")}
+    sp["chroma_weight"] = r["weight_cb"]
+    refs = {}
+    for poc in set(int(r["ref_poc"][l][i]) for l in range(2) for i in range(r["num_ref_idx"][l])):
+        f = finals[poc]; m = f["motion"]
+        refs[poc] = dict(slice_type=f["slice_type"], rec=f["rec"], pred_mode=m["pred_mode"], mv=[m["mv0"], m["mv1"]],
+                         ref_idx=[m["ref_idx0"], m["ref_idx1"]], num_ref_idx=f["num_ref_idx"], ref_poc=f["ref_poc"],
+                         ref_long_term=f["ref_long_term"])
+    return sp, refs

@@ -34,6 +34,9 @@ int main(int argc, char **argv)
   const size_t frameBytes = (size_t)w * h * 3 / 2 * (bd == 8 ? 1 : 2);
   int bad = 0, nP = 0;
   static Shared sh;
+#ifdef HM355_TRACE
+  if (argc > 6) g_hm_trace = fopen(argv[6], "w");
+#endif
   while (g_off < g_n) {
     const char tag = (char)rd<unsigned char>();
     if (tag == 'F') {

@@ -42,6 +42,38 @@ def test_hip_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, qp, wpp, seed):
     enc.close()
 
 
+@pytest.mark.parametrize("name", common.LDP_CASES)
+def test_hip_p_slices_match_reference_fixture(hm, name):
+    """encoder_lowdelay_P_main.cfg clips: every P slice through hm355_compress_slice_inter with the reference pictures and
+    slice parameters the reference's compressSlice saw; decisions, motion, coefficients, costs, reconstruction bit-exact."""
+    cfg, slices, finals = common.load_ldp_case(name)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 0, max_batch=1)
+    n_p = 0
+    for r in slices:
+        if int(r["slice_type"]) != 1:
+            continue
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"])
+        sp, refs = common.ldp_slice_inputs(r, finals)
+        rec, ctus, ictus, stats = enc.compress_inter(planes, sp, refs)
+        common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], f"{name} POC {int(r['poc'])}")
+        for c in range(3):
+            assert np.array_equal(rec[c], r["rec"][c]), f"{name} POC {int(r['poc'])}: reconstruction plane {c}"
+        assert stats[0] == int(ctus["total_bits"].sum())
+        n_p += 1
+    assert n_p >= 4
+    enc.close()
+
+
+def test_hip_p_slice_rejects_wavefront(hm):
+    cfg, slices, finals = common.load_ldp_case(common.LDP_CASES[0])
+    r = [s for s in slices if int(s["slice_type"]) == 1][0]
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 1, max_batch=1)
+    sp, refs = common.ldp_slice_inputs(r, finals)
+    with pytest.raises(RuntimeError):
+        enc.compress_inter(synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"]), sp, refs)
+    enc.close()
+
+
 def test_hip_batch_equals_single(hm):
     """pictures of a batch are independent: batched results == one-at-a-time results"""
     w, h, bd, qp = 128, 128, 8, 32
