@@ -67,9 +67,12 @@ extern "C" __global__ void __launch_bounds__(64, 4) hm355_ctu_kernel(const Param
       if (cx > 0) dep0 = a - 1;
       if (cy > 0) dep1 = (cy - 1) * wCtu + (cx + 1 < wCtu ? cx + 1 : cx);
     } else if (a > 0) dep0 = a - 1;
+    // P slice: a picture-boundary CTU takes the 2Nx2N integer-MV state of its predecessor in coding order (process_ctu)
+    const int dep2 = (P->wpp && cx == 0 && cy > 0 && P->frames[curItem.frame].imeta && (63 >= P->width || cy * 64 + 63 >= P->height)) ? a - 1 : -1;
     int bad = 0;
     if (dep0 >= 0) bad = hm355_wait_flag(done + dep0, sched + 1, epoch);
     if (!bad && dep1 >= 0) bad = hm355_wait_flag(done + dep1, sched + 1, epoch);
+    if (!bad && dep2 >= 0) bad = hm355_wait_flag(done + dep2, sched + 1, epoch);
     if (bad) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     process_ctu(&g_sh, P, &curItem, (int)blockIdx.x);
@@ -242,8 +245,11 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
     fbs[f] = c->slots[f].fb;
   }
   HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
-  if (c->schedFrames != n) {
-    hm355_build_schedule(P.wCtu, P.hCtu, P.wpp, n, c->items, c->stepStart);
+  int carry = 0;
+  for (int f = 0; f < n; f++) carry |= c->slots[f].fb.imeta != NULL && (P.height & 63) != 0;
+  const int schedKey = n * 2 + carry;
+  if (c->schedFrames != schedKey) {
+    hm355_build_schedule(P.wCtu, P.hCtu, P.wpp, n, c->items, c->stepStart, carry);
     if (c->items.size() > c->itemsCap) {
       if (c->dItems) hipFree(c->dItems);
       c->dItems = NULL; c->itemsCap = 0;
@@ -251,7 +257,7 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
       c->itemsCap = c->items.size();
     }
     HM_CHECK(c, hipMemcpyAsync(c->dItems, c->items.data(), sizeof(WorkItem) * c->items.size(), hipMemcpyHostToDevice, c->stream));
-    c->schedFrames = n;
+    c->schedFrames = schedKey;
   }
   c->epoch++; if (c->epoch == 0) c->epoch = 1;
   HM_CHECK(c, hipMemsetAsync(c->dSched, 0, 64, c->stream));        // ticket = 0, abort = 0
@@ -363,7 +369,6 @@ extern "C" int hm355_compress_slice_inter(hm355_ctx *c, const hm355_inter_slice_
   if (!c || !sd || !org) return HM355_ERR_ARG;
   const Params &P = c->hp;
   if (sd->base.slice_type != 1) return fail(c, HM355_ERR_ARG, "hm355_compress_slice_inter: only P slices");
-  if (P.wpp) return fail(c, HM355_ERR_ARG, "P slices need WaveFrontSynchro=0 (the 2Nx2N integer-MV state is carried in coding order)");
   if (sd->num_ref_idx[0] < 1 || sd->num_ref_idx[0] > 16 || sd->num_ref_idx[1] != 0 || sd->max_merge_cand < 1 || sd->max_merge_cand > 5 ||
       (sd->cabac_init_type != 0 && sd->cabac_init_type != 1)) return fail(c, HM355_ERR_ARG, "bad P slice parameters");
   int rc = hm355_upload(c, 0, org);
@@ -411,19 +416,21 @@ extern "C" int hm355_compress_slice_inter(hm355_ctx *c, const hm355_inter_slice_
     hip.ref[0][i] = devRefs[k];
   }
   FrameBuf &fb = c->slots[0].fb;
-  InterPic *dIp = NULL; InterMeta *dIm = NULL;
+  InterPic *dIp = NULL; InterMeta *dIm = NULL; MvD *dIntMv = NULL;
+  if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIntMv, sizeof(MvD) * 16 * c->numCtus);
+  if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIntMv); e = hipMemset(dIntMv, 0, sizeof(MvD) * 16 * c->numCtus); }
   if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIp, sizeof(InterPic));
   if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIp); e = hipMemcpy(dIp, &hip, sizeof(InterPic), hipMemcpyHostToDevice); }
   if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIm, sizeof(InterMeta) * c->numCtus);
   if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIm); e = hipMemset(dIm, 0, sizeof(InterMeta) * c->numCtus); }
   if (rc == HM355_OK && e != hipSuccess) { c->err = std::string("reference picture upload: ") + hipGetErrorString(e); rc = HM355_ERR_DEVICE; }
   if (rc == HM355_OK) {
-    fb.imeta = dIm; fb.ip = dIp;
+    fb.imeta = dIm; fb.ip = dIp; fb.intMv = dIntMv;
     hm355_slice_desc tmp = sd->base; tmp.slice_type = 2;          // hm355_run validates the common fields
     rc = hm355_run(c, 1, &tmp);
     if (rc == HM355_OK) rc = hm355_download(c, 0, rec, ctus, stats);
     if (rc == HM355_OK && ictus && hipMemcpy(ictus, dIm, sizeof(InterMeta) * c->numCtus, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "motion download failed"; rc = HM355_ERR_DEVICE; }
-    fb.imeta = NULL; fb.ip = NULL;
+    fb.imeta = NULL; fb.ip = NULL; fb.intMv = NULL;
   }
   for (size_t i = 0; i < toFree.size(); i++) hipFree(toFree[i]);
   return rc;

@@ -2325,7 +2325,15 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;
   e->im = e->fb.imeta ? e->fb.imeta + e->ctuAddr : (InterMeta *)0;
   HM_SYNC();
-  if (e->im) { HM_PAR_FOR(i, 16) e->intMv[i] = e->fb.ip->integerMv2Nx2N[0][i]; HM_SYNC(); }
+  if (e->im) {
+    // TEncSearch::m_integerMv2Nx2N persists from CTU to CTU in coding order.  A CTU whose 64x64 CU lies inside the picture
+    // overwrites every entry (2Nx2N search at depth 0, all reference indices) before it reads one, so only picture-boundary
+    // CTUs take the state of their predecessor -- which is what lets P slices run as a WPP wavefront.
+    const int bnd = it->ctuX * 64 + 63 >= P->width || it->ctuY * 64 + 63 >= P->height;
+    const MvD *src = e->ctuAddr == 0 ? e->fb.ip->integerMv2Nx2N[0] : e->fb.intMv + (size_t)(e->ctuAddr - 1) * 16;
+    HM_PAR_FOR(i, 16) { MvD v; v.x = v.y = 0; if (bnd) v = src[i]; e->intMv[i] = v; }
+    HM_SYNC();
+  }
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   for (int i = 0; i < HM_PROF_N; i++) { e->prof[i] = 0; e->profCnt[i] = 0; }
 #endif
@@ -2362,7 +2370,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   reset_bits(&e->cur);
   encode_ctu(e, &e->cur, a == numCtus - 1);
   cabac_copy(e->fb.endState + a, &e->cur);
-  if (e->im) { HM_PAR_FOR(i, 16) e->fb.ip->integerMv2Nx2N[0][i] = e->intMv[i]; HM_SYNC(); }   // carried to the next CTU in coding order
+  if (e->im) { HM_PAR_FOR(i, 16) e->fb.intMv[(size_t)a * 16 + i] = e->intMv[i]; HM_SYNC(); }   // carried to the next CTU in coding order
   { // decision arrays back to HBM (TComDataCU::copyToPic of the whole CTU)
     const uint32_t *src = (const uint32_t *)&e->meta; uint32_t *dst = (uint32_t *)(e->fb.meta + a);
     HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];

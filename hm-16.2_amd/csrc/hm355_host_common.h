@@ -81,18 +81,24 @@ static inline void hm355_intra_lambda(int qp, double *lambda, double *chromaWeig
 // above-right CTU and the CABAC hand-off) were produced in steps < s:
 //   WaveFrontSynchro=1 : CTU (x,y) runs at step x + 2y   (2-CTU lag wavefront, TEncSlice.cpp:740-755)
 //   WaveFrontSynchro=0 : the CABAC state chains through every CTU in raster order -> step = address
-// All pictures of a batch are independent (all-intra), so step s carries the CTUs of every picture.
-static inline void hm355_build_schedule(int wCtu, int hCtu, int wpp, int nFrames, std::vector<WorkItem> &items, std::vector<int> &stepStart)
+// All pictures of a batch are independent, so step s carries the CTUs of every picture.
+// carryLastRow (P slices under WPP whose last CTU row is cut by the picture edge): CTU (0, last row) also needs the
+// 2Nx2N integer-MV state of the last CTU of the row above, so that row is ordered behind the whole row above it.
+static inline int hm355_schedule_step(int wCtu, int hCtu, int wpp, int carryLastRow, int x, int y)
+{
+  if (!wpp) return y * wCtu + x;
+  if (carryLastRow && hCtu > 1 && wCtu > 1 && y == hCtu - 1) return (wCtu - 1) + 2 * (hCtu - 2) + 1 + x;
+  return x + 2 * y;
+}
+static inline void hm355_build_schedule(int wCtu, int hCtu, int wpp, int nFrames, std::vector<WorkItem> &items, std::vector<int> &stepStart, int carryLastRow = 0)
 {
   items.clear(); stepStart.clear();
-  const int steps = wpp ? (wCtu + 2 * (hCtu - 1)) : wCtu * hCtu;
+  const int steps = hm355_schedule_step(wCtu, hCtu, wpp, carryLastRow, wCtu - 1, hCtu - 1) + 1;
+  std::vector<std::vector<WorkItem> > bucket(steps);
+  for (int y = 0; y < hCtu; y++) for (int x = 0; x < wCtu; x++) { WorkItem w = {0, x, y, 0}; bucket[hm355_schedule_step(wCtu, hCtu, wpp, carryLastRow, x, y)].push_back(w); }
   for (int s = 0; s < steps; s++) {
     stepStart.push_back((int)items.size());
-    for (int f = 0; f < nFrames; f++) {
-      if (wpp) {
-        for (int y = 0; y < hCtu; y++) { const int x = s - 2 * y; if (x >= 0 && x < wCtu) { WorkItem w = {f, x, y, 0}; items.push_back(w); } }
-      } else { WorkItem w = {f, s % wCtu, s / wCtu, 0}; items.push_back(w); }
-    }
+    for (int f = 0; f < nFrames; f++) for (size_t i = 0; i < bucket[s].size(); i++) { WorkItem w = bucket[s][i]; w.frame = f; items.push_back(w); }
   }
   stepStart.push_back((int)items.size());
 }

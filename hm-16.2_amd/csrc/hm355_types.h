@@ -49,7 +49,7 @@ struct InterPic {
   RefPicDev ref[2][16];
   int32_t colFromL0, colRefIdx, tmvp, mvdL1Zero, maxMergeCand, checkLDC, cabacInitType;
   uint32_t lambdaMotionSAD, lambdaMotionSSE;
-  MvD integerMv2Nx2N[2][16];          // TEncSearch::m_integerMv2Nx2N, carried from CTU to CTU in coding order
+  MvD integerMv2Nx2N[2][16];          // TEncSearch::m_integerMv2Nx2N on entry to the slice
 };
 
 // planes of one CTU-sized scratch picture: Y 64x64 at 0, Cb 32x32 at 4096, Cr 32x32 at 5120
@@ -99,6 +99,7 @@ struct FrameBuf {
   uint32_t *done;                    // [numCtus] == run epoch once the CTU's results are published (persistent scheduler)
   InterMeta *imeta;                  // [numCtus] (P slices; NULL for I slices)
   InterPic *ip;                      // slice-level inter parameters (NULL for I slices)
+  MvD *intMv;                        // [numCtus][16] m_integerMv2Nx2N[0][] as each CTU left it (carried in coding order)
   // slice parameters (TEncSlice::setUpLambda, TEncSlice.cpp:132-159)
   double lambda, sqrtLambda, lambdaC, chromaWeight;
   double errScale[2][4];             // [luma/chroma][log2-2]  TComTrQuant::setErrScaleCoeff :2933

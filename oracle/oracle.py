@@ -92,12 +92,12 @@ CTU_INTER_DTYPE = np.dtype([("skip", "u1", 256), ("merge_flag", "u1", 256), ("me
                             ("ref_idx", "i1", (2, 256)), ("mvp_idx", "i1", (2, 256)), ("mvp_num", "i1", (2, 256))])
 
 
-def compress_inter(planes, bit_depth, srec, finals, trace=None):
+def compress_inter(planes, bit_depth, srec, finals, trace=None, wpp=0):
     """One P slice.  srec: an 'S' record of tests/hmd2.py (slice parameters as the reference used them);
     finals: {poc: 'F' record} of the pictures it references.  Returns (rec planes, ctus, inter ctus)."""
     L = lib()
     h, w = planes[0].shape
-    cfg = Cfg(w, h, bit_depth, int(srec["qp"]), 0, float(srec["lambda"]), float(srec["weight_cb"]))
+    cfg = Cfg(w, h, bit_depth, int(srec["qp"]), wpp, float(srec["lambda"]), float(srec["weight_cb"]))
     n = ((w + 63) // 64) * ((h + 63) // 64)
     keep, refs = [], {}
     for poc in set(int(srec["ref_poc"][l][i]) for l in range(2) for i in range(srec["num_ref_idx"][l])):

@@ -69,15 +69,17 @@ def assert_rec_equal(got_planes, want_flat, w, h, what):
         assert np.array_equal(got_planes[k], want[k]), f"{what}: reconstruction plane {k} differs at {np.count_nonzero(got_planes[k] != want[k])} samples"
 
 
-LDP_CASES = ["ldp_192x128_8b_qp32", "ldp_200x136_8b_qp24"]
+LDP_CASES = ["ldp_192x128_8b_qp32", "ldp_200x136_8b_qp24", "ldpwpp_256x136_8b_qp30"]
 _S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
            "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
 
 
-def load_ldp_case(name):
-    """-> (cfg dict, list of 'S' records, {poc: 'F' record}) in the layout of tests/hmd2.py"""
+def load_ldp_case(name, records=None):
+    """-> (cfg dict, list of 'S' records, {poc: 'F' record}) in the layout of tests/hmd2.py; `records` (a list) receives
+    every record in stream order"""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     cfg = {k: int(g[k]) for k in ("width", "height", "bit_depth", "frames", "seed")}
+    cfg["wpp"] = int(g["wpp"]) if "wpp" in g else 0
     slices, finals = [], {}
     for i in range(int(g["num_records"])):
         r = {"tag": chr(int(g[f"r{i}_tag"])), "num_ref_idx": tuple(int(v) for v in g[f"r{i}_num_ref_idx"]),
@@ -90,6 +92,8 @@ def load_ldp_case(name):
         else:
             r["poc"] = int(g[f"r{i}_poc"]); r["slice_type"] = int(g[f"r{i}_slice_type"]); r["motion"] = g[f"r{i}_motion"]
             finals[r["poc"]] = r
+        if records is not None:
+            records.append(r)
     return cfg, slices, finals
 
 

@@ -61,3 +61,32 @@ def parse(path, width, height):
             raise ValueError(f"bad record tag {tag!r} at {off - 1}")
         recs.append(r)
     return recs
+
+
+def write(path, recs):
+    """the inverse of parse(): records (dicts as parse() returns them; missing S fields are written as 0) -> HMD2 stream"""
+    def ref_lists(r):
+        return struct.pack("<2i", *[int(v) for v in r["num_ref_idx"]]) + np.ascontiguousarray(r["ref_poc"], "<i4").tobytes() + \
+            np.ascontiguousarray(r["ref_long_term"], "<i4").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"HMD2")
+        for r in recs:
+            f.write(r["tag"].encode())
+            rec = b"".join(np.ascontiguousarray(p, "<u2").tobytes() for p in r["rec"])
+            if r["tag"] == "S":
+                f.write(struct.pack("<5i", int(r["poc"]), int(r["slice_type"]), int(r["qp"]), int(r.get("tlayer", 0)), int(r.get("depth", 0))))
+                f.write(struct.pack("<4d", float(r["lambda"]), float(r["sqrt_lambda"]), float(r["weight_cb"]), float(r["weight_cr"])))
+                f.write(struct.pack("<2I", int(r["lambda_motion_sad"]), int(r["lambda_motion_sse"])))
+                f.write(ref_lists(r))
+                f.write(struct.pack("<7i", *[int(r[k]) for k in ("col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")]))
+                f.write(np.ascontiguousarray(r.get("l1_to_l0", np.zeros(16)), "<i4").tobytes())
+                f.write(struct.pack("<I", len(r["ctus"])))
+                f.write(np.ascontiguousarray(r["ctus"], CTU_DT).tobytes())
+                f.write(rec)
+            else:
+                f.write(struct.pack("<i", int(r["poc"])))
+                f.write(rec)
+                f.write(struct.pack("<i", int(r["slice_type"])))
+                f.write(ref_lists(r))
+                f.write(struct.pack("<I", len(r["motion"])))
+                f.write(np.ascontiguousarray(r["motion"], MOT_DT).tobytes())

@@ -1,7 +1,7 @@
 // DEBUGGING AID, NOT PRODUCT: the P-slice path of hm-16.2_amd/csrc/hm355_core.h compiled for the host with one "lane"
 // (see hostsim.cpp), driven by an HMD2 record stream of the real reference (oracle/ref_harness.cpp, `hm_dump enc2`):
 // every P slice is re-run with the slice parameters and reference pictures of its record and compared in place.
-//   hostsim_inter <in.yuv> <dump2.bin> <w> <h> <bitdepth>        exit code 0 = every P slice bit-exact
+//   hostsim_inter <in.yuv> <dump2.bin> <w> <h> <bitdepth> [wpp]   exit code 0 = every P slice bit-exact
 #define HM355_HOSTSIM 1
 #include "../../hm-16.2_amd/csrc/hm355_core.h"
 #include "../../hm-16.2_amd/csrc/hm355_host_common.h"
@@ -25,7 +25,7 @@ int main(int argc, char **argv)
   std::vector<unsigned char> data(g_n); if (fread(data.data(), 1, g_n, fd) != g_n) return 1;
   g_p = data.data(); g_off = 4;
   Params P; memset(&P, 0, sizeof(P));
-  P.width = w; P.height = h; P.bitDepth = bd; P.wpp = 0; P.wCtu = (w + 63) / 64; P.hCtu = (h + 63) / 64;
+  P.width = w; P.height = h; P.bitDepth = bd; P.wpp = argc > 6 ? atoi(argv[6]) : 0; P.wCtu = (w + 63) / 64; P.hCtu = (h + 63) / 64;
   P.stride[0] = P.wCtu * 64; P.stride[1] = P.stride[2] = P.wCtu * 32;
   const int nctu = P.wCtu * P.hCtu;
   Tables *tab = new Tables; hm355_build_tables(tab); P.tab = tab;
@@ -35,7 +35,7 @@ int main(int argc, char **argv)
   int bad = 0, nP = 0;
   static Shared sh;
 #ifdef HM355_TRACE
-  if (argc > 6) g_hm_trace = fopen(argv[6], "w");
+  if (argc > 7) g_hm_trace = fopen(argv[7], "w");
 #endif
   while (g_off < g_n) {
     const char tag = (char)rd<unsigned char>();
@@ -96,7 +96,7 @@ int main(int argc, char **argv)
     }
     fb.meta = (CtuMeta *)calloc(nctu, sizeof(CtuMeta)); fb.coef = (TCoeff *)calloc((size_t)nctu * HM_COEF_CTU, sizeof(TCoeff));
     fb.stat = (CtuStat *)calloc(nctu, sizeof(CtuStat)); fb.endState = (Cabac *)calloc(nctu, sizeof(Cabac));
-    fb.imeta = (InterMeta *)calloc(nctu, sizeof(InterMeta));
+    fb.imeta = (InterMeta *)calloc(nctu, sizeof(InterMeta)); fb.intMv = (MvD *)calloc((size_t)nctu * 16, sizeof(MvD));
     InterPic *ip = (InterPic *)calloc(1, sizeof(InterPic)); fb.ip = ip;
     ip->sliceType = sliceType; ip->poc = poc; ip->numRefIdx[0] = numRef[0]; ip->numRefIdx[1] = numRef[1];
     ip->colFromL0 = misc[0]; ip->colRefIdx = misc[1]; ip->tmvp = misc[2]; ip->mvdL1Zero = misc[3]; ip->maxMergeCand = misc[4]; ip->checkLDC = misc[5]; ip->cabacInitType = misc[6];

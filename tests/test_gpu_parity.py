@@ -47,7 +47,7 @@ def test_hip_p_slices_match_reference_fixture(hm, name):
     """encoder_lowdelay_P_main.cfg clips: every P slice through hm355_compress_slice_inter with the reference pictures and
     slice parameters the reference's compressSlice saw; decisions, motion, coefficients, costs, reconstruction bit-exact."""
     cfg, slices, finals = common.load_ldp_case(name)
-    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 0, max_batch=1)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=1)
     n_p = 0
     for r in slices:
         if int(r["slice_type"]) != 1:
@@ -60,15 +60,17 @@ def test_hip_p_slices_match_reference_fixture(hm, name):
             assert np.array_equal(rec[c], r["rec"][c]), f"{name} POC {int(r['poc'])}: reconstruction plane {c}"
         assert stats[0] == int(ctus["total_bits"].sum())
         n_p += 1
-    assert n_p >= 4
+    assert n_p >= 3
     enc.close()
 
 
-def test_hip_p_slice_rejects_wavefront(hm):
+def test_hip_p_slice_rejects_b_slices(hm):
     cfg, slices, finals = common.load_ldp_case(common.LDP_CASES[0])
     r = [s for s in slices if int(s["slice_type"]) == 1][0]
-    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 1, max_batch=1)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 0, max_batch=1)
     sp, refs = common.ldp_slice_inputs(r, finals)
+    sp["num_ref_idx"] = (sp["num_ref_idx"][0], 1)
+    sp["ref_poc"] = np.array(sp["ref_poc"]); sp["ref_poc"][1][0] = sp["ref_poc"][0][0]
     with pytest.raises(RuntimeError):
         enc.compress_inter(synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"]), sp, refs)
     enc.close()

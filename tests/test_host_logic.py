@@ -40,27 +40,26 @@ def test_create_rejects_bad_config_and_missing_gpu():
         assert rc == -2, "hm355_create must fail with HM355_ERR_NO_DEVICE when there is no GPU"
 
 
-def _schedule(wc, hc, wpp, frames):
+def _schedule(wc, hc, wpp, frames, carry=0):
     """python mirror of hm355_build_schedule (hm355_host_common.h) for property checks"""
-    steps = wc + 2 * (hc - 1) if wpp else wc * hc
-    out = []
-    for s in range(steps):
-        items = []
-        for f in range(frames):
-            if wpp:
-                for y in range(hc):
-                    x = s - 2 * y
-                    if 0 <= x < wc:
-                        items.append((f, x, y))
-            else:
-                items.append((f, s % wc, s // wc))
-        out.append(items)
+    def step(x, y):
+        if not wpp:
+            return y * wc + x
+        if carry and hc > 1 and wc > 1 and y == hc - 1:
+            return (wc - 1) + 2 * (hc - 2) + 1 + x
+        return x + 2 * y
+    out = [[] for _ in range(step(wc - 1, hc - 1) + 1)]
+    for f in range(frames):
+        for y in range(hc):
+            for x in range(wc):
+                out[step(x, y)].append((f, x, y))
     return out
 
 
-@pytest.mark.parametrize("wc,hc,wpp", [(7, 4, 1), (7, 4, 0), (60, 34, 1), (1, 3, 1), (2, 2, 1)])
-def test_schedule_respects_dependencies(wc, hc, wpp):
-    sched = _schedule(wc, hc, wpp, 2)
+@pytest.mark.parametrize("wc,hc,wpp,carry", [(7, 4, 1, 0), (7, 4, 0, 0), (60, 34, 1, 0), (1, 3, 1, 0), (2, 2, 1, 0), (7, 4, 1, 1), (30, 17, 1, 1),
+                                             (1, 3, 1, 1), (2, 2, 1, 1)])
+def test_schedule_respects_dependencies(wc, hc, wpp, carry):
+    sched = _schedule(wc, hc, wpp, 2, carry)
     done = {}
     for s, items in enumerate(sched):
         for (f, x, y) in items:
@@ -70,6 +69,8 @@ def test_schedule_respects_dependencies(wc, hc, wpp):
                 deps.append((px, py))
             if wpp and x == 0 and y > 0 and wc > 1:
                 deps.append((1, y - 1))
+            if carry and x == 0 and y == hc - 1 and y > 0:      # P slice, last CTU row cut by the picture edge
+                deps.append((wc - 1, y - 1))
             for (dx, dy) in deps:
                 if 0 <= dx < wc and 0 <= dy < hc:
                     assert done.get((f, dx, dy), 10 ** 9) < s, f"CTU {(x, y)} scheduled before {(dx, dy)}"
@@ -97,3 +98,23 @@ def test_hostsim_of_kernel_source_matches_reference_fixture(tmp_path):
         for i, (ctus, rec) in enumerate(frames):
             common.assert_ctus_equal(got[i][0], ctus, f"{exe} frame {i}", (cfg["width"], cfg["height"]))
             assert np.array_equal(got[i][1], rec)
+
+
+@pytest.mark.parametrize("name", common.LDP_CASES[1:])
+def test_hostsim_of_kernel_source_matches_reference_p_slices(tmp_path, name):
+    """The P-slice part of the kernel source (hm355_inter.h / hm355_inter_cu.h) compiled for the host with one lane, forwards and
+    with every lane-parallel loop reversed: self-checking replay of the reference's HMD2 record stream (rebuilt from the fixture)."""
+    import synth
+    import hmd2
+    recs = []
+    cfg, _, _ = common.load_ldp_case(name, recs)
+    yuv, dump = tmp_path / "in.yuv", tmp_path / "dump2.bin"
+    synth.write_yuv(str(yuv), cfg["width"], cfg["height"], cfg["bit_depth"], cfg["frames"], cfg["seed"])
+    hmd2.write(str(dump), recs)
+    for flag, exe in (("", "hostsim_inter"), ("-DHM355_HOSTSIM_REVERSE", "hostsim_inter_rev")):
+        out = tmp_path / exe
+        cmd = ["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-w"] + ([flag] if flag else []) + ["-o", str(out), os.path.join(ROOT, "tests", "hostsim", "hostsim_inter.cpp")]
+        subprocess.run(cmd, check=True)
+        r = subprocess.run([str(out), str(yuv), str(dump), str(cfg["width"]), str(cfg["height"]), str(cfg["bit_depth"]), str(cfg["wpp"])],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and "all bit-exact" in r.stdout, r.stdout[-2000:]
