@@ -96,8 +96,60 @@ def cpu_baseline(width, bit_depth, qp, seed):
     return {"value": n_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port", "sample": sample}
 
 
+def run_ldp_p(args, torch):
+    """Secondary workload (BASELINE.json configs[2], the inter ME path): P slices of encoder_lowdelay_P_main, synthetic 1920x1080 8-bit,
+    4 reference pictures, SearchRange 64, `--frames` independent streams per step (one current picture each, WaveFrontSynchro=1).
+    The reference pictures are HIP-path I-slice reconstructions of the same clip.  Reference pictures enter through host buffers in
+    this entry point, so `value` is CTUs / HIP-event kernel time and `call_s` is the PCIe-inclusive wall time of the call."""
+    import math
+    import hm355
+    import synth
+    w, h, bd, qp, nref, S = 1920, 1080, 8, args.qp, 4, args.frames
+    enc = hm355.Encoder(w, h, bd, 1, max(S, nref))
+    n = enc.num_ctus
+    frames = [synth.frame(w, h, bd, i, 1234) for i in range(nref + min(S, 4))]
+    res = enc.compress(frames[:nref], qp)
+    refs = {}
+    for i in range(nref):
+        refs[i] = dict(slice_type=2, rec=res[i][0], pred_mode=np.ones((n, 256), np.uint8), mv=[np.zeros((n, 256, 2), np.int16)] * 2,
+                       ref_idx=[np.full((n, 256), -1, np.int8)] * 2, num_ref_idx=(0, 0), ref_poc=np.zeros((2, 16), np.int32),
+                       ref_long_term=np.zeros((2, 16), np.int32))
+    qpp = qp + 3                                                       # QPoffset of the first GOP entry (cfg/encoder_lowdelay_P_main.cfg:24)
+    lam = 0.4624 * 2.0 ** ((qpp - 12) / 3.0) * min(4.0, max(2.0, (qpp - 12) / 6.0))      # TEncSlice.cpp:323-352
+    ref_poc = np.zeros((2, 16), np.int32)
+    ref_poc[0, :nref] = list(range(nref - 1, -1, -1))
+    sp = dict(qp=qpp, chroma_weight=hm355.intra_lambda(qpp)[1], poc=nref, cabac_init_type=1, num_ref_idx=(nref, 0), ref_poc=ref_poc,
+              col_from_l0=1, col_ref_idx=0, tmvp=1, mvd_l1_zero=0, max_merge_cand=5, check_ldc=1,
+              lambda_motion_sad=int(math.floor(65536.0 * math.sqrt(lam))), lambda_motion_sse=int(math.floor(65536.0 * lam)))
+    sp["lambda"] = lam
+    jobs = [(frames[nref + (s % min(S, 4))], sp, refs) for s in range(S)]
+    kernel_ms, wall = 0.0, 0.0
+    for it in range(args.warmup + args.steps):
+        t0 = time.perf_counter()
+        enc.compress_inter_batch(jobs)
+        torch.cuda.synchronize()
+        k, l = hm355.C.c_double(), hm355.C.c_int()
+        enc.lib.hm355_last_run_info(enc.h_, hm355.C.byref(k), hm355.C.byref(l))
+        if it >= args.warmup:
+            kernel_ms += k.value
+            wall += time.perf_counter() - t0
+    ctus = n * S * args.steps
+    alg = 54278 + nref * 80000 + 4608                                  # SURVEY 8(d): intra bytes + search window per reference + MV fields
+    ach = alg * ctus / (kernel_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "CTUs/sec (enc), P slices, 1080p 8-bit; bit-exact CU partition / MV vs HM", "value": ctus / (kernel_ms * 1e-3), "unit": "CTU/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": kernel_ms / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic", "call_s": wall / args.steps,
+        "config": {"workload": f"encoder_lowdelay_P_main P slices, synthetic 1920x1080 8-bit, {nref} references, SearchRange 64, QP {qpp}, "
+                               f"WaveFrontSynchro=1, {S} independent streams per step", "streams": S, "ctus_per_step": n * S},
+        "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                     "traffic": None, "note": f"algorithmic bytes {alg} B/CTU (SURVEY 8d, {nref} references)"}}))
+    enc.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
@@ -115,6 +167,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: hm355 has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    if args.workload == "ldp_p":
+        if world > 1:
+            raise SystemExit("--workload ldp_p is a single-GPU measurement")
+        return run_ldp_p(args, torch)
     dist = None
     if world > 1:
         import torch.distributed as dist

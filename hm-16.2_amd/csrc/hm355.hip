@@ -198,7 +198,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   }
   P.tab = c->dTab; P.ws = c->dWs; P.frames = c->dFrames; P.prof = NULL;
 #ifdef HM355_PROFILE
-  HM_CHECK(c, hipMalloc((void **)&P.prof, 64 * sizeof(unsigned long long))); HM_CHECK(c, hipMemset(P.prof, 0, 64 * sizeof(unsigned long long)));
+  HM_CHECK(c, hipMalloc((void **)&P.prof, 2 * HM_PROF_N * sizeof(unsigned long long))); HM_CHECK(c, hipMemset(P.prof, 0, 2 * HM_PROF_N * sizeof(unsigned long long)));
 #elif defined(HM355_TRACE)
   HM_CHECK(c, hipMalloc((void **)&P.prof, (1 + 3 * (size_t)HM_TRACE_CAP) * sizeof(unsigned long long))); HM_CHECK(c, hipMemset(P.prof, 0, sizeof(unsigned long long)));
 #endif
@@ -360,80 +360,112 @@ extern "C" int hm355_compress_slice(hm355_ctx *c, const hm355_slice_desc *slice,
 }
 
 // ------------------------------------------------------------------------------------------------
-// P slice: reference pictures are uploaded per call (border-extended like TComPicYuv::extendPicBorder), slot 0 is used
+// P slices: reference pictures are uploaded per call (border-extended like TComPicYuv::extendPicBorder); the n pictures
+// of one call are independent of each other (e.g. the current pictures of n streams) and run concurrently
 // ------------------------------------------------------------------------------------------------
 static_assert(sizeof(hm355_ctu_inter_out) == sizeof(InterMeta), "hm355_ctu_inter_out mirrors InterMeta");
+namespace {
+struct DevAllocs {                     // device allocations that live for one call
+  std::vector<void *> p;
+  ~DevAllocs() { for (size_t i = 0; i < p.size(); i++) hipFree(p[i]); }
+  template <class T> hipError_t make(T **out, size_t count, const void *src)
+  {
+    *out = NULL;
+    hipError_t e = hipMalloc((void **)out, count * sizeof(T));
+    if (e != hipSuccess) return e;
+    p.push_back(*out);
+    return src ? hipMemcpy(*out, src, count * sizeof(T), hipMemcpyHostToDevice) : hipMemset(*out, 0, count * sizeof(T));
+  }
+};
+}
+static hipError_t upload_ref_pic(hm355_ctx *c, const hm355_ref_pic *hp, DevAllocs &da, RefPicDev *out)
+{
+  const Params &P = c->hp;
+  RefPicDev r; memset(&r, 0, sizeof(r));
+  hipError_t e = hipSuccess;
+  for (int cc = 0; cc < 3 && e == hipSuccess; cc++) {
+    const int cw = P.width >> (cc ? 1 : 0), ch = P.height >> (cc ? 1 : 0), mg = HM_REF_MARGIN >> (cc ? 1 : 0), st = cw + 2 * mg;
+    std::vector<Pel> buf((size_t)st * (ch + 2 * mg));
+    for (int y = -mg; y < ch + mg; y++) {
+      const int sy = y < 0 ? 0 : (y >= ch ? ch - 1 : y);
+      Pel *d = buf.data() + (size_t)(y + mg) * st + mg;
+      const uint16_t *srow = hp->plane[cc] + (size_t)sy * cw;
+      for (int x = 0; x < cw; x++) d[x] = (Pel)srow[x];
+      for (int x = 1; x <= mg; x++) { d[-x] = (Pel)srow[0]; d[cw - 1 + x] = (Pel)srow[cw - 1]; }
+    }
+    Pel *dv = NULL; e = da.make(&dv, buf.size(), buf.data());
+    r.plane[cc] = dv + (size_t)mg * st + mg; r.stride[cc] = st;
+  }
+  const size_t np = (size_t)c->numCtus * 256;
+  uint8_t *dpm = NULL; if (e == hipSuccess) e = da.make(&dpm, np, hp->pred_mode);
+  r.predMode = dpm;
+  for (int l = 0; l < 2 && e == hipSuccess; l++) {
+    MvD *dm = NULL; int8_t *dr = NULL;
+    e = da.make(&dm, np, hp->mv[l]); if (e == hipSuccess) e = da.make(&dr, np, hp->ref_idx[l]);
+    r.mv[l] = dm; r.refIdx[l] = dr;
+    memcpy(r.refPoc[l], hp->ref_poc[l], sizeof(r.refPoc[l])); memcpy(r.refLT[l], hp->ref_lt[l], sizeof(r.refLT[l]));
+  }
+  r.poc = hp->poc; r.isLongTerm = hp->long_term;
+  *out = r;
+  return e;
+}
+extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inter_slice_desc *slices, const hm355_planes *org,
+                                           hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_ctu_inter_out *const *ictus, hm355_slice_stats *stats)
+{
+  if (!c || !slices || !org || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  for (int f = 0; f < n; f++) {
+    const hm355_inter_slice_desc *sd = slices + f;
+    if (sd->base.slice_type != 1) return fail(c, HM355_ERR_ARG, "hm355_compress_slices_inter: only P slices");
+    if (sd->num_ref_idx[0] < 1 || sd->num_ref_idx[0] > 16 || sd->num_ref_idx[1] != 0 || sd->max_merge_cand < 1 || sd->max_merge_cand > 5 ||
+        (sd->cabac_init_type != 0 && sd->cabac_init_type != 1)) return fail(c, HM355_ERR_ARG, "bad P slice parameters");
+    for (int i = 0; i < sd->num_ref_idx[0]; i++) {
+      const hm355_ref_pic *hp = sd->ref[0][i];
+      if (!hp || !hp->plane[0] || !hp->plane[1] || !hp->plane[2] || !hp->pred_mode || !hp->mv[0] || !hp->mv[1] || !hp->ref_idx[0] || !hp->ref_idx[1])
+        return fail(c, HM355_ERR_ARG, "null reference picture data");
+    }
+  }
+  int rc;
+  for (int f = 0; f < n; f++) if ((rc = hm355_upload(c, f, org + f)) != HM355_OK) return rc;
+  DevAllocs da;
+  std::vector<const hm355_ref_pic *> seen; std::vector<RefPicDev> devRefs;     // a picture referenced several times is uploaded once
+  std::vector<InterMeta *> dIm(n, (InterMeta *)NULL);
+  std::vector<hm355_slice_desc> base(n);
+  hipError_t e = hipSuccess;
+  for (int f = 0; f < n && e == hipSuccess; f++) {
+    const hm355_inter_slice_desc *sd = slices + f;
+    InterPic hip; memset(&hip, 0, sizeof(hip));
+    hip.sliceType = 1; hip.poc = sd->poc; hip.numRefIdx[0] = sd->num_ref_idx[0]; hip.numRefIdx[1] = 0;
+    hip.colFromL0 = sd->col_from_l0; hip.colRefIdx = sd->col_ref_idx; hip.tmvp = sd->tmvp; hip.mvdL1Zero = sd->mvd_l1_zero;
+    hip.maxMergeCand = sd->max_merge_cand; hip.checkLDC = sd->check_ldc; hip.cabacInitType = sd->cabac_init_type;
+    hip.lambdaMotionSAD = sd->lambda_motion_sad; hip.lambdaMotionSSE = sd->lambda_motion_sse;
+    for (int i = 0; i < sd->num_ref_idx[0] && e == hipSuccess; i++) {
+      const hm355_ref_pic *hp = sd->ref[0][i];
+      size_t k = 0; for (; k < seen.size(); k++) if (seen[k] == hp) break;
+      if (k == seen.size()) { RefPicDev r; e = upload_ref_pic(c, hp, da, &r); seen.push_back(hp); devRefs.push_back(r); }
+      hip.ref[0][i] = devRefs[k];
+    }
+    FrameBuf &fb = c->slots[f].fb;
+    InterPic *dIp = NULL; MvD *dIntMv = NULL;
+    if (e == hipSuccess) e = da.make(&dIp, 1, &hip);
+    if (e == hipSuccess) e = da.make(&dIm[f], (size_t)c->numCtus, NULL);
+    if (e == hipSuccess) e = da.make(&dIntMv, (size_t)c->numCtus * 16, NULL);
+    fb.imeta = dIm[f]; fb.ip = dIp; fb.intMv = dIntMv;
+    base[f] = sd->base; base[f].slice_type = 2;            // hm355_run validates the common fields
+  }
+  if (e != hipSuccess) { c->err = std::string("reference picture upload: ") + hipGetErrorString(e); rc = HM355_ERR_DEVICE; }
+  else rc = hm355_run(c, n, base.data());
+  for (int f = 0; f < n && rc == HM355_OK; f++) {
+    rc = hm355_download(c, f, rec ? rec + f : NULL, ctus ? ctus[f] : NULL, stats ? stats + f : NULL);
+    if (rc == HM355_OK && ictus && ictus[f] && hipMemcpy(ictus[f], dIm[f], sizeof(InterMeta) * c->numCtus, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "motion download failed"; rc = HM355_ERR_DEVICE; }
+  }
+  for (int f = 0; f < n; f++) { FrameBuf &fb = c->slots[f].fb; fb.imeta = NULL; fb.ip = NULL; fb.intMv = NULL; }
+  return rc;
+}
 extern "C" int hm355_compress_slice_inter(hm355_ctx *c, const hm355_inter_slice_desc *sd, const hm355_planes *org,
                                           hm355_planes *rec, hm355_ctu_out *ctus, hm355_ctu_inter_out *ictus, hm355_slice_stats *stats)
 {
-  if (!c || !sd || !org) return HM355_ERR_ARG;
-  const Params &P = c->hp;
-  if (sd->base.slice_type != 1) return fail(c, HM355_ERR_ARG, "hm355_compress_slice_inter: only P slices");
-  if (sd->num_ref_idx[0] < 1 || sd->num_ref_idx[0] > 16 || sd->num_ref_idx[1] != 0 || sd->max_merge_cand < 1 || sd->max_merge_cand > 5 ||
-      (sd->cabac_init_type != 0 && sd->cabac_init_type != 1)) return fail(c, HM355_ERR_ARG, "bad P slice parameters");
-  int rc = hm355_upload(c, 0, org);
-  if (rc != HM355_OK) return rc;
-  std::vector<void *> toFree;
-  InterPic hip; memset(&hip, 0, sizeof(hip));
-  hip.sliceType = 1; hip.poc = sd->poc; hip.numRefIdx[0] = sd->num_ref_idx[0]; hip.numRefIdx[1] = 0;
-  hip.colFromL0 = sd->col_from_l0; hip.colRefIdx = sd->col_ref_idx; hip.tmvp = sd->tmvp; hip.mvdL1Zero = sd->mvd_l1_zero;
-  hip.maxMergeCand = sd->max_merge_cand; hip.checkLDC = sd->check_ldc; hip.cabacInitType = sd->cabac_init_type;
-  hip.lambdaMotionSAD = sd->lambda_motion_sad; hip.lambdaMotionSSE = sd->lambda_motion_sse;
-  std::vector<const hm355_ref_pic *> seen; std::vector<RefPicDev> devRefs;
-  hipError_t e = hipSuccess;
-  for (int i = 0; i < sd->num_ref_idx[0] && e == hipSuccess; i++) {
-    const hm355_ref_pic *hp = sd->ref[0][i];
-    if (!hp || !hp->plane[0] || !hp->plane[1] || !hp->plane[2] || !hp->pred_mode || !hp->mv[0] || !hp->mv[1] || !hp->ref_idx[0] || !hp->ref_idx[1]) { rc = fail(c, HM355_ERR_ARG, "null reference picture data"); break; }
-    size_t k = 0; for (; k < seen.size(); k++) if (seen[k] == hp) break;
-    if (k == seen.size()) {
-      RefPicDev r; memset(&r, 0, sizeof(r));
-      for (int cc = 0; cc < 3 && e == hipSuccess; cc++) {
-        const int cw = P.width >> (cc ? 1 : 0), ch = P.height >> (cc ? 1 : 0), mg = HM_REF_MARGIN >> (cc ? 1 : 0), st = cw + 2 * mg;
-        std::vector<Pel> buf((size_t)st * (ch + 2 * mg));
-        for (int y = -mg; y < ch + mg; y++) {
-          const int sy = y < 0 ? 0 : (y >= ch ? ch - 1 : y);
-          Pel *d = buf.data() + (size_t)(y + mg) * st + mg;
-          for (int x = -mg; x < cw + mg; x++) { const int sx = x < 0 ? 0 : (x >= cw ? cw - 1 : x); d[x] = (Pel)hp->plane[cc][(size_t)sy * cw + sx]; }
-        }
-        Pel *dv = NULL; e = hipMalloc((void **)&dv, buf.size() * sizeof(Pel));
-        if (e == hipSuccess) { toFree.push_back(dv); e = hipMemcpy(dv, buf.data(), buf.size() * sizeof(Pel), hipMemcpyHostToDevice); }
-        r.plane[cc] = dv + (size_t)mg * st + mg; r.stride[cc] = st;
-      }
-      const size_t np = (size_t)c->numCtus * 256;
-      uint8_t *dpm = NULL; if (e == hipSuccess) e = hipMalloc((void **)&dpm, np);
-      if (e == hipSuccess) { toFree.push_back(dpm); e = hipMemcpy(dpm, hp->pred_mode, np, hipMemcpyHostToDevice); }
-      r.predMode = dpm;
-      for (int l = 0; l < 2 && e == hipSuccess; l++) {
-        MvD *dm = NULL; int8_t *dr = NULL;
-        e = hipMalloc((void **)&dm, np * sizeof(MvD)); if (e == hipSuccess) { toFree.push_back(dm); e = hipMemcpy(dm, hp->mv[l], np * sizeof(MvD), hipMemcpyHostToDevice); }
-        if (e == hipSuccess) e = hipMalloc((void **)&dr, np); if (e == hipSuccess) { toFree.push_back(dr); e = hipMemcpy(dr, hp->ref_idx[l], np, hipMemcpyHostToDevice); }
-        r.mv[l] = dm; r.refIdx[l] = dr;
-        memcpy(r.refPoc[l], hp->ref_poc[l], sizeof(r.refPoc[l])); memcpy(r.refLT[l], hp->ref_lt[l], sizeof(r.refLT[l]));
-      }
-      r.poc = hp->poc; r.isLongTerm = hp->long_term;
-      seen.push_back(hp); devRefs.push_back(r);
-    }
-    hip.ref[0][i] = devRefs[k];
-  }
-  FrameBuf &fb = c->slots[0].fb;
-  InterPic *dIp = NULL; InterMeta *dIm = NULL; MvD *dIntMv = NULL;
-  if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIntMv, sizeof(MvD) * 16 * c->numCtus);
-  if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIntMv); e = hipMemset(dIntMv, 0, sizeof(MvD) * 16 * c->numCtus); }
-  if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIp, sizeof(InterPic));
-  if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIp); e = hipMemcpy(dIp, &hip, sizeof(InterPic), hipMemcpyHostToDevice); }
-  if (rc == HM355_OK && e == hipSuccess) e = hipMalloc((void **)&dIm, sizeof(InterMeta) * c->numCtus);
-  if (rc == HM355_OK && e == hipSuccess) { toFree.push_back(dIm); e = hipMemset(dIm, 0, sizeof(InterMeta) * c->numCtus); }
-  if (rc == HM355_OK && e != hipSuccess) { c->err = std::string("reference picture upload: ") + hipGetErrorString(e); rc = HM355_ERR_DEVICE; }
-  if (rc == HM355_OK) {
-    fb.imeta = dIm; fb.ip = dIp; fb.intMv = dIntMv;
-    hm355_slice_desc tmp = sd->base; tmp.slice_type = 2;          // hm355_run validates the common fields
-    rc = hm355_run(c, 1, &tmp);
-    if (rc == HM355_OK) rc = hm355_download(c, 0, rec, ctus, stats);
-    if (rc == HM355_OK && ictus && hipMemcpy(ictus, dIm, sizeof(InterMeta) * c->numCtus, hipMemcpyDeviceToHost) != hipSuccess) { c->err = "motion download failed"; rc = HM355_ERR_DEVICE; }
-    fb.imeta = NULL; fb.ip = NULL; fb.intMv = NULL;
-  }
-  for (size_t i = 0; i < toFree.size(); i++) hipFree(toFree[i]);
-  return rc;
+  hm355_ctu_out *cl[1] = { ctus }; hm355_ctu_inter_out *il[1] = { ictus };
+  return hm355_compress_slices_inter(c, 1, sd, org, rec, ctus ? cl : NULL, ictus ? il : NULL, stats);
 }
 
 // ------------------------------------------------------------------------------------------------

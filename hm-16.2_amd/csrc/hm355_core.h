@@ -149,14 +149,15 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 
 // optional in-kernel cycle accounting (diagnostic build only: -DHM355_PROFILE, never in the product build)
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-#define HM_PROF_N 16
+#define HM_PROF_N 32
 #define HM_PROF_BEGIN(e, id) const unsigned long long prof_t0_##id = __builtin_readcyclecounter()
 #define HM_PROF_END(e, id) do { (e)->prof[id] += __builtin_readcyclecounter() - prof_t0_##id; (e)->profCnt[id] += 1; } while (0)
 #else
 #define HM_PROF_BEGIN(e, id) ((void)0)
 #define HM_PROF_END(e, id) ((void)0)
 #endif
-enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBLK, PR_SAVE, PR_CHROMA, PR_LUMA, PR_ENCCU, PR_TOTAL };
+enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBLK, PR_SAVE, PR_CHROMA, PR_LUMA, PR_ENCCU, PR_TOTAL,
+       PR_ME_INT = 16, PR_ME_FRAC, PR_AMVP, PR_MRG_EST, PR_MC, PR_IRQ, PR_IRES, PR_MRG2N, PR_INTERCU, PR_INTRA_IN_P, PR_MRGCAND };
 
 #define HM_MAX_DOUBLE 1.7e+308
 #define PLANAR_IDX 0
@@ -2219,7 +2220,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
       f->boundary = !((lx + size - 1 < e->width) && (ty + size - 1 < e->height));
       f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
       if (!f->boundary && e->im) { // P slice: TEncCu.cpp:628-836
-        compress_cu_inter_modes(e, cuZ, cuDepth, sp);
+        { HM_PROF_BEGIN(e, PR_INTERCU); compress_cu_inter_modes(e, cuZ, cuDepth, sp); HM_PROF_END(e, PR_INTERCU); }
         reset_bits(&e->cur);
         if (cuDepth != 3) enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
         f->bestBits += num_bits(&e->cur);

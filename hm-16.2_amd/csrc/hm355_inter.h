@@ -506,7 +506,10 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   MvD mv = mvPred;
   const int useInt = (partSize != SIZE_2Nx2N || cuDepth != 0);
   MvD im = e->intMv[refIdx];
+  HM_PROF_BEGIN(e, PR_ME_INT);
   uint32_t c = tz_search(e, &z, &mv, cuX, cuY, lt, rb, useInt, im);
+  HM_PROF_END(e, PR_ME_INT);
+  HM_PROF_BEGIN(e, PR_ME_FRAC);
   if (partSize == SIZE_2Nx2N) e->intMv[refIdx] = mv;
   e->costScale = 1;
   const Pel *refAtInt = z.ref + (ptrdiff_t)mv.y * z.refStride + mv.x;
@@ -517,6 +520,7 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   qter.x = (int16_t)(((mv.x << 1) + half.x) << 1); qter.y = (int16_t)(((mv.y << 1) + half.y) << 1);
   c = pattern_refinement(e, &z, refAtInt, base, 1, &qter);
   mv.x = (int16_t)((mv.x << 2) + (half.x << 1) + qter.x); mv.y = (int16_t)((mv.y << 2) + (half.y << 1) + qter.y);
+  HM_PROF_END(e, PR_ME_FRAC);
   const uint32_t mvBits = mc_bits(e, mv.x, mv.y);
   const uint32_t bits = bitsIn + mvBits;
   e->outMv = mv; e->outBits = bits;
@@ -633,7 +637,9 @@ HM_DEV HM_NOINLINE void pred_inter_search(Shared *e, int cuZ, int cuDepth, int p
         uint32_t bitsTemp = mbBits, costTemp;
         if (s->numRefIdx[0] > 1) { bitsTemp += refIdx + 1; if (refIdx == s->numRefIdx[0] - 1) bitsTemp--; }
         AmvpInfo *info = &e->amvp; int mvpIdx;
+        HM_PROF_BEGIN(e, PR_AMVP);
         MvD mvPred = estimate_mvp_amvp(e, cuZ, cuDepth, partSize, puIdx, refIdx, info, &mvpIdx);
+        HM_PROF_END(e, PR_AMVP);
         const int mvpNum = info->n;
         bitsTemp += 1;
         motion_estimation(e, cuZ, cuDepth, partSize, puIdx, mvPred.x, mvPred.y, refIdx, bitsTemp);
@@ -666,7 +672,7 @@ HM_DEV HM_NOINLINE void pred_inter_search(Shared *e, int cuZ, int cuDepth, int p
       const int z0 = rect_z(r);
       const int meDir = m->interDir[z0];
       const MvD meMv = m->mv[0][z0]; const int meRef = m->refIdx[0][z0];
-      merge_estimation(e, cuZ, cuDepth, partSize, puIdx);
+      { HM_PROF_BEGIN(e, PR_MRG_EST); merge_estimation(e, cuZ, cuDepth, partSize, puIdx); HM_PROF_END(e, PR_MRG_EST); }
       if (e->mrgCost < meCost) {
         pu_set_u8(m->mrg, r, 1); pu_set_u8(m->mrgIdx, r, e->mrgIdx); pu_set_u8(m->interDir, r, e->mrgDir);
         pu_set_motion(e, r, 0, e->mrgField.mv, e->mrgField.ref); pu_set_motion(e, r, 1, zero, -1);
@@ -677,7 +683,7 @@ HM_DEV HM_NOINLINE void pred_inter_search(Shared *e, int cuZ, int cuDepth, int p
         pu_set_motion(e, r, 0, meMv, meRef); pu_set_motion(e, r, 1, zero, -1);
       }
     }
-    motion_compensation_pu(e, cuZ, r, e->ws->pred);
+    { HM_PROF_BEGIN(e, PR_MC); motion_compensation_pu(e, cuZ, r, e->ws->pred); HM_PROF_END(e, PR_MC); }
   }
 }
 
@@ -1097,7 +1103,7 @@ HM_DEV HM_NOINLINE void encode_res_and_calc_rd_inter(Shared *e, int cuZ, int cuD
   HM_SYNC();
   const TU root = tu_root(e, cuZ, cuDepth);
   cabac_copy(&e->cur, &ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
-  estimate_residual_qt(e, root);
+  { HM_PROF_BEGIN(e, PR_IRQ); estimate_residual_qt(e, root); HM_PROF_END(e, PR_IRQ); }
   const double dCost = e->outRdCost; dist = e->outDist;
   HM_TRACE(e, 6, e->outBits, e->outDist, dCost);
   const uint32_t zeroDist = e->irqZeroDist;

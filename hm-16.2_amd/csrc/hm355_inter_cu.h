@@ -32,7 +32,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_merge_2Nx2N(Shared *e, int cuZ, int cuDept
       par_set8(im->mrg + cuZ, 1, parts); par_set8(im->mrgIdx + cuZ, cand, parts); par_set8(im->interDir + cuZ, ml.dir[cand], parts);
       pu_set_motion(e, r, 0, ml.f[cand].mv, ml.f[cand].ref); pu_set_motion(e, r, 1, zero, -1);
       motion_compensation_pu(e, cuZ, r, e->ws->pred);
-      encode_res_and_calc_rd_inter(e, cuZ, cuDepth, noResidual != 0);
+      { HM_PROF_BEGIN(e, PR_IRES); encode_res_and_calc_rd_inter(e, cuZ, cuDepth, noResidual != 0); HM_PROF_END(e, PR_IRES); }
       if (noResidual == 0 && !qt_root_cbf(m, cuZ)) mergeCandBuffer[cand] = 1;
       par_set8(im->skip + cuZ, !qt_root_cbf(m, cuZ), parts);
       check_best_mode(e, f, cuZ, cuDepth);
@@ -49,7 +49,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_inter(Shared *e, int cuZ, int cuDepth, int
   init_est_data(e, cuZ, cuDepth);
   par_set8(m->part + cuZ, partSize, parts); par_set8(m->pred + cuZ, MODE_INTER, parts);
   pred_inter_search(e, cuZ, cuDepth, partSize, useMRG);
-  encode_res_and_calc_rd_inter(e, cuZ, cuDepth, 0);
+  { HM_PROF_BEGIN(e, PR_IRES); encode_res_and_calc_rd_inter(e, cuZ, cuDepth, 0); HM_PROF_END(e, PR_IRES); }
   check_best_mode(e, f, cuZ, cuDepth);
 }
 // the mode tests of one CU in a P slice (TEncCu::xCompressCU :600-857 with ESD/CFM/ECU off)
@@ -57,7 +57,7 @@ HM_DEV HM_NOINLINE void compress_cu_inter_modes(Shared *e, int cuZ, int cuDepth,
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp);
   CuFrame *f = &e->cuf[sp];
-  check_rd_cost_merge_2Nx2N(e, cuZ, cuDepth, sp);
+  { HM_PROF_BEGIN(e, PR_MRG2N); check_rd_cost_merge_2Nx2N(e, cuZ, cuDepth, sp); HM_PROF_END(e, PR_MRG2N); }
   check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2Nx2N, 0, sp);
   check_rd_cost_inter(e, cuZ, cuDepth, SIZE_Nx2N, 0, sp);
   check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxN, 0, sp);
@@ -80,8 +80,10 @@ HM_DEV HM_NOINLINE void compress_cu_inter_modes(Shared *e, int cuZ, int cuDepth,
   { // intra only when the best inter mode left a residual ("avoid very complex intra if it is unlikely", :820)
     const Best *b = &e->ws->best[cuDepth];
     if (b->m.cbf[0][cuZ] != 0 || b->m.cbf[1][cuZ] != 0 || b->m.cbf[2][cuZ] != 0) {
+      HM_PROF_BEGIN(e, PR_INTRA_IN_P);
       check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N); check_best_mode(e, f, cuZ, cuDepth);
       if (cuDepth == 3) { check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN); check_best_mode(e, f, cuZ, cuDepth); }
+      HM_PROF_END(e, PR_INTRA_IN_P);
     }
   }
 }

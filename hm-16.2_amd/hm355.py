@@ -62,7 +62,7 @@ CTU_INTER_DTYPE = np.dtype([("skip", "u1", 256), ("merge_flag", "u1", 256), ("me
                             ("ref_idx", "i1", (2, 256)), ("mvp_idx", "i1", (2, 256)), ("mvp_num", "i1", (2, 256))])
 
 EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
-           "hm355_compress_slice_inter",
+           "hm355_compress_slice_inter", "hm355_compress_slices_inter",
            "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
@@ -86,6 +86,8 @@ def load_library(path=LIB_PATH):
                                          C.POINTER(SliceStats)]
     lib.hm355_compress_slice_inter.argtypes = [C.c_void_p, C.POINTER(InterSliceDesc), C.POINTER(Planes), C.POINTER(Planes), C.c_void_p,
                                                C.c_void_p, C.POINTER(SliceStats)]
+    lib.hm355_compress_slices_inter.argtypes = [C.c_void_p, C.c_int, C.POINTER(InterSliceDesc), C.POINTER(Planes), C.POINTER(Planes),
+                                                C.c_void_p, C.c_void_p, C.POINTER(SliceStats)]
     lib.hm355_dist_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hm355_transform_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
@@ -170,49 +172,63 @@ class Encoder:
         self.run(len(frames), qp)
         return [self.download(i) for i in range(len(frames))]
 
-    def compress_inter(self, planes, slice_params, ref_pics):
-        """One P slice through hm355_compress_slice_inter.
-        slice_params: dict with qp, lambda, chroma_weight, poc, cabac_init_type, num_ref_idx, ref_poc (per list),
-        col_from_l0, col_ref_idx, tmvp, mvd_l1_zero, max_merge_cand, check_ldc, lambda_motion_sad, lambda_motion_sse;
-        ref_pics: {poc: dict(slice_type, rec=[3 planes], pred_mode, mv=[2], ref_idx=[2], num_ref_idx, ref_poc, ref_long_term)}.
-        Returns (rec planes, ctus, inter ctus, stats)."""
-        sp = slice_params
-        keep, refs = [], {}
-        for poc, f in ref_pics.items():
-            pl = [np.ascontiguousarray(p, np.uint16) for p in f["rec"]]
-            pm = np.ascontiguousarray(f["pred_mode"], np.uint8)
-            mv = [np.ascontiguousarray(f["mv"][l], np.int16) for l in range(2)]
-            ri = [np.ascontiguousarray(f["ref_idx"][l], np.int8) for l in range(2)]
-            keep += pl + [pm] + mv + ri
-            r = RefPic()
-            r.poc, r.slice_type, r.long_term = int(poc), int(f["slice_type"]), 0
-            for c in range(3):
-                r.plane[c] = pl[c].ctypes.data
-            r.pred_mode = pm.ctypes.data
+    def compress_inter_batch(self, jobs):
+        """n independent P slices through hm355_compress_slices_inter.  jobs: list of (planes, slice_params, ref_pics) with
+        slice_params: dict with qp, lambda, chroma_weight, poc, cabac_init_type, num_ref_idx, ref_poc (per list), col_from_l0,
+        col_ref_idx, tmvp, mvd_l1_zero, max_merge_cand, check_ldc, lambda_motion_sad, lambda_motion_sse;
+        ref_pics: {poc: dict(slice_type, rec=[3 planes], pred_mode, mv=[2], ref_idx=[2], num_ref_idx, ref_poc, ref_long_term)}
+        (a ref_pics dict object shared by several jobs is uploaded once).  Returns [(rec planes, ctus, inter ctus, stats)]."""
+        n = len(jobs)
+        keep, conv = [], {}
+        descs = (InterSliceDesc * n)()
+        orgs, recs, po, pr = [], [], (Planes * n)(), (Planes * n)()
+        ctus = [np.zeros(self.num_ctus, CTU_DTYPE) for _ in range(n)]
+        ictus = [np.zeros(self.num_ctus, CTU_INTER_DTYPE) for _ in range(n)]
+        for k, (planes, sp, ref_pics) in enumerate(jobs):
+            if id(ref_pics) not in conv:
+                refs = {}
+                for poc, f in ref_pics.items():
+                    pl = [np.ascontiguousarray(p, np.uint16) for p in f["rec"]]
+                    pm = np.ascontiguousarray(f["pred_mode"], np.uint8)
+                    mv = [np.ascontiguousarray(f["mv"][l], np.int16) for l in range(2)]
+                    ri = [np.ascontiguousarray(f["ref_idx"][l], np.int8) for l in range(2)]
+                    keep += pl + [pm] + mv + ri
+                    r = RefPic()
+                    r.poc, r.slice_type, r.long_term = int(poc), int(f["slice_type"]), 0
+                    for c in range(3):
+                        r.plane[c] = pl[c].ctypes.data
+                    r.pred_mode = pm.ctypes.data
+                    for l in range(2):
+                        r.mv[l] = mv[l].ctypes.data; r.ref_idx[l] = ri[l].ctypes.data; r.num_ref[l] = int(f["num_ref_idx"][l])
+                        for i in range(16):
+                            r.ref_poc[l][i] = int(f["ref_poc"][l][i]); r.ref_lt[l][i] = int(f["ref_long_term"][l][i])
+                    refs[int(poc)] = r
+                conv[id(ref_pics)] = refs
+            refs = conv[id(ref_pics)]
+            s = descs[k]
+            s.base = SliceDesc(1, int(sp["qp"]), float(sp["lambda"]), float(sp["chroma_weight"]))
+            s.poc, s.cabac_init_type = int(sp["poc"]), int(sp["cabac_init_type"])
             for l in range(2):
-                r.mv[l] = mv[l].ctypes.data; r.ref_idx[l] = ri[l].ctypes.data; r.num_ref[l] = int(f["num_ref_idx"][l])
-                for i in range(16):
-                    r.ref_poc[l][i] = int(f["ref_poc"][l][i]); r.ref_lt[l][i] = int(f["ref_long_term"][l][i])
-            refs[int(poc)] = r
-        s = InterSliceDesc()
-        s.base = SliceDesc(1, int(sp["qp"]), float(sp["lambda"]), float(sp["chroma_weight"]))
-        s.poc, s.cabac_init_type = int(sp["poc"]), int(sp["cabac_init_type"])
-        for l in range(2):
-            s.num_ref_idx[l] = int(sp["num_ref_idx"][l])
-            for i in range(s.num_ref_idx[l]):
-                s.ref[l][i] = C.pointer(refs[int(sp["ref_poc"][l][i])])
-        for k in ("col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "lambda_motion_sad",
-                  "lambda_motion_sse"):
-            setattr(s, k, int(sp[k]))
-        org = [np.ascontiguousarray(p, np.uint16) for p in planes]
-        rec = [np.zeros_like(p) for p in org]
-        po, pr = _planes(org), _planes(rec)
-        ctus, ictus = np.zeros(self.num_ctus, CTU_DTYPE), np.zeros(self.num_ctus, CTU_INTER_DTYPE)
-        st = SliceStats()
-        self._check(self.lib.hm355_compress_slice_inter(self.h_, C.byref(s), C.byref(po), C.byref(pr), ctus.ctypes.data,
-                                                        ictus.ctypes.data, C.byref(st)), "hm355_compress_slice_inter")
+                s.num_ref_idx[l] = int(sp["num_ref_idx"][l])
+                for i in range(s.num_ref_idx[l]):
+                    s.ref[l][i] = C.pointer(refs[int(sp["ref_poc"][l][i])])
+            for key in ("col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "lambda_motion_sad",
+                        "lambda_motion_sse"):
+                setattr(s, key, int(sp[key]))
+            org = [np.ascontiguousarray(p, np.uint16) for p in planes]
+            rec = [np.zeros_like(p) for p in org]
+            orgs.append(org); recs.append(rec)
+            po[k], pr[k] = _planes(org), _planes(rec)
+        pc = (C.c_void_p * n)(*[a.ctypes.data for a in ctus])
+        pi = (C.c_void_p * n)(*[a.ctypes.data for a in ictus])
+        st = (SliceStats * n)()
+        self._check(self.lib.hm355_compress_slices_inter(self.h_, n, descs, po, pr, pc, pi, st), "hm355_compress_slices_inter")
         del keep
-        return rec, ctus, ictus, (st.pic_total_bits, st.pic_rd_cost, st.pic_dist)
+        return [(recs[k], ctus[k], ictus[k], (st[k].pic_total_bits, st[k].pic_rd_cost, st[k].pic_dist)) for k in range(n)]
+
+    def compress_inter(self, planes, slice_params, ref_pics):
+        """One P slice (see compress_inter_batch)."""
+        return self.compress_inter_batch([(planes, slice_params, ref_pics)])[0]
 
     def dist_batch(self, kind, org, cur, bit_depth):
         """org/cur: (count, n, n) int16; kind 0 SAD, 1 SSE, 2 SATD, 3 SAD with row sub-sampling"""

@@ -120,6 +120,10 @@ typedef struct {
 } hm355_ctu_inter_out;
 int hm355_compress_slice_inter(hm355_ctx *ctx, const hm355_inter_slice_desc *slice, const hm355_planes *org,
                                hm355_planes *rec, hm355_ctu_out *ctus, hm355_ctu_inter_out *ictus, hm355_slice_stats *stats);
+/* n P pictures that do not reference each other (the current pictures of n streams, or of n independent GOP chains),
+ * evaluated concurrently; a hm355_ref_pic named by several slices is uploaded once.  n <= max_batch. */
+int hm355_compress_slices_inter(hm355_ctx *ctx, int n, const hm355_inter_slice_desc *slices, const hm355_planes *org,
+                                hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_ctu_inter_out *const *ictus, hm355_slice_stats *stats);
 
 /* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
  * Upload / run / download are separate so that a caller can keep pictures resident. */

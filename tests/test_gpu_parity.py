@@ -64,6 +64,23 @@ def test_hip_p_slices_match_reference_fixture(hm, name):
     enc.close()
 
 
+def test_hip_p_slice_batch_equals_single(hm):
+    """P pictures of one call are independent: all P slices of a clip in one batch == the fixture (each with its own references)"""
+    name = common.LDP_CASES[2]
+    cfg, slices, finals = common.load_ldp_case(name)
+    ps = [r for r in slices if int(r["slice_type"]) == 1]
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=len(ps))
+    jobs = []
+    for r in ps:
+        sp, refs = common.ldp_slice_inputs(r, finals)
+        jobs.append((synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"]), sp, refs))
+    for r, (rec, ctus, ictus, stats) in zip(ps, enc.compress_inter_batch(jobs)):
+        common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], f"{name} POC {int(r['poc'])} (batched)")
+        for c in range(3):
+            assert np.array_equal(rec[c], r["rec"][c])
+    enc.close()
+
+
 def test_hip_p_slice_rejects_b_slices(hm):
     cfg, slices, finals = common.load_ldp_case(common.LDP_CASES[0])
     r = [s for s in slices if int(s["slice_type"]) == 1][0]

@@ -9,7 +9,8 @@ w, h, wpp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 qp = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 nref = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 bd = 8
-enc = hm355.Encoder(w, h, bd, wpp, 1)
+lib = hm355.load_library(os.environ["HM355_LIB"]) if os.environ.get("HM355_LIB") else None
+enc = hm355.Encoder(w, h, bd, wpp, 1, lib=lib)
 n = enc.num_ctus
 refs = {}
 for i in range(nref):
@@ -30,3 +31,13 @@ ms, _ = hm355.C.c_double(), None
 k = hm355.C.c_double(); l = hm355.C.c_int(); enc.lib.hm355_last_run_info(enc.h_, hm355.C.byref(k), hm355.C.byref(l))
 print(f"{w}x{h} wpp={wpp} refs={nref}: {n} CTUs, kernel {k.value:.1f} ms ({n / k.value * 1000:.2f} CTU/s), wall {dt * 1000:.0f} ms; "
       f"skip {float((ictus['skip'] != 0).mean()):.2f} merge {float((ictus['merge_flag'] != 0).mean()):.2f} intra {float((ctus['pred_mode'] == 1).mean()):.2f} bits {st[0]}")
+if lib is not None and hasattr(lib, "hm355_read_profile"):
+    NP = 32
+    out = (hm355.C.c_ulonglong * (2 * NP))()
+    lib.hm355_read_profile.argtypes = [hm355.C.c_void_p, hm355.C.c_void_p]
+    lib.hm355_read_profile(enc.h_, out)
+    names = {0: "RDOQ", 1: "BITS", 2: "ADI", 3: "PRED", 4: "FWD", 5: "INV", 6: "SATD35", 8: "SAVE", 9: "CHROMA", 10: "LUMA", 11: "ENCCU", 12: "TOTAL",
+             16: "ME_INT", 17: "ME_FRAC", 18: "AMVP", 19: "MRG_EST", 20: "MC", 21: "IRQ", 22: "IRES", 23: "MRG2N", 24: "INTERCU", 25: "INTRA_IN_P"}
+    tot = out[12]
+    for i, nm in names.items():
+        print(f"{nm:10s} {100.0 * out[i] / tot:6.2f}%  calls {out[NP + i]:9d}  cyc/call {out[i] / max(1, out[NP + i]):10.0f}")
