@@ -272,6 +272,7 @@ typedef struct {
   uint32_t mcost; Mv mvPredictor; int costScale;
   /* TEncSearch::m_integerMv2Nx2N[list][refIdx]: integer MV of the last 2Nx2N ME on that reference (persists across CUs) */
   Mv integerMv2Nx2N[2][16];
+  int list1ToList0[16];            /* TComSlice::m_list1IdxToList0Idx (setList1IdxToList0Idx, TComSlice.cpp) */
 } InterSlice;
 
 typedef struct {
@@ -294,6 +295,8 @@ typedef struct {
   /* per-trial scratch, CTU-relative */
   Pel pred[3][64 * 64], resi[3][64 * 64], reco[3][64 * 64];
   Pel tmpPred[3][64 * 64];         /* m_tmpYuvPred (merge / ME prediction error) */
+  Pel yuvPred[2][3][64 * 64];      /* m_acYuvPred[list] (bi-prediction halves / the other list's prediction during the bi search) */
+  Pel orgBi[64 * 64];              /* m_cYuvPredTemp: 2*org - other prediction (luma), CTU-relative */
   Pel resiBest[3][64 * 64];        /* m_ppcResiYuvBest[depth] */
   Pel qtRec[4][3][64 * 64];        /* m_pcQTTempTComYuv[layer] */
   TCoeff qtCoef[3][4][4096];       /* m_ppcQTTempCoeff[comp][layer] */
@@ -1714,7 +1717,7 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
   InterSlice islice; RefPic refPics[32]; int numRefPics = 0;
   g_slice_type = I_SLICE;
   if (hs) { /* slice header / DPB view of a P slice */
-    if (hs->slice_type != P_SLICE) { free(e); return -3; }
+    if (hs->slice_type != P_SLICE && hs->slice_type != B_SLICE) { free(e); return -3; }
     memset(&islice, 0, sizeof(islice));
     islice.sliceType = hs->slice_type; islice.poc = hs->poc;
     islice.colFromL0 = hs->col_from_l0; islice.colRefIdx = hs->col_ref_idx; islice.tmvp = hs->tmvp; islice.mvdL1Zero = hs->mvd_l1_zero;
@@ -1736,6 +1739,10 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
         }
         islice.ref[l][i] = &refPics[k];
       }
+    }
+    for (int i1 = 0; i1 < islice.numRefIdx[1]; i1++) {
+      islice.list1ToList0[i1] = -1;
+      for (int i0 = 0; i0 < islice.numRefIdx[0]; i0++) if (islice.ref[0][i0]->poc == islice.ref[1][i1]->poc) { islice.list1ToList0[i1] = i0; break; }
     }
     e->is = &islice;
     g_slice_type = hs->cabac_init_type;

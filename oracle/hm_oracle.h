@@ -53,7 +53,7 @@ int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_
 int hmo_compress_rows(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus,
                       int max_ctus);
 
-/* ---- P slices (rows a2 inter, a4-a7, a12, a14 of SURVEY.md section 8): reference pictures and slice parameters are inputs,
+/* ---- P and B slices (rows a2 inter, a4-a7, a12, a14 of SURVEY.md section 8): reference pictures and slice parameters are inputs,
  * exactly what TEncSlice::compressSlice finds in the slice header / decoded picture buffer ---- */
 typedef struct {
   int poc, slice_type, long_term;
@@ -64,7 +64,7 @@ typedef struct {
   int num_ref[2], ref_poc[2][16], ref_lt[2][16];    /* the reference lists that picture was coded with */
 } hmo_ref_pic;
 typedef struct {
-  int slice_type, poc;               /* 1 = P (B slices: not restated yet) */
+  int slice_type, poc;               /* 1 = P, 0 = B */
   int cabac_init_type;               /* context table actually used (TEncSbac::resetEntropy :106-115): 0 = B, 1 = P */
   int num_ref_idx[2];
   const hmo_ref_pic *ref[2][16];

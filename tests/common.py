@@ -69,7 +69,8 @@ def assert_rec_equal(got_planes, want_flat, w, h, what):
         assert np.array_equal(got_planes[k], want[k]), f"{what}: reconstruction plane {k} differs at {np.count_nonzero(got_planes[k] != want[k])} samples"
 
 
-LDP_CASES = ["ldp_192x128_8b_qp32", "ldp_200x136_8b_qp24", "ldpwpp_256x136_8b_qp30"]
+LDP_CASES = ["ldp_192x128_8b_qp32", "ldp_200x136_8b_qp24", "ldpwpp_256x136_8b_qp30"]      # P slices (encoder_lowdelay_P_main.cfg)
+B_CASES = ["ra_192x128_10b_qp32", "ldb_200x136_8b_qp30"]       # B slices: encoder_randomaccess_main10.cfg, encoder_lowdelay_main.cfg
 _S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
            "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
 

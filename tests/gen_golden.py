@@ -110,18 +110,21 @@ LDP_CASES = [
     ("ldp_192x128_8b_qp32", 192, 128, 8, 6, 32, 1234),
     ("ldp_200x136_8b_qp24", 200, 136, 8, 5, 24, 5),           # picture not a multiple of the CTU size
     ("ldpwpp_256x136_8b_qp30", 256, 136, 8, 4, 30, 77, 1),    # WaveFrontSynchro=1, last CTU row partial (2Nx2N integer-MV carry)
+    # B slices: random access (hierarchical GOP 8, both directions) and low-delay B (list 1 == list 0, mvd_l1_zero)
+    ("ra_192x128_10b_qp32", 192, 128, 10, 9, 32, 4321, 0, "encoder_randomaccess_main10.cfg"),
+    ("ldb_200x136_8b_qp30", 200, 136, 8, 4, 30, 99, 0, "encoder_lowdelay_main.cfg"),
 ]
 S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
           "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
 
 
-def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0):
+def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_main.cfg"):
     import hmd2
     with tempfile.TemporaryDirectory() as td:
         yuv = os.path.join(td, "in.yuv")
         synth.write_yuv(yuv, w, h, bd, nf, seed)
         dump = os.path.join(td, "dump2.bin")
-        cmd = [HM_DUMP, "enc2", "-c", os.path.join(REF_CFG, "encoder_lowdelay_P_main.cfg"), "-i", yuv, "-wdt", str(w), "-hgt", str(h),
+        cmd = [HM_DUMP, "enc2", "-c", os.path.join(REF_CFG, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h),
                "-fr", "50", "-f", str(nf), f"--InputBitDepth={bd}", "-q", str(qp), "-b", os.path.join(td, "o.bin"),
                "-o", os.path.join(td, "r.yuv")] + (["--WaveFrontSynchro=1"] if wpp else []) + ["--", dump]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

@@ -53,16 +53,16 @@ def test_oracle_transform_kats(built):
         assert np.array_equal(got, want), f"record {r} tag {tag} n {n} bd {bd} dst {dst}"
 
 
-@pytest.mark.parametrize("name", common.LDP_CASES)
-def test_oracle_matches_reference_p_slices(built, name):
-    """encoder_lowdelay_P_main.cfg: every P slice of the clip, with the reference pictures (final reconstruction + motion
-    field) and slice parameters exactly as the reference's compressSlice saw them; decisions, motion, coefficients,
-    costs and the pre-deblocking reconstruction must match bit for bit."""
+@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES)
+def test_oracle_matches_reference_p_and_b_slices(built, name):
+    """encoder_lowdelay_P_main.cfg / encoder_randomaccess_main10.cfg / encoder_lowdelay_main.cfg: every P or B slice of the clip,
+    with the reference pictures (final reconstruction + motion field) and slice parameters exactly as the reference's
+    compressSlice saw them; decisions, motion, coefficients, costs and the pre-deblocking reconstruction must match bit for bit."""
     import oracle
     cfg, slices, finals = common.load_ldp_case(name)
     n_p = 0
     for r in slices:
-        if int(r["slice_type"]) != 1:
+        if int(r["slice_type"]) == 2:
             continue
         planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"])
         rec, ctus, ictus = oracle.compress_inter(planes, cfg["bit_depth"], r, finals, wpp=cfg["wpp"])
