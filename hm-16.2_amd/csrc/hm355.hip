@@ -360,7 +360,7 @@ extern "C" int hm355_compress_slice(hm355_ctx *c, const hm355_slice_desc *slice,
 }
 
 // ------------------------------------------------------------------------------------------------
-// P slices: reference pictures are uploaded per call (border-extended like TComPicYuv::extendPicBorder); the n pictures
+// P and B slices: reference pictures are uploaded per call (border-extended like TComPicYuv::extendPicBorder); the n pictures
 // of one call are independent of each other (e.g. the current pictures of n streams) and run concurrently
 // ------------------------------------------------------------------------------------------------
 static_assert(sizeof(hm355_ctu_inter_out) == sizeof(InterMeta), "hm355_ctu_inter_out mirrors InterMeta");
@@ -415,11 +415,14 @@ extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inte
   if (!c || !slices || !org || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
   for (int f = 0; f < n; f++) {
     const hm355_inter_slice_desc *sd = slices + f;
-    if (sd->base.slice_type != 1) return fail(c, HM355_ERR_ARG, "hm355_compress_slices_inter: only P slices");
-    if (sd->num_ref_idx[0] < 1 || sd->num_ref_idx[0] > 16 || sd->num_ref_idx[1] != 0 || sd->max_merge_cand < 1 || sd->max_merge_cand > 5 ||
-        (sd->cabac_init_type != 0 && sd->cabac_init_type != 1)) return fail(c, HM355_ERR_ARG, "bad P slice parameters");
-    for (int i = 0; i < sd->num_ref_idx[0]; i++) {
-      const hm355_ref_pic *hp = sd->ref[0][i];
+    const int isB = sd->base.slice_type == 0;
+    if (sd->base.slice_type != 1 && !isB) return fail(c, HM355_ERR_ARG, "hm355_compress_slices_inter: P (1) or B (0) slices");
+    if (sd->num_ref_idx[0] < 1 || sd->num_ref_idx[0] > 16 || (isB ? (sd->num_ref_idx[1] < 1 || sd->num_ref_idx[1] > 16) : sd->num_ref_idx[1] != 0) ||
+        sd->max_merge_cand < 1 || sd->max_merge_cand > 5 || (sd->cabac_init_type != 0 && sd->cabac_init_type != 1) ||
+        sd->col_ref_idx < 0 || sd->col_ref_idx >= sd->num_ref_idx[(isB && !sd->col_from_l0) ? 1 : 0])
+      return fail(c, HM355_ERR_ARG, "bad inter slice parameters");
+    for (int l = 0; l < 2; l++) for (int i = 0; i < sd->num_ref_idx[l]; i++) {
+      const hm355_ref_pic *hp = sd->ref[l][i];
       if (!hp || !hp->plane[0] || !hp->plane[1] || !hp->plane[2] || !hp->pred_mode || !hp->mv[0] || !hp->mv[1] || !hp->ref_idx[0] || !hp->ref_idx[1])
         return fail(c, HM355_ERR_ARG, "null reference picture data");
     }
@@ -434,21 +437,25 @@ extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inte
   for (int f = 0; f < n && e == hipSuccess; f++) {
     const hm355_inter_slice_desc *sd = slices + f;
     InterPic hip; memset(&hip, 0, sizeof(hip));
-    hip.sliceType = 1; hip.poc = sd->poc; hip.numRefIdx[0] = sd->num_ref_idx[0]; hip.numRefIdx[1] = 0;
+    hip.sliceType = sd->base.slice_type; hip.poc = sd->poc; hip.numRefIdx[0] = sd->num_ref_idx[0]; hip.numRefIdx[1] = sd->num_ref_idx[1];
     hip.colFromL0 = sd->col_from_l0; hip.colRefIdx = sd->col_ref_idx; hip.tmvp = sd->tmvp; hip.mvdL1Zero = sd->mvd_l1_zero;
     hip.maxMergeCand = sd->max_merge_cand; hip.checkLDC = sd->check_ldc; hip.cabacInitType = sd->cabac_init_type;
     hip.lambdaMotionSAD = sd->lambda_motion_sad; hip.lambdaMotionSSE = sd->lambda_motion_sse;
-    for (int i = 0; i < sd->num_ref_idx[0] && e == hipSuccess; i++) {
-      const hm355_ref_pic *hp = sd->ref[0][i];
+    for (int l = 0; l < 2; l++) for (int i = 0; i < sd->num_ref_idx[l] && e == hipSuccess; i++) {
+      const hm355_ref_pic *hp = sd->ref[l][i];
       size_t k = 0; for (; k < seen.size(); k++) if (seen[k] == hp) break;
       if (k == seen.size()) { RefPicDev r; e = upload_ref_pic(c, hp, da, &r); seen.push_back(hp); devRefs.push_back(r); }
-      hip.ref[0][i] = devRefs[k];
+      hip.ref[l][i] = devRefs[k];
+    }
+    for (int i1 = 0; i1 < sd->num_ref_idx[1]; i1++) {            // TComSlice::setList1IdxToList0Idx
+      hip.list1ToList0[i1] = -1;
+      for (int i0 = 0; i0 < sd->num_ref_idx[0]; i0++) if (sd->ref[0][i0]->poc == sd->ref[1][i1]->poc) { hip.list1ToList0[i1] = i0; break; }
     }
     FrameBuf &fb = c->slots[f].fb;
     InterPic *dIp = NULL; MvD *dIntMv = NULL;
     if (e == hipSuccess) e = da.make(&dIp, 1, &hip);
     if (e == hipSuccess) e = da.make(&dIm[f], (size_t)c->numCtus, NULL);
-    if (e == hipSuccess) e = da.make(&dIntMv, (size_t)c->numCtus * 16, NULL);
+    if (e == hipSuccess) e = da.make(&dIntMv, (size_t)c->numCtus * 32, NULL);
     fb.imeta = dIm[f]; fb.ip = dIp; fb.intMv = dIntMv;
     base[f] = sd->base; base[f].slice_type = 2;            // hm355_run validates the common fields
   }

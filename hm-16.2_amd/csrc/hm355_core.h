@@ -277,7 +277,7 @@ struct RqtFrame {
 struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary, parentPart; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
 // inter (P slice) helpers kept in LDS
 struct MvFieldD { MvD mv; int ref; };
-struct MergeList { MvFieldD f[5]; uint8_t dir[5]; int num; };      // list 0 only (P slice)
+struct MergeList { MvFieldD f[5][2]; uint8_t dir[5]; int num; };
 struct AmvpInfo { MvD cand[3]; int n; };
 struct TZ {                            // state of one integer motion search (IntTZSearchStruct, TEncSearch.h:121-133)
   const Pel *org; int orgStride, w, h;
@@ -337,8 +337,8 @@ struct Shared {
   // inter (P slice) state
   InterMeta *im;                       // motion arrays of the CTU under search (HBM)
   uint32_t mcost; MvD mvPredictor; int32_t costScale;   // TComRdCost motion-cost state
-  MvD intMv[16];                       // TEncSearch::m_integerMv2Nx2N[list 0][refIdx]
-  TZ tz; MvD outMv; MergeList ml; AmvpInfo amvp; MvFieldD mrgField; int32_t mrgDir, mrgIdx; uint32_t mrgCost, irqZeroDist;
+  MvD intMv[2][16];                    // TEncSearch::m_integerMv2Nx2N[list][refIdx]
+  TZ tz; MvD outMv; MergeList ml; AmvpInfo amvp; MvFieldD mrgField[2]; int32_t mrgDir, mrgIdx; uint32_t mrgCost, irqZeroDist;
   IrqFrame irq[4];
   // uniform per-CTU context
   int32_t width, height, bitDepth, wCtu, stride[3];
@@ -2331,8 +2331,8 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     // overwrites every entry (2Nx2N search at depth 0, all reference indices) before it reads one, so only picture-boundary
     // CTUs take the state of their predecessor -- which is what lets P slices run as a WPP wavefront.
     const int bnd = it->ctuX * 64 + 63 >= P->width || it->ctuY * 64 + 63 >= P->height;
-    const MvD *src = e->ctuAddr == 0 ? e->fb.ip->integerMv2Nx2N[0] : e->fb.intMv + (size_t)(e->ctuAddr - 1) * 16;
-    HM_PAR_FOR(i, 16) { MvD v; v.x = v.y = 0; if (bnd) v = src[i]; e->intMv[i] = v; }
+    const MvD *src = e->ctuAddr == 0 ? e->fb.ip->integerMv2Nx2N[0] : e->fb.intMv + (size_t)(e->ctuAddr - 1) * 32;
+    HM_PAR_FOR(i, 32) { MvD v; v.x = v.y = 0; if (bnd) v = src[i]; e->intMv[i >> 4][i & 15] = v; }
     HM_SYNC();
   }
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
@@ -2371,7 +2371,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   reset_bits(&e->cur);
   encode_ctu(e, &e->cur, a == numCtus - 1);
   cabac_copy(e->fb.endState + a, &e->cur);
-  if (e->im) { HM_PAR_FOR(i, 16) e->fb.intMv[(size_t)a * 16 + i] = e->intMv[i]; HM_SYNC(); }   // carried to the next CTU in coding order
+  if (e->im) { HM_PAR_FOR(i, 32) e->fb.intMv[(size_t)a * 32 + i] = e->intMv[i >> 4][i & 15]; HM_SYNC(); }   // carried to the next CTU in coding order
   { // decision arrays back to HBM (TComDataCU::copyToPic of the whole CTU)
     const uint32_t *src = (const uint32_t *)&e->meta; uint32_t *dst = (uint32_t *)(e->fb.meta + a);
     HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];

@@ -11,6 +11,7 @@
 #define SIZE_nRx2N 7
 #define MODE_INTER 0
 #define HM_P_SLICE 1
+#define HM_B_SLICE 0
 
 // ------------------------------------------------------------------------------------------------
 // interpolation (TComInterpolationFilter.cpp:55-260) and motion compensation (TComPrediction.cpp:586-697)
@@ -48,15 +49,15 @@ HM_DEV inline Pel if_sample(int bitDepth, const Pel *src, int cs, int frac, int 
 }
 // block prediction at a (possibly fractional) displacement; r = reference sample of the block's top-left at the integer
 // part of the motion vector; cw x ch samples; always two-stage when twoStage != 0 (the fractional search planes)
-HM_DEV inline void interp_block(Shared *e, int chroma, const Pel *r, int refStride, int xFrac, int yFrac, int cw, int ch, Pel *dst, int dstStride, int twoStage)
+HM_DEV inline void interp_block(Shared *e, int chroma, const Pel *r, int refStride, int xFrac, int yFrac, int cw, int ch, Pel *dst, int dstStride, int twoStage, int bi = 0)
 {
-  const int bd = e->bitDepth;
-  if (!twoStage && yFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, 1, xFrac, chroma, 1, 1); } HM_SYNC(); return; }
-  if (!twoStage && xFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, refStride, yFrac, chroma, 1, 1); } HM_SYNC(); return; }
+  const int bd = e->bitDepth, last = !bi;
+  if (!twoStage && yFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, 1, xFrac, chroma, 1, last); } HM_SYNC(); return; }
+  if (!twoStage && xFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, refStride, yFrac, chroma, 1, last); } HM_SYNC(); return; }
   Pel *tmp = e->ws->mcTmp; const int half = chroma ? 1 : 3, rows = ch + (chroma ? 3 : 7);
   HM_PAR_FOR(i, cw * rows) { const int y = i / cw, x = i - y * cw; tmp[y * 64 + x] = if_sample(bd, r + (y - half) * refStride + x, 1, xFrac, chroma, 1, 0); }
   HM_SYNC();
-  HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, tmp + (y + half) * 64 + x, 64, yFrac, chroma, 0, 1); }
+  HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, tmp + (y + half) * 64 + x, 64, yFrac, chroma, 0, last); }
   HM_SYNC();
 }
 HM_DEV inline MvD clip_mv(const Shared *e, MvD mv, int cuX, int cuY)
@@ -71,12 +72,12 @@ HM_DEV inline MvD clip_mv(const Shared *e, MvD mv, int cuX, int cuY)
   return r;
 }
 // TComPrediction::xPredInterBlk :660-697 (uni-directional): (px,py) luma position in the picture, w x h luma size
-HM_DEV inline void pred_inter_blk(Shared *e, int comp, const RefPicDev *ref, int px, int py, MvD mv, int w, int h, Pel *dst, int dstStride)
+HM_DEV inline void pred_inter_blk(Shared *e, int comp, const RefPicDev *ref, int px, int py, MvD mv, int w, int h, Pel *dst, int dstStride, int bi = 0)
 {
   const int sh = comp ? 1 : 0, shift = 2 + sh;
   const int refStride = ref->stride[comp];
   const Pel *r = ref->plane[comp] + (ptrdiff_t)((py >> sh) + (mv.y >> shift)) * refStride + (px >> sh) + (mv.x >> shift);
-  interp_block(e, comp != 0, r, refStride, mv.x & ((1 << shift) - 1), mv.y & ((1 << shift) - 1), w >> sh, h >> sh, dst, dstStride, 0);
+  interp_block(e, comp != 0, r, refStride, mv.x & ((1 << shift) - 1), mv.y & ((1 << shift) - 1), w >> sh, h >> sh, dst, dstStride, 0, bi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -179,7 +180,7 @@ HM_DEV inline MvD scale_mv(MvD mv, int scale)
 HM_DEV inline int get_col_mvp(const Shared *e, int list, int ctuAddr, int z, MvD *out, int refIdx)
 {
   const InterPic *s = e->fb.ip;
-  const RefPicDev *col = &s->ref[0][s->colRefIdx];              // P slice: collocated picture from list 0
+  const RefPicDev *col = &s->ref[s->sliceType == HM_B_SLICE ? 1 - s->colFromL0 : 0][s->colRefIdx];
   const size_t p = (size_t)ctuAddr * 256 + z;
   if (col->predMode[p] != MODE_INTER) return 0;
   int colList = s->checkLDC ? list : s->colFromL0;
@@ -220,14 +221,17 @@ HM_DEV inline int equal_motion(const Shared *e, int ca, int za, int cb, int zb)
       if (a->mv[l][za].x != b->mv[l][zb].x || a->mv[l][za].y != b->mv[l][zb].y || a->refIdx[l][za] != b->refIdx[l][zb]) return 0;
   return 1;
 }
-HM_DEV inline void merge_take(const Shared *e, MergeList *ml, int cnt, int ca, int z)
-{ const InterMeta *m = imeta_of(e, ca); ml->dir[cnt] = m->interDir[z]; ml->f[cnt].mv = m->mv[0][z]; ml->f[cnt].ref = m->refIdx[0][z]; }
+HM_DEV inline void merge_take(const Shared *e, MergeList *ml, int cnt, int ca, int z, int isB)
+{
+  const InterMeta *m = imeta_of(e, ca); ml->dir[cnt] = m->interDir[z]; ml->f[cnt][0].mv = m->mv[0][z]; ml->f[cnt][0].ref = m->refIdx[0][z];
+  if (isB) { ml->f[cnt][1].mv = m->mv[1][z]; ml->f[cnt][1].ref = m->refIdx[1][z]; }
+}
 HM_DEV HM_NOINLINE void merge_candidates(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, MergeList *ml)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); ml = hm_uni_ptr(ml);
-  const InterPic *s = e->fb.ip; const int maxC = s->maxMergeCand;
+  const InterPic *s = e->fb.ip; const int maxC = s->maxMergeCand, isB = s->sliceType == HM_B_SLICE;
   const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
-  for (int i = 0; i < 5; i++) { ml->dir[i] = 0; ml->f[i].mv.x = ml->f[i].mv.y = 0; ml->f[i].ref = -1; }
+  for (int i = 0; i < 5; i++) { ml->dir[i] = 0; for (int l = 0; l < 2; l++) { ml->f[i][l].mv.x = ml->f[i][l].mv.y = 0; ml->f[i][l].ref = -1; } }
   ml->num = maxC;
   int cnt = 0;
   const int ltx = r.x >> 2, lty = r.y >> 2, rtx = (r.x + r.w - 4) >> 2, lbx = ltx, lby = (r.y + r.h - 4) >> 2;
@@ -235,37 +239,57 @@ HM_DEV HM_NOINLINE void merge_candidates(Shared *e, int cuZ, int cuDepth, int pa
   int zl = 0, za = 0, zt = 0;
   const int cL = nb_at(e, lbx, lby, NB_LEFT, zLB, &zl);
   const int availA1 = cL >= 0 && !(puIdx == 1 && (partSize == SIZE_Nx2N || partSize == SIZE_nLx2N || partSize == SIZE_nRx2N)) && nb_is_inter(e, cL, zl);
-  if (availA1) { merge_take(e, ml, cnt, cL, zl); cnt++; }
+  if (availA1) { merge_take(e, ml, cnt, cL, zl, isB); cnt++; }
   if (cnt == maxC) return;
   const int cA = nb_at(e, rtx, lty, NB_ABOVE, zRT, &za);
   const int availB1 = cA >= 0 && !(puIdx == 1 && (partSize == SIZE_2NxN || partSize == SIZE_2NxnU || partSize == SIZE_2NxnD)) && nb_is_inter(e, cA, za);
-  if (availB1 && (!availA1 || !equal_motion(e, cL, zl, cA, za))) { merge_take(e, ml, cnt, cA, za); cnt++; }
+  if (availB1 && (!availA1 || !equal_motion(e, cL, zl, cA, za))) { merge_take(e, ml, cnt, cA, za, isB); cnt++; }
   if (cnt == maxC) return;
   int cT = nb_at(e, rtx, lty, NB_ABOVE_RIGHT, zRT, &zt);
   const int availB0 = cT >= 0 && nb_is_inter(e, cT, zt);
-  if (availB0 && (!availB1 || !equal_motion(e, cA, za, cT, zt))) { merge_take(e, ml, cnt, cT, zt); cnt++; }
+  if (availB0 && (!availB1 || !equal_motion(e, cA, za, cT, zt))) { merge_take(e, ml, cnt, cT, zt, isB); cnt++; }
   if (cnt == maxC) return;
   cT = nb_at(e, lbx, lby, NB_BELOW_LEFT, zLB, &zt);
   const int availA0 = cT >= 0 && nb_is_inter(e, cT, zt);
-  if (availA0 && (!availA1 || !equal_motion(e, cL, zl, cT, zt))) { merge_take(e, ml, cnt, cT, zt); cnt++; }
+  if (availA0 && (!availA1 || !equal_motion(e, cL, zl, cT, zt))) { merge_take(e, ml, cnt, cT, zt, isB); cnt++; }
   if (cnt == maxC) return;
   if (cnt < 4) {
     cT = nb_at(e, ltx, lty, NB_ABOVE_LEFT, zLT, &zt);
     const int availB2 = cT >= 0 && nb_is_inter(e, cT, zt);
-    if (availB2 && (!availA1 || !equal_motion(e, cL, zl, cT, zt)) && (!availB1 || !equal_motion(e, cA, za, cT, zt))) { merge_take(e, ml, cnt, cT, zt); cnt++; }
+    if (availB2 && (!availA1 || !equal_motion(e, cL, zl, cT, zt)) && (!availB1 || !equal_motion(e, cA, za, cT, zt))) { merge_take(e, ml, cnt, cT, zt, isB); cnt++; }
   }
   if (cnt == maxC) return;
-  if (s->tmvp) { MvD cm; if (temporal_mv(e, r, 0, 0, &cm)) { ml->dir[cnt] = 1; ml->f[cnt].mv = cm; ml->f[cnt].ref = 0; cnt++; } }
+  if (s->tmvp) {
+    int dir = 0; MvD cm;
+    if (temporal_mv(e, r, 0, 0, &cm)) { dir |= 1; ml->f[cnt][0].mv = cm; ml->f[cnt][0].ref = 0; }
+    if (isB && temporal_mv(e, r, 1, 0, &cm)) { dir |= 2; ml->f[cnt][1].mv = cm; ml->f[cnt][1].ref = 0; }
+    if (dir) { ml->dir[cnt] = (uint8_t)dir; cnt++; }
+  }
   if (cnt == maxC) return;
-  int arr = cnt, rr = 0, refcnt = 0;
-  const int numRef = s->numRefIdx[0];
+  int arr = cnt; const int cutoff = arr;
+  if (isB) { // combined bi-predictive candidates :2556-2597 (every candidate so far is an inter candidate)
+    for (int idx = 0; idx < cutoff * (cutoff - 1) && arr != maxC; idx++) {
+      // uiPriorityList0 = {0,1,0,2,1,2,0,3,1,3,2,3}, uiPriorityList1 = {1,0,2,0,2,1,3,0,3,1,3,2}
+      const int pi = idx == 0 ? 0 : idx == 1 ? 1 : idx == 2 ? 0 : idx == 3 ? 2 : idx == 4 ? 1 : idx == 5 ? 2 : idx == 6 ? 0 : idx == 7 ? 3 : idx == 8 ? 1 : idx == 9 ? 3 : idx == 10 ? 2 : 3;
+      const int pj = idx == 0 ? 1 : idx == 1 ? 0 : idx == 2 ? 2 : idx == 3 ? 0 : idx == 4 ? 2 : idx == 5 ? 1 : idx == 6 ? 3 : idx == 7 ? 0 : idx == 8 ? 3 : idx == 9 ? 1 : idx == 10 ? 3 : 2;
+      if ((ml->dir[pi] & 1) && (ml->dir[pj] & 2)) {
+        ml->dir[arr] = 3; ml->f[arr][0] = ml->f[pi][0]; ml->f[arr][1] = ml->f[pj][1];
+        const int p0 = s->ref[0][ml->f[arr][0].ref].poc, p1 = s->ref[1][ml->f[arr][1].ref].poc;
+        if (!(p0 == p1 && ml->f[arr][0].mv.x == ml->f[arr][1].mv.x && ml->f[arr][0].mv.y == ml->f[arr][1].mv.y)) arr++;
+      }
+    }
+  }
+  if (arr == maxC) return;
+  int rr = 0, refcnt = 0;
+  const int numRef = isB ? (s->numRefIdx[0] < s->numRefIdx[1] ? s->numRefIdx[0] : s->numRefIdx[1]) : s->numRefIdx[0];
   while (arr < maxC) {
-    ml->dir[arr] = 1; ml->f[arr].mv.x = ml->f[arr].mv.y = 0; ml->f[arr].ref = rr;
+    ml->dir[arr] = 1; ml->f[arr][0].mv.x = ml->f[arr][0].mv.y = 0; ml->f[arr][0].ref = rr;
+    if (isB) { ml->dir[arr] = 3; ml->f[arr][1].mv.x = ml->f[arr][1].mv.y = 0; ml->f[arr][1].ref = rr; }
     arr++;
     if (refcnt == numRef - 1) rr = 0; else { ++rr; ++refcnt; }
   }
   ml->num = arr;
-  HM_TRACE(e, 5, ((uint32_t)(uint16_t)ml->f[0].mv.x << 16) | (uint16_t)ml->f[0].mv.y, ((uint32_t)(uint16_t)ml->f[1].mv.x << 16) | (uint16_t)ml->f[1].mv.y, (double)arr);
+  HM_TRACE(e, 5, ((uint32_t)(uint16_t)ml->f[0][0].mv.x << 16) | (uint16_t)ml->f[0][0].mv.y, ((uint32_t)(uint16_t)ml->f[1][0].mv.x << 16) | (uint16_t)ml->f[1][0].mv.y, (double)arr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -304,10 +328,10 @@ HM_DEV inline int add_mvp_cand_order(const Shared *e, AmvpInfo *info, int list, 
   }
   return 0;
 }
-HM_DEV HM_NOINLINE void fill_mvp_cand(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int refIdx, AmvpInfo *info)
+HM_DEV HM_NOINLINE void fill_mvp_cand(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int list, int refIdx, AmvpInfo *info)
 {
-  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); refIdx = HM_UNI(refIdx); info = hm_uni_ptr(info);
-  const InterPic *s = e->fb.ip; const int list = 0;
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); list = HM_UNI(list); refIdx = HM_UNI(refIdx); info = hm_uni_ptr(info);
+  const InterPic *s = e->fb.ip;
   info->n = 0;
   if (refIdx < 0) return;
   const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
@@ -485,32 +509,55 @@ HM_DEV inline uint32_t pattern_refinement(Shared *e, TZ *z, const Pel *refAtInt,
   return best;
 }
 
-// xMotionEstimation :3816-3906 (uni-directional, list 0); results in e->outMv / e->outBits / e->outDist(cost)
-HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int predX, int predY, int refIdx, uint32_t bitsIn)
+// xPatternSearch :3932-3988: full search over the (small) bi-prediction range, one point per tz_help call
+HM_DEV inline uint32_t pattern_search(Shared *e, TZ *z, MvD *mv, MvD lt, MvD rb)
 {
-  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); predX = HM_UNI(predX); predY = HM_UNI(predY); refIdx = HM_UNI(refIdx); bitsIn = HM_UCALL(bitsIn);
+  z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0;
+  for (int y = lt.y; y <= rb.y; y++) for (int x = lt.x; x <= rb.x; x++) tz_help(e, x, y, 0, 0);
+  mv->x = (int16_t)z->bestX; mv->y = (int16_t)z->bestY;
+  return z->bestSad - mc_cost32(e, mc_bits(e, z->bestX, z->bestY));
+}
+// xMotionEstimation :3816-3906; results in e->outMv / e->outBits / e->outDist(cost).
+// bi != 0: (inX, inY) is this list's uni-directional MV (search centre, quarter samples) and the pattern is
+// 2*org - prediction of the other list (ws->yuvPred[1-list]), TComYuv::removeHighFreq :393 without clipping
+HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int predX, int predY, int listRef, uint32_t bitsIn, int bi, int inX, int inY)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); predX = HM_UNI(predX); predY = HM_UNI(predY); listRef = HM_UNI(listRef); bitsIn = HM_UCALL(bitsIn);
+  bi = HM_UNI(bi); inX = HM_UNI(inX); inY = HM_UNI(inY);
+  const int list = listRef >> 4, refIdx = listRef & 15;
   InterPic *s = e->fb.ip;
   const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
   const int rz = hm_z2r(cuZ), cuX = e->ctuX * 64 + (rz & 15) * 4, cuY = e->ctuY * 64 + (rz >> 4) * 4;
   const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
-  const RefPicDev *ref = &s->ref[0][refIdx];
+  const RefPicDev *ref = &s->ref[list][refIdx];
   MvD mvPred; mvPred.x = (int16_t)predX; mvPred.y = (int16_t)predY;
   TZ *zp = &e->tz;
 #define z (*zp)
   z.org = e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px; z.orgStride = e->stride[0]; z.w = r.w; z.h = r.h;
+  if (bi) {
+    const Pel *other = e->ws->yuvPred[1 - list], *org = z.org; Pel *ob = e->ws->orgBi; const int so = z.orgStride;
+    HM_PAR_FOR(i, r.w * r.h) { const int y = i / r.w, x = i - y * r.w; ob[(r.y + y) * 64 + r.x + x] = (Pel)(2 * org[y * so + x] - other[(r.y + y) * 64 + r.x + x]); }
+    HM_SYNC();
+    z.org = ob + r.y * 64 + r.x; z.orgStride = 64;
+  }
   z.ref = ref->plane[0] + (ptrdiff_t)py * ref->stride[0] + px; z.refStride = ref->stride[0];
   z.subShift = r.h > 8 ? 1 : 0;
-  MvD lt, rb;
-  set_search_range(e, mvPred, 64, cuX, cuY, &lt, &rb);
+  MvD lt, rb, centre = mvPred;
+  if (bi) { centre.x = (int16_t)inX; centre.y = (int16_t)inY; }
+  set_search_range(e, centre, bi ? 4 : 64, cuX, cuY, &lt, &rb);   // BipredSearchRange 4 / SearchRange 64
   e->mcost = s->lambdaMotionSAD; e->mvPredictor = mvPred; e->costScale = 2;
   MvD mv = mvPred;
-  const int useInt = (partSize != SIZE_2Nx2N || cuDepth != 0);
-  MvD im = e->intMv[refIdx];
+  uint32_t c;
   HM_PROF_BEGIN(e, PR_ME_INT);
-  uint32_t c = tz_search(e, &z, &mv, cuX, cuY, lt, rb, useInt, im);
+  if (bi) c = pattern_search(e, &z, &mv, lt, rb);
+  else {
+    const int useInt = (partSize != SIZE_2Nx2N || cuDepth != 0);
+    MvD im = e->intMv[list][refIdx];
+    c = tz_search(e, &z, &mv, cuX, cuY, lt, rb, useInt, im);
+    if (partSize == SIZE_2Nx2N) e->intMv[list][refIdx] = mv;
+  }
   HM_PROF_END(e, PR_ME_INT);
   HM_PROF_BEGIN(e, PR_ME_FRAC);
-  if (partSize == SIZE_2Nx2N) e->intMv[refIdx] = mv;
   e->costScale = 1;
   const Pel *refAtInt = z.ref + (ptrdiff_t)mv.y * z.refStride + mv.x;
   MvD half, base, qter; half.x = (int16_t)(mv.x << 1); half.y = (int16_t)(mv.y << 1); base.x = base.y = 0;
@@ -524,51 +571,73 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   const uint32_t mvBits = mc_bits(e, mv.x, mv.y);
   const uint32_t bits = bitsIn + mvBits;
   e->outMv = mv; e->outBits = bits;
-  e->outDist = (uint32_t)(floor(1.0 * ((double)c - (double)mc_cost32(e, mvBits))) + (double)mc_cost32(e, bits));
+  e->outDist = (uint32_t)(floor((bi ? 0.5 : 1.0) * ((double)c - (double)mc_cost32(e, mvBits))) + (double)mc_cost32(e, bits));
   HM_TRACE(e, 2, ((uint32_t)(uint16_t)mv.x << 16) | (uint16_t)mv.y, bits, (double)e->outDist);
 #undef z
 }
 
-// TComPrediction::motionCompensation of one PU (P slice: list 0) into a CTU-relative scratch picture
-HM_DEV inline void motion_compensation_pu(Shared *e, int cuZ, Rect r, Pel *dst)
+// xPredInterUni :586: one list of one PU into a CTU-relative scratch picture (bi: 14-bit intermediate, no rounding)
+HM_DEV inline void pred_inter_uni(Shared *e, int cuZ, Rect r, int list, Pel *dst, int bi)
 {
   const InterPic *s = e->fb.ip; const InterMeta *m = e->im;
   const int z = rect_z(r), rz = hm_z2r(cuZ), cuX = e->ctuX * 64 + (rz & 15) * 4, cuY = e->ctuY * 64 + (rz >> 4) * 4;
-  const int refIdx = m->refIdx[0][z];
-  const MvD mv = clip_mv(e, m->mv[0][z], cuX, cuY);
+  const int refIdx = m->refIdx[list][z];
+  const MvD mv = clip_mv(e, m->mv[list][z], cuX, cuY);
   for (int c = 0; c < 3; c++) {
     const int st = HM_PLANE_STRIDE(c), sh = c ? 1 : 0;
-    pred_inter_blk(e, c, &s->ref[0][refIdx], e->ctuX * 64 + r.x, e->ctuY * 64 + r.y, mv, r.w, r.h, dst + HM_PLANE_OFF(c) + (r.y >> sh) * st + (r.x >> sh), st);
+    pred_inter_blk(e, c, &s->ref[list][refIdx], e->ctuX * 64 + r.x, e->ctuY * 64 + r.y, mv, r.w, r.h, dst + HM_PLANE_OFF(c) + (r.y >> sh) * st + (r.x >> sh), st, bi);
   }
+}
+// TComPrediction::motionCompensation :514 of one PU into a CTU-relative scratch picture.  list 0 / 1: that list alone
+// (uni-directional, rounded); list 2 = REF_PIC_LIST_X: what the PU's motion says (xCheckIdenticalMotion :497, xPredInterBi :596,
+// xWeightedAverage :700 -> TComYuv::addAvg :336; weighted prediction off)
+HM_DEV inline void motion_compensation_pu(Shared *e, int cuZ, Rect r, Pel *dst, int list = 2)
+{
+  const InterPic *s = e->fb.ip; const InterMeta *m = e->im;
+  if (list != 2) { pred_inter_uni(e, cuZ, r, list, dst, 0); return; }
+  const int z = rect_z(r), r0 = m->refIdx[0][z], r1 = m->refIdx[1][z];
+  if (r0 >= 0 && r1 >= 0) {
+    if (s->ref[0][r0].poc == s->ref[1][r1].poc && m->mv[0][z].x == m->mv[1][z].x && m->mv[0][z].y == m->mv[1][z].y) { pred_inter_uni(e, cuZ, r, 0, dst, 0); return; }
+    Pel *p0 = e->ws->yuvPred[0], *p1 = e->ws->yuvPred[1];
+    pred_inter_uni(e, cuZ, r, 0, p0, 1); pred_inter_uni(e, cuZ, r, 1, p1, 1);
+    const int bd = e->bitDepth, shiftNum = ((14 - bd) > 2 ? (14 - bd) : 2) + 1, offset = (1 << (shiftNum - 1)) + 2 * HM_IF_OFFS, maxv = (1 << bd) - 1;
+    for (int c = 0; c < 3; c++) {
+      const int st = HM_PLANE_STRIDE(c), sh = c ? 1 : 0, o0 = HM_PLANE_OFF(c) + (r.y >> sh) * st + (r.x >> sh), cw = r.w >> sh, ch = r.h >> sh;
+      HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw, o = o0 + y * st + x; dst[o] = (Pel)hm_clip3(0, maxv, (p0[o] + p1[o] + offset) >> shiftNum); }
+    }
+    HM_SYNC();
+    return;
+  }
+  pred_inter_uni(e, cuZ, r, r0 >= 0 ? 0 : 1, dst, 0);
 }
 
 // AMVP predictor choice (xEstimateMvPredAMVP :3571, xGetTemplateCost :3771, xCheckBestMVP :3725)
-HM_DEV inline uint32_t template_cost(Shared *e, int cuZ, Rect r, MvD cand, int refIdx)
+HM_DEV inline uint32_t template_cost(Shared *e, int cuZ, Rect r, MvD cand, int list, int refIdx)
 {
   const InterPic *s = e->fb.ip;
   const int rz = hm_z2r(cuZ), cuX = e->ctuX * 64 + (rz & 15) * 4, cuY = e->ctuY * 64 + (rz >> 4) * 4;
   const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
   Pel *blk = e->ws->mcBlk;
-  pred_inter_blk(e, 0, &s->ref[0][refIdx], px, py, clip_mv(e, cand, cuX, cuY), r.w, r.h, blk, 64);
+  pred_inter_blk(e, 0, &s->ref[list][refIdx], px, py, clip_mv(e, cand, cuX, cuY), r.w, r.h, blk, 64);
   const uint32_t sad = dist_sad_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], blk, 64, r.w, r.h, 0, e->bitDepth);
   HM_TRACE(e, 9, ((uint32_t)(uint16_t)cand.x << 16) | (uint16_t)cand.y, sad, 0.0);
   const double t = floor(((double)1 * (double)s->lambdaMotionSAD) + 0.5) / 65536.0;
   return (uint32_t)floor((double)sad + t);
 }
-HM_DEV inline MvD estimate_mvp_amvp(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int refIdx, AmvpInfo *info, int *bestIdx)
+HM_DEV inline MvD estimate_mvp_amvp(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int list, int refIdx, AmvpInfo *info, int *bestIdx, uint32_t *distBiP)
 {
   const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
-  fill_mvp_cand(e, cuZ, cuDepth, partSize, puIdx, refIdx, info);
+  fill_mvp_cand(e, cuZ, cuDepth, partSize, puIdx, list, refIdx, info);
   *bestIdx = 0;
   MvD best = info->cand[0];
-  if (info->n > 1) {
+  if (info->n > 1) {                                            // always: the list is padded to AMVP_MAX_NUM_CANDS
     uint32_t bestCost = 0xffffffffu;
     for (int i = 0; i < info->n; i++) {
-      const uint32_t c = template_cost(e, cuZ, r, info->cand[i], refIdx);
-      if (bestCost > c) { bestCost = c; best = info->cand[i]; *bestIdx = i; }
+      const uint32_t c = template_cost(e, cuZ, r, info->cand[i], list, refIdx);
+      if (bestCost > c) { bestCost = c; best = info->cand[i]; *bestIdx = i; *distBiP = c; }   // (*puiDistBiP) = uiTmpCost :3626
     }
   }
-  pu_set_mvp(e, r, 0, *bestIdx, info->n);
+  pu_set_mvp(e, r, list, *bestIdx, info->n);
   return best;
 }
 HM_DEV inline void check_best_mvp(Shared *e, const AmvpInfo *info, MvD mv, MvD *mvPred, int *mvpIdx, uint32_t *bits, uint32_t *cost)
@@ -601,64 +670,157 @@ HM_DEV HM_NOINLINE void merge_estimation(Shared *e, int cuZ, int cuDepth, int pa
   const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
   MergeList *ml = &e->ml;
   merge_candidates(e, cuZ, cuDepth, partSize, puIdx, ml);
-  // xRestrictBipredMergeCand: no bi-predictive candidates in a P slice
+  if ((64 >> cuDepth) == 8 && (r.w < 8 || r.h < 8))             // xRestrictBipredMergeCand :3047
+    for (int i = 0; i < ml->num; i++) if (ml->dir[i] == 3) { ml->dir[i] = 1; ml->f[i][1].mv.x = ml->f[i][1].mv.y = 0; ml->f[i][1].ref = -1; }
   uint32_t cost = 0xffffffffu;
   const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
-  MvD zero; zero.x = zero.y = 0;
   for (int c = 0; c < ml->num; c++) {
-    pu_set_motion(e, r, 0, ml->f[c].mv, ml->f[c].ref);
-    pu_set_motion(e, r, 1, zero, -1);
+    pu_set_motion(e, r, 0, ml->f[c][0].mv, ml->f[c][0].ref);
+    pu_set_motion(e, r, 1, ml->f[c][1].mv, ml->f[c][1].ref);
     motion_compensation_pu(e, cuZ, r, e->ws->tmpPred);
     uint32_t d = dist_hads_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], e->ws->tmpPred + r.y * 64 + r.x, 64, r.w, r.h, e->bitDepth);
     uint32_t b = (uint32_t)c + 1;
     if (c == s->maxMergeCand - 1) b--;
     d += mc_cost32(e, b);
-    if (d < cost) { cost = d; e->mrgField = ml->f[c]; e->mrgDir = ml->dir[c]; e->mrgIdx = c; }
+    if (d < cost) { cost = d; e->mrgField[0] = ml->f[c][0]; e->mrgField[1] = ml->f[c][1]; e->mrgDir = ml->dir[c]; e->mrgIdx = c; }
   }
   e->mrgCost = cost;
   HM_TRACE(e, 3, e->mrgIdx, cost, (double)ml->num);
 }
 
-// TEncSearch::predInterSearch :3075-3567, P slice
+// TEncSearch::predInterSearch :3075-3567 (P and B slices; FEN: one bi-prediction iteration).  The per-(list, refIdx) arrays of
+// the reference live in ws->ps; every lane holds the same scalars.
+HM_DEV inline void get_blk_bits(int partSize, int isP, int puIdx, uint32_t lastMode, uint32_t blkBit[3])
+{ // xGetBlkBits :3667-3713
+  if (partSize == SIZE_2Nx2N || partSize == SIZE_NxN) { blkBit[0] = isP ? 1 : 3; blkBit[1] = 3; blkBit[2] = 5; return; }
+  if (isP) { blkBit[0] = 3; blkBit[1] = 0; blkBit[2] = 0; return; }
+  const int isHor = partSize == SIZE_2NxN || partSize == SIZE_2NxnU || partSize == SIZE_2NxnD;
+  if (puIdx == 0) { blkBit[0] = 0; blkBit[1] = (lastMode == 0 && !isHor) ? 2 : 0; blkBit[2] = lastMode == 0 ? 3 : 0; return; }
+  // aauiMbBits[1][lastMode]: 2NxN {5,7,7},{7,5,7},{6,6,6}; Nx2N {5,7,7},{5,5,7},{6,6,6}
+  if (lastMode == 0) { blkBit[0] = 5; blkBit[1] = 7; blkBit[2] = 7; }
+  else if (lastMode == 1) { blkBit[0] = isHor ? 7 : 5; blkBit[1] = 5; blkBit[2] = 7; }
+  else { blkBit[0] = blkBit[1] = blkBit[2] = 6; }
+}
 HM_DEV HM_NOINLINE void pred_inter_search(Shared *e, int cuZ, int cuDepth, int partSize, int useMRG)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); useMRG = HM_UNI(useMRG);
   const InterPic *s = e->fb.ip; InterMeta *m = e->im;
+  WorkSpace::PuSearch *ps = &e->ws->ps;
+  const int isP = s->sliceType == HM_P_SLICE, numPredDir = isP ? 1 : 2, mvdL1Zero = s->mvdL1Zero;
   const int numPart = num_parts_of(partSize), cuW = 64 >> cuDepth;
   MvD zero; zero.x = zero.y = 0;
+  // declared outside the PU loop in the reference (:3098-3135): carried from PU 0 to PU 1
+  MvD cMv[2], cMvBi[2]; cMv[0] = cMv[1] = cMvBi[0] = cMvBi[1] = zero;
+  int refIdx[2] = {0, 0}, refIdxBi[2] = {0, 0};
+  uint32_t lastMode = 0, biPDistTemp = 0xffffffffu;
+  int bestBiPRefIdxL1 = 0, bestBiPMvpL1 = 0;
   for (int puIdx = 0; puIdx < numPart; puIdx++) {
     const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
-    uint32_t costL0 = 0xffffffffu, bitsL0 = 0;
-    MvD mvL0 = zero, predL0 = zero; int refL0 = 0, mvpIdxL0 = 0, mvpNumL0 = 0;
-    const uint32_t mbBits = (partSize == SIZE_2Nx2N || partSize == SIZE_NxN) ? 1 : 3;
+    uint32_t cost[2] = {0xffffffffu, 0xffffffffu}, costBi = 0xffffffffu, costTemp, bits[3] = {0, 0, 0}, bitsTemp, bestBiPDist = 0xffffffffu;
+    MvD mvValidList1 = zero; int refIdxValidList1 = 0; uint32_t bitsValidList1 = 0xffffffffu, costValidList1 = 0xffffffffu;
+    uint32_t mbBits[3];
+    get_blk_bits(partSize, isP, puIdx, lastMode, mbBits);
     const int testNormalMC = !(useMRG && cuW > 8 && numPart == 2);
     if (testNormalMC) {
-      for (int refIdx = 0; refIdx < s->numRefIdx[0]; refIdx++) {
-        uint32_t bitsTemp = mbBits, costTemp;
-        if (s->numRefIdx[0] > 1) { bitsTemp += refIdx + 1; if (refIdx == s->numRefIdx[0] - 1) bitsTemp--; }
-        AmvpInfo *info = &e->amvp; int mvpIdx;
-        HM_PROF_BEGIN(e, PR_AMVP);
-        MvD mvPred = estimate_mvp_amvp(e, cuZ, cuDepth, partSize, puIdx, refIdx, info, &mvpIdx);
-        HM_PROF_END(e, PR_AMVP);
-        const int mvpNum = info->n;
-        bitsTemp += 1;
-        motion_estimation(e, cuZ, cuDepth, partSize, puIdx, mvPred.x, mvPred.y, refIdx, bitsTemp);
-        const MvD mvTemp = e->outMv; bitsTemp = e->outBits; costTemp = e->outDist;
-        check_best_mvp(e, info, mvTemp, &mvPred, &mvpIdx, &bitsTemp, &costTemp);
-        if (costTemp < costL0) { costL0 = costTemp; bitsL0 = bitsTemp; mvL0 = mvTemp; refL0 = refIdx; predL0 = mvPred; mvpIdxL0 = mvpIdx; mvpNumL0 = mvpNum; }
+      for (int list = 0; list < numPredDir; list++) {               // uni-directional prediction :3166-3259
+        const int numRef = s->numRefIdx[list];
+        for (int ri = 0; ri < numRef; ri++) {
+          bitsTemp = mbBits[list];
+          if (numRef > 1) { bitsTemp += ri + 1; if (ri == numRef - 1) bitsTemp--; }
+          AmvpInfo *info = &e->amvp; int mvpIdx;
+          HM_PROF_BEGIN(e, PR_AMVP);
+          MvD mvPred = estimate_mvp_amvp(e, cuZ, cuDepth, partSize, puIdx, list, ri, info, &mvpIdx, &biPDistTemp);
+          HM_PROF_END(e, PR_AMVP);
+          ps->cand[list][ri][0] = info->cand[0]; ps->cand[list][ri][1] = info->cand[1]; ps->mvpNum[list][ri] = (int8_t)info->n;
+          if (mvdL1Zero && list == 1 && biPDistTemp < bestBiPDist) { bestBiPDist = biPDistTemp; bestBiPMvpL1 = mvpIdx; bestBiPRefIdxL1 = ri; }
+          bitsTemp += 1;                                            // m_auiMVPIdxCost[idx][AMVP_MAX_NUM_CANDS]
+          MvD mvTemp;
+          const int r0 = list == 1 ? s->list1ToList0[ri] : -1;
+          if (r0 >= 0) {                                            // GPB_SIMPLE_UNI :3190-3204: same picture as a list-0 entry
+            mvTemp = ps->mvTemp[0][r0];
+            costTemp = ps->costTempL0[r0];
+            costTemp -= mc_cost32(e, ps->bitsTempL0[r0]);
+            e->mvPredictor = mvPred;
+            bitsTemp += mc_bits(e, mvTemp.x, mvTemp.y);
+            costTemp += mc_cost32(e, bitsTemp);
+          } else {
+            motion_estimation(e, cuZ, cuDepth, partSize, puIdx, mvPred.x, mvPred.y, (list << 4) | ri, bitsTemp, 0, 0, 0);
+            mvTemp = e->outMv; bitsTemp = e->outBits; costTemp = e->outDist;
+          }
+          check_best_mvp(e, info, mvTemp, &mvPred, &mvpIdx, &bitsTemp, &costTemp);
+          ps->mvTemp[list][ri] = mvTemp; ps->mvPred[list][ri] = mvPred; ps->mvpIdx[list][ri] = (int8_t)mvpIdx;
+          if (list == 0) { ps->costTempL0[ri] = costTemp; ps->bitsTempL0[ri] = bitsTemp; }
+          if (costTemp < cost[list]) { cost[list] = costTemp; bits[list] = bitsTemp; cMv[list] = mvTemp; refIdx[list] = ri; }
+          if (list == 1 && costTemp < costValidList1 && r0 < 0) { costValidList1 = costTemp; bitsValidList1 = bitsTemp; mvValidList1 = mvTemp; refIdxValidList1 = ri; }
+        }
+      }
+      // bi-directional prediction :3262-3416; isBipredRestriction :2902: none for 8x4 / 4x8
+      if (!isP && !(cuW == 8 && (r.w < 8 || r.h < 8))) {
+        cMvBi[0] = cMv[0]; cMvBi[1] = cMv[1]; refIdxBi[0] = refIdx[0]; refIdxBi[1] = refIdx[1];
+        for (int l = 0; l < 2; l++) for (int i = 0; i < s->numRefIdx[l]; i++) { ps->mvPredBi[l][i] = ps->mvPred[l][i]; ps->mvpIdxBi[l][i] = ps->mvpIdx[l][i]; }
+        uint32_t motBits[2];
+        if (mvdL1Zero) {
+          { InterMeta *mm = e->im; HM_PU_FOR(r, z) mm->mvpIdx[1][z] = (int8_t)bestBiPMvpL1; HM_SYNC(); }
+          ps->mvpIdxBi[1][bestBiPRefIdxL1] = (int8_t)bestBiPMvpL1;
+          ps->mvPredBi[1][bestBiPRefIdxL1] = ps->cand[1][bestBiPRefIdxL1][bestBiPMvpL1];
+          cMvBi[1] = ps->mvPredBi[1][bestBiPRefIdxL1]; refIdxBi[1] = bestBiPRefIdxL1;
+          pu_set_motion(e, r, 1, cMvBi[1], refIdxBi[1]);
+          motion_compensation_pu(e, cuZ, r, e->ws->yuvPred[1], 1);
+          motBits[0] = bits[0] - mbBits[0]; motBits[1] = mbBits[1];
+          if (s->numRefIdx[1] > 1) { motBits[1] += bestBiPRefIdxL1 + 1; if (bestBiPRefIdxL1 == s->numRefIdx[1] - 1) motBits[1]--; }
+          motBits[1] += 1;
+          bits[2] = mbBits[2] + motBits[0] + motBits[1];
+          ps->mvTemp[1][bestBiPRefIdxL1] = cMvBi[1];
+        } else { motBits[0] = bits[0] - mbBits[0]; motBits[1] = bits[1] - mbBits[1]; bits[2] = mbBits[2] + motBits[0] + motBits[1]; }
+        // FEN (getUseFastEnc) or mvd_l1_zero: one iteration, refining the list with the larger uni-directional cost
+        int list = cost[0] <= cost[1] ? 1 : 0;
+        if (!mvdL1Zero) { pu_set_motion(e, r, 1 - list, cMv[1 - list], refIdx[1 - list]); motion_compensation_pu(e, cuZ, r, e->ws->yuvPred[1 - list], 1 - list); }
+        else list = 0;
+        const int numRef = s->numRefIdx[list];
+        for (int ri = 0; ri < numRef; ri++) {
+          bitsTemp = mbBits[2] + motBits[1 - list];
+          if (numRef > 1) { bitsTemp += ri + 1; if (ri == numRef - 1) bitsTemp--; }
+          bitsTemp += 1;
+          MvD mvPred = ps->mvPredBi[list][ri]; const MvD in = ps->mvTemp[list][ri]; int mvpIdx = ps->mvpIdxBi[list][ri];
+          motion_estimation(e, cuZ, cuDepth, partSize, puIdx, mvPred.x, mvPred.y, (list << 4) | ri, bitsTemp, 1, in.x, in.y);
+          const MvD mvTemp = e->outMv; bitsTemp = e->outBits; costTemp = e->outDist;
+          AmvpInfo *info = &e->amvp; info->n = ps->mvpNum[list][ri]; info->cand[0] = ps->cand[list][ri][0]; info->cand[1] = ps->cand[list][ri][1];
+          check_best_mvp(e, info, mvTemp, &mvPred, &mvpIdx, &bitsTemp, &costTemp);
+          ps->mvTemp[list][ri] = mvTemp; ps->mvPredBi[list][ri] = mvPred; ps->mvpIdxBi[list][ri] = (int8_t)mvpIdx;
+          if (costTemp < costBi) {
+            cMvBi[list] = mvTemp; refIdxBi[list] = ri; costBi = costTemp;
+            motBits[list] = bitsTemp - mbBits[2] - motBits[1 - list]; bits[2] = bitsTemp;
+          }
+        }
       }
     }
+    // clear the motion field, then set the winner :3420-3493
     pu_set_motion(e, r, 0, zero, -1); pu_set_motion(e, r, 1, zero, -1);
     pu_set_mvd(e, r, 0, zero); pu_set_mvd(e, r, 1, zero);
     pu_set_mvp(e, r, 0, -1, -1); pu_set_mvp(e, r, 1, -1, -1);
     uint32_t meBits = 0;
+    cMv[1] = mvValidList1; refIdx[1] = refIdxValidList1; bits[1] = bitsValidList1; cost[1] = costValidList1;
     if (testNormalMC) {
-      pu_set_motion(e, r, 0, mvL0, refL0);
-      MvD mvd; mvd.x = (int16_t)(mvL0.x - predL0.x); mvd.y = (int16_t)(mvL0.y - predL0.y);
-      pu_set_mvd(e, r, 0, mvd);
-      pu_set_u8(m->interDir, r, 1);
-      pu_set_mvp(e, r, 0, mvpIdxL0, mvpNumL0);
-      meBits = bitsL0;
+      if (costBi <= cost[0] && costBi <= cost[1]) {
+        lastMode = 2;
+        for (int l = 0; l < 2; l++) {
+          pu_set_motion(e, r, l, cMvBi[l], refIdxBi[l]);
+          const MvD p = ps->mvPredBi[l][refIdxBi[l]]; MvD mvd; mvd.x = (int16_t)(cMvBi[l].x - p.x); mvd.y = (int16_t)(cMvBi[l].y - p.y);
+          pu_set_mvd(e, r, l, mvd);
+          pu_set_mvp(e, r, l, ps->mvpIdxBi[l][refIdxBi[l]], ps->mvpNum[l][refIdxBi[l]]);
+        }
+        pu_set_u8(m->interDir, r, 3);
+        meBits = bits[2];
+      } else {
+        const int l = cost[0] <= cost[1] ? 0 : 1;
+        lastMode = (uint32_t)l;
+        pu_set_motion(e, r, l, cMv[l], refIdx[l]);
+        const MvD p = ps->mvPred[l][refIdx[l]]; MvD mvd; mvd.x = (int16_t)(cMv[l].x - p.x); mvd.y = (int16_t)(cMv[l].y - p.y);
+        pu_set_mvd(e, r, l, mvd);
+        pu_set_u8(m->interDir, r, 1 + l);
+        pu_set_mvp(e, r, l, ps->mvpIdx[l][refIdx[l]], ps->mvpNum[l][refIdx[l]]);
+        meBits = bits[l];
+      }
     }
     if (partSize != SIZE_2Nx2N) {
       e->mcost = s->lambdaMotionSAD;
@@ -671,16 +833,16 @@ HM_DEV HM_NOINLINE void pred_inter_search(Shared *e, int cuZ, int cuDepth, int p
       }
       const int z0 = rect_z(r);
       const int meDir = m->interDir[z0];
-      const MvD meMv = m->mv[0][z0]; const int meRef = m->refIdx[0][z0];
+      const MvD meMv0 = m->mv[0][z0], meMv1 = m->mv[1][z0]; const int meRef0 = m->refIdx[0][z0], meRef1 = m->refIdx[1][z0];
       { HM_PROF_BEGIN(e, PR_MRG_EST); merge_estimation(e, cuZ, cuDepth, partSize, puIdx); HM_PROF_END(e, PR_MRG_EST); }
       if (e->mrgCost < meCost) {
         pu_set_u8(m->mrg, r, 1); pu_set_u8(m->mrgIdx, r, e->mrgIdx); pu_set_u8(m->interDir, r, e->mrgDir);
-        pu_set_motion(e, r, 0, e->mrgField.mv, e->mrgField.ref); pu_set_motion(e, r, 1, zero, -1);
+        pu_set_motion(e, r, 0, e->mrgField[0].mv, e->mrgField[0].ref); pu_set_motion(e, r, 1, e->mrgField[1].mv, e->mrgField[1].ref);
         pu_set_mvd(e, r, 0, zero); pu_set_mvd(e, r, 1, zero);
         pu_set_mvp(e, r, 0, -1, -1); pu_set_mvp(e, r, 1, -1, -1);
       } else {
         pu_set_u8(m->mrg, r, 0); pu_set_u8(m->interDir, r, meDir);
-        pu_set_motion(e, r, 0, meMv, meRef); pu_set_motion(e, r, 1, zero, -1);
+        pu_set_motion(e, r, 0, meMv0, meRef0); pu_set_motion(e, r, 1, meMv1, meRef1);
       }
     }
     { HM_PROF_BEGIN(e, PR_MC); motion_compensation_pu(e, cuZ, r, e->ws->pred); HM_PROF_END(e, PR_MC); }
@@ -731,8 +893,15 @@ HM_DEV inline void write_ep_ex_golomb(Cabac *c, uint32_t symbol, uint32_t count)
   numBins++; numBins += count;
   enc_ep(c, (int)numBins);
 }
+HM_DEV inline void code_inter_dir(Shared *e, Cabac *c, int z, int cuDepth)
+{ // codeInterDir :723-740; getCtxInterDir = depth (TComDataCU.cpp:1662)
+  const int dir = e->im->interDir[z] - 1;
+  if (e->meta.part[z] == SIZE_2Nx2N || (64 >> cuDepth) != 8) enc_bin(e, c, C_INTER_DIR + cuDepth, dir == 2 ? 1 : 0);
+  if (dir < 2) enc_bin(e, c, C_INTER_DIR + 4, dir);
+}
 HM_DEV inline void code_mvd(Shared *e, Cabac *c, int z, int list)
 { // codeMvd :757
+  if (e->fb.ip->mvdL1Zero && list == 1 && e->im->interDir[z] == 3) return;
   const int hor = e->im->mvd[list][z].x, ver = e->im->mvd[list][z].y;
   enc_bin(e, c, C_MVD, hor != 0); enc_bin(e, c, C_MVD, ver != 0);
   const uint32_t ha = (uint32_t)hm_abs(hor), va = (uint32_t)hm_abs(ver);
@@ -756,13 +925,14 @@ HM_DEV inline void code_ref_idx(Shared *e, Cabac *c, int z, int list)
   }
 }
 HM_DEV inline void code_pu_wise(Shared *e, Cabac *c, int cuZ, int cuDepth)
-{ // TEncEntropy::encodePUWise :477 (P slice: no inter_pred_idc)
+{ // TEncEntropy::encodePUWise :477
   const InterMeta *m = e->im; const int partSize = e->meta.part[cuZ], np = num_parts_of(partSize);
   for (int p = 0; p < np; p++) {
     const int z = rect_z(pu_rect(cuZ, cuDepth, partSize, p));
     enc_bin(e, c, C_MRG_FLAG, m->mrg[z] ? 1 : 0);
     if (m->mrg[z]) code_merge_index(e, c, z);
     else {
+      if (e->fb.ip->sliceType == HM_B_SLICE) code_inter_dir(e, c, z, cuDepth);
       for (int l = 0; l < 2; l++) {
         if (e->fb.ip->numRefIdx[l] > 0) {
           if (e->fb.ip->numRefIdx[l] > 1 && (m->interDir[z] & (1 << l))) code_ref_idx(e, c, z, l);

@@ -18,9 +18,10 @@ HM_DEV HM_NOINLINE void check_rd_cost_merge_2Nx2N(Shared *e, int cuZ, int cuDept
   const Rect r = pu_rect(cuZ, cuDepth, SIZE_2Nx2N, 0);
   init_est_data(e, cuZ, cuDepth);
   par_set8(m->part + cuZ, SIZE_2Nx2N, parts);
-  MergeList ml;                                               // private copy: merge_estimation of later modes reuses e->ml
   merge_candidates(e, cuZ, cuDepth, SIZE_2Nx2N, 0, &e->ml);
-  ml = e->ml;
+  auto &ml = e->ws->mrg2N;                                    // copy in HBM: merge_estimation of later modes reuses e->ml
+  for (int i = 0; i < 5; i++) { ml.dir[i] = e->ml.dir[i]; for (int l = 0; l < 2; l++) { ml.mv[i][l] = e->ml.f[i][l].mv; ml.ref[i][l] = e->ml.f[i][l].ref; } }
+  ml.num = e->ml.num;
   int mergeCandBuffer[5] = {0, 0, 0, 0, 0};
   int bestIsSkip = 0;
   MvD zero; zero.x = zero.y = 0;
@@ -30,7 +31,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_merge_2Nx2N(Shared *e, int cuZ, int cuDept
       if (bestIsSkip && noResidual == 0) continue;
       par_set8(m->pred + cuZ, MODE_INTER, parts); par_set8(m->part + cuZ, SIZE_2Nx2N, parts);
       par_set8(im->mrg + cuZ, 1, parts); par_set8(im->mrgIdx + cuZ, cand, parts); par_set8(im->interDir + cuZ, ml.dir[cand], parts);
-      pu_set_motion(e, r, 0, ml.f[cand].mv, ml.f[cand].ref); pu_set_motion(e, r, 1, zero, -1);
+      pu_set_motion(e, r, 0, ml.mv[cand][0], ml.ref[cand][0]); pu_set_motion(e, r, 1, ml.mv[cand][1], ml.ref[cand][1]);
       motion_compensation_pu(e, cuZ, r, e->ws->pred);
       { HM_PROF_BEGIN(e, PR_IRES); encode_res_and_calc_rd_inter(e, cuZ, cuDepth, noResidual != 0); HM_PROF_END(e, PR_IRES); }
       if (noResidual == 0 && !qt_root_cbf(m, cuZ)) mergeCandBuffer[cand] = 1;

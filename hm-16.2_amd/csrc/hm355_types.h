@@ -50,6 +50,7 @@ struct InterPic {
   int32_t colFromL0, colRefIdx, tmvp, mvdL1Zero, maxMergeCand, checkLDC, cabacInitType;
   uint32_t lambdaMotionSAD, lambdaMotionSSE;
   MvD integerMv2Nx2N[2][16];          // TEncSearch::m_integerMv2Nx2N on entry to the slice
+  int32_t list1ToList0[16];           // TComSlice::m_list1IdxToList0Idx: list-1 entry -> list-0 entry holding the same picture, or -1
 };
 
 // planes of one CTU-sized scratch picture: Y 64x64 at 0, Cb 32x32 at 4096, Cr 32x32 at 5120
@@ -79,6 +80,15 @@ struct WorkSpace {
   Pel resiBest[HM_COEF_CTU];         // m_ppcResiYuvBest[depth]
   Pel mcTmp[72 * 64];                // first interpolation stage of a block (m_filteredBlockTmp)
   Pel mcBlk[64 * 64];                // interpolated candidate block of the fractional search
+  Pel yuvPred[2][HM_COEF_CTU];       // m_acYuvPred[list]: bi-prediction halves (14-bit) / the other list's prediction during the bi search
+  Pel orgBi[64 * 64];                // m_cYuvPredTemp: 2*org - other prediction (luma)
+  // per-(list, refIdx) state of TEncSearch::predInterSearch (:3098-3135) for the PU under search
+  struct PuSearch {
+    MvD mvTemp[2][16], mvPred[2][16], mvPredBi[2][16], cand[2][16][2];
+    int8_t mvpIdx[2][16], mvpIdxBi[2][16], mvpNum[2][16];
+    uint32_t costTempL0[16], bitsTempL0[16];
+  } ps;
+  struct { MvD mv[5][2]; int32_t ref[5][2]; uint8_t dir[5]; int32_t num; } mrg2N;   // merge list of xCheckRDCostMerge2Nx2N (outlives the per-PU list in LDS)
   uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
 };
 
@@ -99,7 +109,7 @@ struct FrameBuf {
   uint32_t *done;                    // [numCtus] == run epoch once the CTU's results are published (persistent scheduler)
   InterMeta *imeta;                  // [numCtus] (P slices; NULL for I slices)
   InterPic *ip;                      // slice-level inter parameters (NULL for I slices)
-  MvD *intMv;                        // [numCtus][16] m_integerMv2Nx2N[0][] as each CTU left it (carried in coding order)
+  MvD *intMv;                        // [numCtus][2][16] m_integerMv2Nx2N as each CTU left it (carried in coding order)
   // slice parameters (TEncSlice::setUpLambda, TEncSlice.cpp:132-159)
   double lambda, sqrtLambda, lambdaC, chromaWeight;
   double errScale[2][4];             // [luma/chroma][log2-2]  TComTrQuant::setErrScaleCoeff :2933

@@ -206,7 +206,7 @@ class Encoder:
                 conv[id(ref_pics)] = refs
             refs = conv[id(ref_pics)]
             s = descs[k]
-            s.base = SliceDesc(1, int(sp["qp"]), float(sp["lambda"]), float(sp["chroma_weight"]))
+            s.base = SliceDesc(int(sp.get("slice_type", 1)), int(sp["qp"]), float(sp["lambda"]), float(sp["chroma_weight"]))
             s.poc, s.cabac_init_type = int(sp["poc"]), int(sp["cabac_init_type"])
             for l in range(2):
                 s.num_ref_idx[l] = int(sp["num_ref_idx"][l])

@@ -89,11 +89,12 @@ int hm355_compress_slice(hm355_ctx *ctx, const hm355_slice_desc *slice, const hm
 int hm355_compress_slices(hm355_ctx *ctx, int n, const hm355_slice_desc *slices, const hm355_planes *org,
                           hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_slice_stats *stats);
 
-/* ---- P slices (encoder_lowdelay_P_main.cfg): the reference pictures and slice-header values that
- * TEncSlice::compressSlice finds through pcSlice->getRefPic(list, idx) / TComSlice getters are inputs.
- * Replaces the same member for P slices: merge / skip, AMVP, TZ integer search + fractional refinement
- * (TEncSearch::predInterSearch / xMotionEstimation, TEncSearch.cpp:3075-3906), AMP, inter RQT
- * (xEstimateResidualQT :4680) and the intra candidates of P slices.  B slices: not yet. ---- */
+/* ---- P and B slices (encoder_lowdelay_P_main.cfg, encoder_lowdelay_main.cfg, encoder_randomaccess_main*.cfg): the reference
+ * pictures and slice-header values that TEncSlice::compressSlice finds through pcSlice->getRefPic(list, idx) / TComSlice
+ * getters are inputs.  Replaces the same member for inter slices: merge / skip, AMVP, TZ integer search + fractional
+ * refinement (TEncSearch::predInterSearch / xMotionEstimation, TEncSearch.cpp:3075-3906), bi-prediction search
+ * (xPatternSearch :3932, GPB shortcut, mvd_l1_zero), AMP, inter RQT (xEstimateResidualQT :4680) and the intra candidates of
+ * inter slices.  Weighted prediction off, FEN on (one bi-prediction iteration), as in the reference's cfg files. ---- */
 typedef struct {
   int32_t poc, slice_type, long_term;
   const uint16_t *plane[3];           /* TComPic::getPicYuvRec() after the loop filters, tightly packed */
@@ -103,7 +104,7 @@ typedef struct {
   int32_t num_ref[2], ref_poc[2][16], ref_lt[2][16];   /* reference lists that picture was coded with (TMVP scaling) */
 } hm355_ref_pic;
 typedef struct {
-  hm355_slice_desc base;              /* slice_type 1 (P), qp, lambda, chroma weight */
+  hm355_slice_desc base;              /* slice_type 1 (P) or 0 (B), qp, lambda, chroma weight */
   int32_t poc;
   int32_t cabac_init_type;            /* context table in use (TEncSbac::resetEntropy, TEncSbac.cpp:106-115): 0 = B, 1 = P */
   int32_t num_ref_idx[2];

@@ -115,7 +115,7 @@ def assert_inter_ctus_equal(ctus, ictus, want, what):
 
 def ldp_slice_inputs(r, finals):
     """(slice_params, ref_pics) in the form hm355.Encoder.compress_inter takes, from an 'S' record and the 'F' records"""
-    sp = {k: r[k] for k in ("qp", "lambda", "poc", "cabac_init_type", "num_ref_idx", "ref_poc", "col_from_l0", "col_ref_idx", "tmvp",
+    sp = {k: r[k] for k in ("slice_type", "qp", "lambda", "poc", "cabac_init_type", "num_ref_idx", "ref_poc", "col_from_l0", "col_ref_idx", "tmvp",
                             "mvd_l1_zero", "max_merge_cand", "check_ldc", "lambda_motion_sad", "lambda_motion_sse")}
     sp["chroma_weight"] = r["weight_cb"]
     refs = {}

@@ -1,6 +1,6 @@
 // DEBUGGING AID, NOT PRODUCT: the P-slice path of hm-16.2_amd/csrc/hm355_core.h compiled for the host with one "lane"
 // (see hostsim.cpp), driven by an HMD2 record stream of the real reference (oracle/ref_harness.cpp, `hm_dump enc2`):
-// every P slice is re-run with the slice parameters and reference pictures of its record and compared in place.
+// every P or B slice is re-run with the slice parameters and reference pictures of its record and compared in place.
 //   hostsim_inter <in.yuv> <dump2.bin> <w> <h> <bitdepth> [wpp]   exit code 0 = every P slice bit-exact
 #define HM355_HOSTSIM 1
 #include "../../hm-16.2_amd/csrc/hm355_core.h"
@@ -80,7 +80,7 @@ int main(int argc, char **argv)
     }
     std::vector<uint16_t> wantRec[3];
     for (int c = 0; c < 3; c++) { wantRec[c].resize((size_t)(w >> (c ? 1 : 0)) * (h >> (c ? 1 : 0))); rdbuf(wantRec[c].data(), wantRec[c].size() * 2); }
-    if (sliceType != HM_P_SLICE) continue;
+    if (sliceType != HM_P_SLICE && sliceType != HM_B_SLICE) continue;
     nP++;
     FrameBuf fb; memset(&fb, 0, sizeof(fb));
     fseek(fy, (long)(frameBytes * poc), SEEK_SET);
@@ -96,7 +96,7 @@ int main(int argc, char **argv)
     }
     fb.meta = (CtuMeta *)calloc(nctu, sizeof(CtuMeta)); fb.coef = (TCoeff *)calloc((size_t)nctu * HM_COEF_CTU, sizeof(TCoeff));
     fb.stat = (CtuStat *)calloc(nctu, sizeof(CtuStat)); fb.endState = (Cabac *)calloc(nctu, sizeof(Cabac));
-    fb.imeta = (InterMeta *)calloc(nctu, sizeof(InterMeta)); fb.intMv = (MvD *)calloc((size_t)nctu * 16, sizeof(MvD));
+    fb.imeta = (InterMeta *)calloc(nctu, sizeof(InterMeta)); fb.intMv = (MvD *)calloc((size_t)nctu * 32, sizeof(MvD));
     InterPic *ip = (InterPic *)calloc(1, sizeof(InterPic)); fb.ip = ip;
     ip->sliceType = sliceType; ip->poc = poc; ip->numRefIdx[0] = numRef[0]; ip->numRefIdx[1] = numRef[1];
     ip->colFromL0 = misc[0]; ip->colRefIdx = misc[1]; ip->tmvp = misc[2]; ip->mvdL1Zero = misc[3]; ip->maxMergeCand = misc[4]; ip->checkLDC = misc[5]; ip->cabacInitType = misc[6];
@@ -107,6 +107,7 @@ int main(int argc, char **argv)
       r.poc = f.poc; r.isLongTerm = refLT[l][i]; r.predMode = f.pm.data();
       for (int ll = 0; ll < 2; ll++) { r.mv[ll] = f.mv[ll].data(); r.refIdx[ll] = f.ri[ll].data(); memcpy(r.refPoc[ll], f.refPoc[ll], sizeof(r.refPoc[ll])); memcpy(r.refLT[ll], f.refLT[ll], sizeof(r.refLT[ll])); }
     }
+    for (int i1 = 0; i1 < numRef[1]; i1++) { ip->list1ToList0[i1] = -1; for (int i0 = 0; i0 < numRef[0]; i0++) if (refPoc[0][i0] == refPoc[1][i1]) { ip->list1ToList0[i1] = i0; break; } }
     hm355_fill_slice_params(&fb, bd, qp, lambda, wcb);
     P.frames = &fb;
     for (int a = 0; a < nctu; a++) { WorkItem it; it.frame = 0; it.ctuX = a % P.wCtu; it.ctuY = a / P.wCtu; it.pad = 0; process_ctu(&sh, &P, &it, 0); }

@@ -42,15 +42,15 @@ def test_hip_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, qp, wpp, seed):
     enc.close()
 
 
-@pytest.mark.parametrize("name", common.LDP_CASES)
-def test_hip_p_slices_match_reference_fixture(hm, name):
-    """encoder_lowdelay_P_main.cfg clips: every P slice through hm355_compress_slice_inter with the reference pictures and
-    slice parameters the reference's compressSlice saw; decisions, motion, coefficients, costs, reconstruction bit-exact."""
+@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES)
+def test_hip_p_and_b_slices_match_reference_fixture(hm, name):
+    """low-delay P, random access and low-delay B clips: every P / B slice through hm355_compress_slice_inter with the reference
+    pictures and slice parameters the reference's compressSlice saw; decisions, motion, coefficients, costs, reconstruction bit-exact."""
     cfg, slices, finals = common.load_ldp_case(name)
     enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=1)
     n_p = 0
     for r in slices:
-        if int(r["slice_type"]) != 1:
+        if int(r["slice_type"]) == 2:
             continue
         planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"])
         sp, refs = common.ldp_slice_inputs(r, finals)
@@ -81,12 +81,12 @@ def test_hip_p_slice_batch_equals_single(hm):
     enc.close()
 
 
-def test_hip_p_slice_rejects_b_slices(hm):
+def test_hip_inter_slice_rejects_bad_parameters(hm):
     cfg, slices, finals = common.load_ldp_case(common.LDP_CASES[0])
     r = [s for s in slices if int(s["slice_type"]) == 1][0]
     enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 0, max_batch=1)
     sp, refs = common.ldp_slice_inputs(r, finals)
-    sp["num_ref_idx"] = (sp["num_ref_idx"][0], 1)
+    sp["num_ref_idx"] = (sp["num_ref_idx"][0], 1)                  # a P slice has no list 1
     sp["ref_poc"] = np.array(sp["ref_poc"]); sp["ref_poc"][1][0] = sp["ref_poc"][0][0]
     with pytest.raises(RuntimeError):
         enc.compress_inter(synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"]), sp, refs)
