@@ -96,37 +96,114 @@ def cpu_baseline(width, bit_depth, qp, seed):
     return {"value": n_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port", "sample": sample}
 
 
-def run_ldp_p(args, torch):
-    """Secondary workload (BASELINE.json configs[2], the inter ME path): P slices of encoder_lowdelay_P_main, synthetic 1920x1080 8-bit,
-    4 reference pictures, SearchRange 64, `--frames` independent streams per step (one current picture each, WaveFrontSynchro=1).
-    The reference pictures are HIP-path I-slice reconstructions of the same clip.  Reference pictures enter through host buffers in
-    this entry point, so `value` is CTUs / HIP-event kernel time and `call_s` is the PCIe-inclusive wall time of the call."""
+# GOP tables of the reference's inter configurations (cfg/encoder_lowdelay_P_main.cfg:24-27, cfg/encoder_randomaccess_main10.cfg:24-31)
+REF_CFG_INTER = {
+    "ldp_p": ("main", 8, """IntraPeriod : -1
+DecodingRefreshType : 0
+GOPSize : 4
+Frame1:  P    1   3        0.4624   0            0               0           4                4         -1 -5 -9 -13       0
+Frame2:  P    2   2        0.4624   0            0               0           4                4         -1 -2 -6 -10       1      -1       5         1 1 1 0 1
+Frame3:  P    3   3        0.4624   0            0               0           4                4         -1 -3 -7 -11       1      -1       5         0 1 1 1 1
+Frame4:  P    4   1        0.578    0            0               0           4                4         -1 -4 -8 -12       1      -1       5         0 1 1 1 1
+"""),
+    "ra_b": ("main10", 10, """IntraPeriod : 32
+DecodingRefreshType : 1
+GOPSize : 8
+Frame1:  B    8   1        0.442    0            0              0           4                4         -8 -10 -12 -16         0
+Frame2:  B    4   2        0.3536   0            0              0           2                3         -4 -6  4               1       4        5         1 1 0 0 1
+Frame3:  B    2   3        0.3536   0            0              0           2                4         -2 -4  2 6             1       2        4         1 1 1 1
+Frame4:  B    1   4        0.68     0            0              1           2                4         -1  1  3 7             1       1        5         1 0 1 1 1
+Frame5:  B    3   4        0.68     0            0              1           2                4         -1 -3  1 5             1      -2        5         1 1 1 1 0
+Frame6:  B    6   3        0.3536   0            0              0           2                4         -2 -4 -6 2             1      -3        5         1 1 1 1 0
+Frame7:  B    5   4        0.68     0            0              1           2                4         -1 -5  1 3             1       1        5         1 0 1 1 1
+Frame8:  B    7   4        0.68     0            0              1           2                4         -1 -3 -7 1             1      -2        5         1 1 1 1 0
+"""),
+}
+
+
+def cpu_baseline_inter(kind, qp):
+    """The reference's own encoder (oracle/_ref/hm_encoder) on one host core for the same configuration: a 416x240 clip encoded with
+    1 picture and with 1 + n inter pictures; the difference is the time of the n inter pictures (whole encoder: the search dominates)."""
+    import synth
+    enc = os.path.join(ROOT, "oracle", "_ref", "hm_encoder")
+    if not os.path.exists(enc):
+        return None
+    profile, bd, gop = REF_CFG_INTER[kind]
+    w, h, n_inter = 416, 240, 8
+    common = REF_CFG.split("IntraPeriod")[0] + "".join(l + "\n" for l in REF_CFG.splitlines() if l.split(" ")[0] in (
+        "FastSearch", "SearchRange", "HadamardME", "FEN", "FDM", "QP", "MaxDeltaQP", "MaxCuDQPDepth", "DeltaQpRD", "RDOQ", "RDOQTS", "SAO", "AMP",
+        "TransformSkip", "TransformSkipFast"))
+    cfg_text = common + gop + f"BipredSearchRange : 4\nInternalBitDepth : {bd}\nProfile : {profile}\n"
+    times = []
+    with tempfile.TemporaryDirectory() as td:
+        yuv = os.path.join(td, "in.yuv")
+        synth.write_yuv(yuv, w, h, bd, 1 + n_inter, 1234)
+        cfg = os.path.join(td, "inter.cfg")
+        open(cfg, "w").write(cfg_text)
+        for frames in (1, 1 + n_inter):
+            cmd = [enc, "-c", cfg, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "50", "-f", str(frames), f"--InputBitDepth={bd}", "-q", str(qp),
+                   "-b", os.path.join(td, "o.bin"), "-o", os.path.join(td, "r.yuv")]
+            t0 = time.time()
+            out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+            dt = time.time() - t0
+            for line in out.splitlines():
+                if "Total Time" in line:
+                    dt = float(line.split()[2])
+            times.append(dt)
+    n_ctus = 7 * 4 * n_inter
+    return {"value": n_ctus / max(1e-9, times[1] - times[0]), "unit": "CTU/s", "cores": 1, "kind": "reference",
+            "sample": f"{n_inter} inter pictures of a 416x240 {bd}-bit clip ({n_ctus} CTUs), same cfg, QP {qp}; HM 'Total Time' of 1+{n_inter} pictures minus 1 picture"}
+
+
+def run_inter(args, torch):
+    """Secondary workloads: inter slices through hm355_compress_slices_inter, `--frames` independent streams per step (one current
+    picture each, WaveFrontSynchro=1); the reference pictures are HIP-path I-slice reconstructions of the same synthetic clip,
+    shifted per stream so that every stream has its own data.
+      ldp_p (BASELINE.json configs[2]): encoder_lowdelay_P_main P slices, 1920x1080 8-bit, 4 references, SearchRange 64
+      ra_b  (BASELINE.json configs[4]): encoder_randomaccess_main10 B slices, 3840x2160 10-bit, 2 + 2 references (POC 4 between POC 0 and 8)
+    Reference pictures enter through host buffers in this entry point, so `value` is CTUs / HIP-event kernel time and `call_s` is
+    the PCIe-inclusive wall time of the call."""
     import math
     import hm355
     import synth
-    w, h, bd, qp, nref, S = 1920, 1080, 8, args.qp, 4, args.frames
+    kind, qp, S = args.workload, args.qp, args.frames
+    if kind == "ldp_p":
+        w, h, bd, nref, qpp, qpf, ref_idx_pocs, cur_poc = 1920, 1080, 8, 4, qp + 3, 0.4624, [3, 2, 1, 0], 4
+    else:
+        w, h, bd, nref, qpp, qpf, ref_idx_pocs, cur_poc = 3840, 2160, 10, 2, qp + 2, 0.3536, [0, 8], 4
     enc = hm355.Encoder(w, h, bd, 1, max(S, nref))
     n = enc.num_ctus
-    frames = [synth.frame(w, h, bd, i, 1234) for i in range(nref + min(S, 4))]
-    res = enc.compress(frames[:nref], qp)
+    ref_frames = sorted(set(ref_idx_pocs))
+    res = enc.compress([synth.frame(w, h, bd, f, 1234) for f in ref_frames], qp)
     refs = {}
-    for i in range(nref):
-        refs[i] = dict(slice_type=2, rec=res[i][0], pred_mode=np.ones((n, 256), np.uint8), mv=[np.zeros((n, 256, 2), np.int16)] * 2,
+    for k, f in enumerate(ref_frames):
+        refs[f] = dict(slice_type=2, rec=res[k][0], pred_mode=np.ones((n, 256), np.uint8), mv=[np.zeros((n, 256, 2), np.int16)] * 2,
                        ref_idx=[np.full((n, 256), -1, np.int8)] * 2, num_ref_idx=(0, 0), ref_poc=np.zeros((2, 16), np.int32),
                        ref_long_term=np.zeros((2, 16), np.int32))
-    qpp = qp + 3                                                       # QPoffset of the first GOP entry (cfg/encoder_lowdelay_P_main.cfg:24)
-    lam = 0.4624 * 2.0 ** ((qpp - 12) / 3.0) * min(4.0, max(2.0, (qpp - 12) / 6.0))      # TEncSlice.cpp:323-352
+    lam = qpf * 2.0 ** ((qpp - 12) / 3.0) * min(4.0, max(2.0, (qpp - 12) / 6.0))          # TEncSlice.cpp:323-352
     ref_poc = np.zeros((2, 16), np.int32)
-    ref_poc[0, :nref] = list(range(nref - 1, -1, -1))
-    sp = dict(qp=qpp, chroma_weight=hm355.intra_lambda(qpp)[1], poc=nref, cabac_init_type=1, num_ref_idx=(nref, 0), ref_poc=ref_poc,
-              col_from_l0=1, col_ref_idx=0, tmvp=1, mvd_l1_zero=0, max_merge_cand=5, check_ldc=1,
+    ref_poc[0, :nref] = ref_idx_pocs
+    if kind == "ra_b":
+        ref_poc[1, :nref] = ref_idx_pocs[::-1]
+    sp = dict(slice_type=1 if kind == "ldp_p" else 0, qp=qpp, chroma_weight=hm355.intra_lambda(qpp)[1], poc=cur_poc,
+              cabac_init_type=1 if kind == "ldp_p" else 0, num_ref_idx=(nref, 0 if kind == "ldp_p" else nref), ref_poc=ref_poc,
+              col_from_l0=1, col_ref_idx=0, tmvp=1, mvd_l1_zero=0, max_merge_cand=5, check_ldc=1 if kind == "ldp_p" else 0,
               lambda_motion_sad=int(math.floor(65536.0 * math.sqrt(lam))), lambda_motion_sse=int(math.floor(65536.0 * lam)))
     sp["lambda"] = lam
-    jobs = [(frames[nref + (s % min(S, 4))], sp, refs) for s in range(S)]
+    # every stream gets its own pictures in HBM: the clip shifted by a stream-specific offset (whole CTU-misaligned steps), so streams
+    # neither share reference data in the caches nor repeat each other's decisions
+    cur0 = synth.frame(w, h, bd, cur_poc, 1234)
+    def shifted(planes, k):
+        dx, dy = (24 * k) % w, (8 * k) % h
+        return [np.ascontiguousarray(np.roll(np.roll(p, dy >> (1 if i else 0), axis=0), dx >> (1 if i else 0), axis=1)) for i, p in enumerate(planes)]
+    jobs = []
+    for k in range(S):
+        rk = {f: dict(r, rec=shifted(r["rec"], k)) for f, r in refs.items()} if k else refs
+        jobs.append((shifted(cur0, k) if k else cur0, sp, rk))
     kernel_ms, wall = 0.0, 0.0
     for it in range(args.warmup + args.steps):
         t0 = time.perf_counter()
-        enc.compress_inter_batch(jobs)
+        out = enc.compress_inter_batch(jobs)
         torch.cuda.synchronize()
         k, l = hm355.C.c_double(), hm355.C.c_int()
         enc.lib.hm355_last_run_info(enc.h_, hm355.C.byref(k), hm355.C.byref(l))
@@ -134,22 +211,33 @@ def run_ldp_p(args, torch):
             kernel_ms += k.value
             wall += time.perf_counter() - t0
     ctus = n * S * args.steps
-    alg = 54278 + nref * 80000 + 4608                                  # intra bytes + search window per reference + MV fields
+    alg = 54278 + (nref if kind == "ldp_p" else 2 * nref) * 80000 + 4608        # intra bytes + search window per reference + MV fields
     ach = alg * ctus / (kernel_ms * 1e-3) / 1e9
-    print(json.dumps({
-        "metric": "CTUs/sec (enc), P slices, 1080p 8-bit; bit-exact CU partition / MV vs HM", "value": ctus / (kernel_ms * 1e-3), "unit": "CTU/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": kernel_ms / args.steps, "higher_is_better": True,
+    what = ("encoder_lowdelay_P_main P slices, synthetic 1920x1080 8-bit, 4 references" if kind == "ldp_p"
+            else "encoder_randomaccess_main10 B slices, synthetic 3840x2160 10-bit, 2 + 2 references, BipredSearchRange 4")
+    line = {
+        "metric": f"CTUs/sec (enc), {'P' if kind == 'ldp_p' else 'B'} slices; bit-exact CU partition / MV vs HM", "value": ctus / (kernel_ms * 1e-3),
+        "unit": "CTU/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": kernel_ms / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic", "call_s": wall / args.steps,
-        "config": {"workload": f"encoder_lowdelay_P_main P slices, synthetic 1920x1080 8-bit, {nref} references, SearchRange 64, QP {qpp}, "
-                               f"WaveFrontSynchro=1, {S} independent streams per step", "streams": S, "ctus_per_step": n * S},
+        "config": {"workload": f"{what}, SearchRange 64, QP {qpp}, WaveFrontSynchro=1, {S} independent streams per step", "streams": S,
+                   "ctus_per_step": n * S,
+                   "mode_mix": {"skip": float(np.mean([(o[2]["skip"] != 0).mean() for o in out])),
+                                "bi": float(np.mean([(o[2]["inter_dir"] == 3).mean() for o in out])),
+                                "intra": float(np.mean([(o[1]["pred_mode"] == 1).mean() for o in out]))}},
         "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "traffic": None, "note": f"algorithmic bytes {alg} B/CTU (SURVEY 8d, {nref} references)"}}))
+                     "traffic": None, "note": f"algorithmic bytes {alg} B/CTU (SURVEY 8d)"}}
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline_inter(kind, qp)
+        if cb:
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_1core"] = line["value"] / cb["value"]
+    print(json.dumps(line))
     enc.close()
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p"], help="intra4k = the BASELINE.json metric (default)")
+    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
@@ -167,10 +255,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: hm355 has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if args.workload == "ldp_p":
+    if args.workload != "intra4k":
         if world > 1:
-            raise SystemExit("--workload ldp_p is a single-GPU measurement")
-        return run_ldp_p(args, torch)
+            raise SystemExit("--workload ldp_p / ra_b are single-GPU measurements")
+        return run_inter(args, torch)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -43,9 +43,11 @@ static inline int hm_wave_max_i(int v) { return v; }
 #define HM_ENTRY(e) ((void)0)
 #define HM_LDS_ADD(p, v) (*(p) += (v))
 #ifdef HM355_HOSTSIM_REVERSE   /* run every lane-parallel loop backwards: catches order dependence */
+#define HM_PAR_FOR_XY(x, y, w, n) for (int i_ = (n) - 1, y = i_ / (w), x = i_ - y * (w); i_ >= 0; i_--, x--, (x < 0 ? (x = (w) - 1, y--) : 0))
 #define HM_PAR_FOR(i, n) for (int i = (n) - 1; i >= 0; i--)
 #define HM_WAVE_FOR(k) for (int k = 63; k >= 0; k--)
 #else
+#define HM_PAR_FOR_XY(x, y, w, n) for (int i_ = 0, y = 0, x = 0; i_ < (n); i_++, x++, (x >= (w) ? (x = 0, y++) : 0))
 #define HM_PAR_FOR(i, n) for (int i = 0; i < (n); i++)
 #define HM_WAVE_FOR(k) for (int k = 0; k < 64; k++)
 #endif
@@ -124,6 +126,11 @@ template <class T> __device__ __forceinline__ T hm_uni_struct(T v)
 #define HM_ENTRY(e) ((e) = &g_sh)
 #define HM_UCALL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define HM_PAR_FOR(i, n) for (int i = hm_lane(); i < (n); i += HM_NT)
+// lane-parallel loop over the first n samples of a rectangle of width w in raster order, with the (x, y) of a lane's sample kept
+// incrementally (one division per loop instead of one per sample; w need not be a power of two: AMP widths 12, 24, 48)
+#define HM_PAR_FOR_XY(x, y, w, n) \
+  for (int i_ = hm_lane(), sy_ = HM_NT / (w), sx_ = HM_NT - sy_ * (w), y = i_ / (w), x = i_ - y * (w); i_ < (n); \
+       i_ += HM_NT, x += sx_, y += sy_, (x >= (w) ? (x -= (w), y++) : 0))
 // Lane variables: one value per lane of the wavefront, held in a VGPR.  HM_WAVE_FOR runs its body once on every
 // lane (k = lane id, all lanes active); a wave-uniform lane index reads a lane with v_readlane and writes one with
 // a compare + select (no memory access); a per-lane index gathers through ds_bpermute; HM_BALLOT collects a predicate.

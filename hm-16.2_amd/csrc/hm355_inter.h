@@ -52,12 +52,12 @@ HM_DEV inline Pel if_sample(int bitDepth, const Pel *src, int cs, int frac, int 
 HM_DEV inline void interp_block(Shared *e, int chroma, const Pel *r, int refStride, int xFrac, int yFrac, int cw, int ch, Pel *dst, int dstStride, int twoStage, int bi = 0)
 {
   const int bd = e->bitDepth, last = !bi;
-  if (!twoStage && yFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, 1, xFrac, chroma, 1, last); } HM_SYNC(); return; }
-  if (!twoStage && xFrac == 0) { HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, refStride, yFrac, chroma, 1, last); } HM_SYNC(); return; }
+  if (!twoStage && yFrac == 0) { HM_PAR_FOR_XY(x, y, cw, cw * ch) dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, 1, xFrac, chroma, 1, last); HM_SYNC(); return; }
+  if (!twoStage && xFrac == 0) { HM_PAR_FOR_XY(x, y, cw, cw * ch) dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, refStride, yFrac, chroma, 1, last); HM_SYNC(); return; }
   Pel *tmp = e->ws->mcTmp; const int half = chroma ? 1 : 3, rows = ch + (chroma ? 3 : 7);
-  HM_PAR_FOR(i, cw * rows) { const int y = i / cw, x = i - y * cw; tmp[y * 64 + x] = if_sample(bd, r + (y - half) * refStride + x, 1, xFrac, chroma, 1, 0); }
+  HM_PAR_FOR_XY(x, y, cw, cw * rows) tmp[y * 64 + x] = if_sample(bd, r + (y - half) * refStride + x, 1, xFrac, chroma, 1, 0);
   HM_SYNC();
-  HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw; dst[y * dstStride + x] = if_sample(bd, tmp + (y + half) * 64 + x, 64, yFrac, chroma, 0, last); }
+  HM_PAR_FOR_XY(x, y, cw, cw * ch) dst[y * dstStride + x] = if_sample(bd, tmp + (y + half) * 64 + x, 64, yFrac, chroma, 0, last);
   HM_SYNC();
 }
 HM_DEV inline MvD clip_mv(const Shared *e, MvD mv, int cuX, int cuY)
@@ -87,14 +87,62 @@ HM_DEV inline uint32_t dist_sad_rect(const Pel *org, int so, const Pel *cur, int
 {
   const int rows = h >> subShift;
   uint32_t sum = 0;
-  HM_PAR_FOR(i, rows * w) { const int yy = i / w, x = i - yy * w, y = yy << subShift; sum += (uint32_t)hm_abs(org[y * so + x] - cur[y * sc + x]); }
+  const int so2 = so << subShift, sc2 = sc << subShift;
+  HM_PAR_FOR_XY(x, yy, w, rows * w) sum += (uint32_t)hm_abs(org[yy * so2 + x] - cur[yy * sc2 + x]);
   return (hm_wave_sum(sum) << subShift) >> (bitDepth - 8);
 }
+#if !defined(HM355_HOSTSIM)
+// Small blocks leave most lanes idle when a lane owns a whole 8x8 / 4x4 Hadamard block, so they are transformed across lanes
+// instead: a lane holds one difference sample and the 2-D Hadamard is log2(N) butterfly exchange stages (the set of |coefficients|
+// does not depend on the butterfly order, so the sum equals xCalcHADs8x8 / xCalcHADs4x4 exactly).
+__device__ __forceinline__ int hm_bfly(int v, int m)
+{
+  int t;
+  if (m == 1) t = hm_dpp<0xB1>(0, v);                               // quad_perm [1,0,3,2]
+  else if (m == 2) t = hm_dpp<0x4E>(0, v);                          // quad_perm [2,3,0,1]
+  else t = __shfl_xor(v, m, 64);
+  return (hm_lane() & m) ? (t - v) : (v + t);
+}
+__device__ __forceinline__ uint32_t had8_wave(const Pel *org, int so, const Pel *cur, int sc)
+{ // one 8x8 block per pass: lane = y*8 + x
+  const int l = hm_lane(), x = l & 7, y = l >> 3;
+  int v = org[y * so + x] - cur[y * sc + x];
+  v = hm_bfly(v, 1); v = hm_bfly(v, 2); v = hm_bfly(v, 4); v = hm_bfly(v, 8); v = hm_bfly(v, 16); v = hm_bfly(v, 32);
+  return (hm_wave_sum((uint32_t)hm_abs(v)) + 2) >> 2;
+}
+__device__ __forceinline__ uint32_t had4_wave4(const Pel *org, int so, const Pel *cur, int sc, int b0, int nb, int nbx)
+{ // four 4x4 blocks per pass, one per 16-lane row: lane = blk*16 + y*4 + x
+  const int l = hm_lane(), bi = b0 + (l >> 4), x = l & 3, y = (l >> 2) & 3;
+  int v = 0;
+  if (bi < nb) { const int by = bi / nbx, bx = bi - by * nbx; v = org[(by * 4 + y) * so + bx * 4 + x] - cur[(by * 4 + y) * sc + bx * 4 + x]; }
+  v = hm_bfly(v, 1); v = hm_bfly(v, 2); v = hm_bfly(v, 4); v = hm_bfly(v, 8);
+  int a = hm_abs(v);
+  a += hm_dpp<0x111>(0, a); a += hm_dpp<0x112>(0, a); a += hm_dpp<0x114>(0, a); a += hm_dpp<0x118>(0, a);     // per-row sums in lanes 15/31/47/63
+  const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane(a, 15), s1 = (uint32_t)__builtin_amdgcn_readlane(a, 31);
+  const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane(a, 47), s3 = (uint32_t)__builtin_amdgcn_readlane(a, 63);
+  return ((s0 + 1) >> 1) + ((s1 + 1) >> 1) + ((s2 + 1) >> 1) + ((s3 + 1) >> 1);
+}
+#endif
 HM_DEV inline uint32_t dist_hads_rect(const Pel *org, int so, const Pel *cur, int sc, int w, int h, int bitDepth)
 { // xGetHADs, TComRdCost.cpp:1537-1606
   uint32_t sum = 0;
-  if ((w & 7) == 0 && (h & 7) == 0) { const int nbx = w >> 3, nb = nbx * (h >> 3); HM_PAR_FOR(b, nb) { const int by = b / nbx, bx = b - by * nbx; sum += had8(org + by * 8 * so + bx * 8, so, cur + by * 8 * sc + bx * 8, sc); } }
-  else { const int nbx = w >> 2, nb = nbx * (h >> 2); HM_PAR_FOR(b, nb) { const int by = b / nbx, bx = b - by * nbx; sum += had4(org + by * 4 * so + bx * 4, so, cur + by * 4 * sc + bx * 4, sc); } }
+  if ((w & 7) == 0 && (h & 7) == 0) {
+    const int nbx = w >> 3, nb = nbx * (h >> 3);
+#if !defined(HM355_HOSTSIM)
+    if (nb <= 12) {
+      for (int b = 0; b < nb; b++) { const int by = b / nbx, bx = b - by * nbx; sum += had8_wave(org + by * 8 * so + bx * 8, so, cur + by * 8 * sc + bx * 8, sc); }
+      return sum >> (bitDepth - 8);
+    }
+#endif
+    HM_PAR_FOR(b, nb) { const int by = b / nbx, bx = b - by * nbx; sum += had8(org + by * 8 * so + bx * 8, so, cur + by * 8 * sc + bx * 8, sc); }
+  } else {
+    const int nbx = w >> 2, nb = nbx * (h >> 2);
+#if !defined(HM355_HOSTSIM)
+    for (int b0 = 0; b0 < nb; b0 += 4) sum += had4_wave4(org, so, cur, sc, b0, nb, nbx);
+    return sum >> (bitDepth - 8);
+#endif
+    HM_PAR_FOR(b, nb) { const int by = b / nbx, bx = b - by * nbx; sum += had4(org + by * 4 * so + bx * 4, so, cur + by * 4 * sc + bx * 4, sc); }
+  }
   return hm_wave_sum(sum) >> (bitDepth - 8);
 }
 
@@ -364,9 +412,8 @@ HM_DEV HM_NOINLINE void fill_mvp_cand(Shared *e, int cuZ, int cuDepth, int partS
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline uint32_t mv_comp_bits(int val)
 {
-  uint32_t len = 1, tmp = (val <= 0) ? (uint32_t)((-val << 1) + 1) : (uint32_t)(val << 1);
-  while (tmp != 1) { tmp >>= 1; len += 2; }
-  return len;
+  const uint32_t tmp = (val <= 0) ? (uint32_t)((-val << 1) + 1) : (uint32_t)(val << 1);
+  return 1u + 2u * (uint32_t)(31 - __builtin_clz(tmp));          // xGetComponentBits (TComRdCost.cpp:278): one shift per 2 bits until tmp == 1
 }
 HM_DEV inline uint32_t mc_bits(const Shared *e, int x, int y)
 { return mv_comp_bits((x << e->costScale) - e->mvPredictor.x) + mv_comp_bits((y << e->costScale) - e->mvPredictor.y); }
@@ -494,14 +541,32 @@ HM_CONST int8_t HM_MV_REFINE_H[9][2] = { {0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0
 HM_CONST int8_t HM_MV_REFINE_Q[9][2] = { {0, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {1, 1} };
 HM_DEV inline uint32_t pattern_refinement(Shared *e, TZ *z, const Pel *refAtInt, MvD base, int frac, MvD *mvFrac)
 {
+  // The nine candidates are (tx, ty) in {-1,0,1}^2 around `base`.  Candidates with the same tx share the first (horizontal)
+  // interpolation stage, so it is done once per tx over the rows all three ty need (two integer row offsets at most);
+  // the costs are then compared in the reference's candidate order (strict <, first wins).
+  Pel *blk = e->ws->mcBlk, *tmp = e->ws->mcTmp;
+  const int bd = e->bitDepth, w = z->w, h = z->h, rs = z->refStride;
+  const int vyLo = (base.y - 1) * frac, rowLo = vyLo >> 2, rows = h + 8;      // rows rowLo-3 .. rowLo+h+4 of the reference
+  int32_t *cost9 = e->absCoeff;                                                // [(ty+1)*3 + tx+1]
+  for (int tx = -1; tx <= 1; tx++) {
+    const int hx = (tx + base.x) * frac, xFrac = hx & 3;
+    const Pel *r = refAtInt + (ptrdiff_t)(rowLo - 3) * rs + (hx >> 2);
+    HM_PAR_FOR_XY(x, y, w, w * rows) tmp[y * 64 + x] = if_sample(bd, r + (ptrdiff_t)y * rs + x, 1, xFrac, 0, 1, 0);
+    HM_SYNC();
+    for (int ty = -1; ty <= 1; ty++) {
+      const int vy = (ty + base.y) * frac, yFrac = vy & 3, ro = (vy >> 2) - rowLo;
+      HM_PAR_FOR_XY(x, y, w, w * h) blk[y * 64 + x] = if_sample(bd, tmp + (y + ro + 3) * 64 + x, 64, yFrac, 0, 0, 1);
+      HM_SYNC();
+      uint32_t d = dist_hads_rect(z->org, z->orgStride, blk, 64, w, h, bd);
+      d += mc_cost32(e, mc_bits(e, tx + mvFrac->x, ty + mvFrac->y));
+      cost9[(ty + 1) * 3 + tx + 1] = (int32_t)d;
+    }
+  }
+  HM_SYNC();
   uint32_t best = 0xffffffffu; int bestDir = 0;
-  Pel *blk = e->ws->mcBlk;
   for (int i = 0; i < 9; i++) {
     const int tx = frac == 2 ? HM_MV_REFINE_H[i][0] : HM_MV_REFINE_Q[i][0], ty = frac == 2 ? HM_MV_REFINE_H[i][1] : HM_MV_REFINE_Q[i][1];
-    const int hx = (tx + base.x) * frac, vy = (ty + base.y) * frac;
-    interp_block(e, 0, refAtInt + (ptrdiff_t)(vy >> 2) * z->refStride + (hx >> 2), z->refStride, hx & 3, vy & 3, z->w, z->h, blk, 64, 1);
-    uint32_t d = dist_hads_rect(z->org, z->orgStride, blk, 64, z->w, z->h, e->bitDepth);
-    d += mc_cost32(e, mc_bits(e, tx + mvFrac->x, ty + mvFrac->y));
+    const uint32_t d = (uint32_t)cost9[(ty + 1) * 3 + tx + 1];
     if (d < best) { best = d; bestDir = i; }
   }
   mvFrac->x = frac == 2 ? HM_MV_REFINE_H[bestDir][0] : HM_MV_REFINE_Q[bestDir][0];
@@ -536,7 +601,7 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   z.org = e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px; z.orgStride = e->stride[0]; z.w = r.w; z.h = r.h;
   if (bi) {
     const Pel *other = e->ws->yuvPred[1 - list], *org = z.org; Pel *ob = e->ws->orgBi; const int so = z.orgStride;
-    HM_PAR_FOR(i, r.w * r.h) { const int y = i / r.w, x = i - y * r.w; ob[(r.y + y) * 64 + r.x + x] = (Pel)(2 * org[y * so + x] - other[(r.y + y) * 64 + r.x + x]); }
+    HM_PAR_FOR_XY(x, y, r.w, r.w * r.h) ob[(r.y + y) * 64 + r.x + x] = (Pel)(2 * org[y * so + x] - other[(r.y + y) * 64 + r.x + x]);
     HM_SYNC();
     z.org = ob + r.y * 64 + r.x; z.orgStride = 64;
   }
@@ -603,7 +668,7 @@ HM_DEV inline void motion_compensation_pu(Shared *e, int cuZ, Rect r, Pel *dst, 
     const int bd = e->bitDepth, shiftNum = ((14 - bd) > 2 ? (14 - bd) : 2) + 1, offset = (1 << (shiftNum - 1)) + 2 * HM_IF_OFFS, maxv = (1 << bd) - 1;
     for (int c = 0; c < 3; c++) {
       const int st = HM_PLANE_STRIDE(c), sh = c ? 1 : 0, o0 = HM_PLANE_OFF(c) + (r.y >> sh) * st + (r.x >> sh), cw = r.w >> sh, ch = r.h >> sh;
-      HM_PAR_FOR(i, cw * ch) { const int y = i / cw, x = i - y * cw, o = o0 + y * st + x; dst[o] = (Pel)hm_clip3(0, maxv, (p0[o] + p1[o] + offset) >> shiftNum); }
+      HM_PAR_FOR_XY(x, y, cw, cw * ch) { const int o = o0 + y * st + x; dst[o] = (Pel)hm_clip3(0, maxv, (p0[o] + p1[o] + offset) >> shiftNum); }
     }
     HM_SYNC();
     return;
