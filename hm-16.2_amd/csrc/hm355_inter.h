@@ -596,8 +596,7 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
   const RefPicDev *ref = &s->ref[list][refIdx];
   MvD mvPred; mvPred.x = (int16_t)predX; mvPred.y = (int16_t)predY;
-  TZ *zp = &e->tz;
-#define z (*zp)
+  TZ &z = e->tz;
   z.org = e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px; z.orgStride = e->stride[0]; z.w = r.w; z.h = r.h;
   if (bi) {
     const Pel *other = e->ws->yuvPred[1 - list], *org = z.org; Pel *ob = e->ws->orgBi; const int so = z.orgStride;
@@ -638,7 +637,6 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   e->outMv = mv; e->outBits = bits;
   e->outDist = (uint32_t)(floor((bi ? 0.5 : 1.0) * ((double)c - (double)mc_cost32(e, mvBits))) + (double)mc_cost32(e, bits));
   HM_TRACE(e, 2, ((uint32_t)(uint16_t)mv.x << 16) | (uint16_t)mv.y, bits, (double)e->outDist);
-#undef z
 }
 
 // xPredInterUni :586: one list of one PU into a CTU-relative scratch picture (bi: 14-bit intermediate, no rounding)
