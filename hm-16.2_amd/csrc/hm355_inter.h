@@ -1134,6 +1134,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
   const int z = t->cuZ + t->relZ, fullDepth = t->cuDepth + t->trDepth, trMode = t->trDepth, layer = 5 - t->log2;
   const int minLog2 = tr_min_size_in_cu(6 - t->cuDepth, 0), bd = e->bitDepth;
   uint32_t singleDist = 0;
+  const CabacHold root = cabac_hold(&e->cur);                       // == slot[fullDepth][CI_QT_TRAFO_ROOT]: the caller stored it from e->cur just before
   par_set8(m->tr + z, trMode, t->parts);
   for (int comp = 0; comp < 3; comp++) {
     f->absSum[comp] = 0; f->bestTS[comp] = 0;
@@ -1150,7 +1151,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
     for (int tsMode = 0; tsMode < nModes; tsMode++) {
       const int isFirst = tsMode == 0, isOne = nModes == 1;
       par_set8(m->ts[comp] + zc, tsMode, parts);
-      cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+      cabac_put(&e->cur, root);
       reset_bits(&e->cur);
       uint32_t currBits = 0, currDist = 0, nonCoeffBits = 0, nonCoeffDist = 0; double currCost = 0, nonCoeffCost = 0;
       if (!isOne && !isFirst) { HM_PAR_FOR(i, 16) { e->tsCoef[comp][i] = coef[i]; e->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; } HM_SYNC(); }
@@ -1171,7 +1172,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
       }
       if (f->zero && isFirst) e->irqZeroDist += nonCoeffDist;
       if (absSum > 0) {
-        if (isFirst) { cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); reset_bits(&e->cur); }
+        if (isFirst) { cabac_put(&e->cur, root); reset_bits(&e->cur); }
         code_qt_cbf(e, &e->cur, t, comp, 1);
         code_coeff_nxn(e, &e->cur, coef, n, comp, SCAN_DIAG, tsMode);
         currBits = num_bits(&e->cur);
@@ -1218,7 +1219,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
     par_set8(m->cbf[comp] + zc, (f->absSum[comp] > 0 ? 1 : 0) << trMode, parts);
     singleDist += compDist;
   }
-  cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+  cabac_put(&e->cur, root);
   reset_bits(&e->cur);
   if (t->log2 > minLog2) enc_bin(e, &e->cur, C_SUBDIV + (5 - t->log2), 0);
   for (int ch = 0; ch < 3; ch++) { const int comp = (ch + 1 == 3) ? 0 : ch + 1; if (!(comp && !t->cW)) code_qt_cbf(e, &e->cur, t, comp, 1); }

@@ -1812,6 +1812,8 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
   return 0;
 }
 
+#include "hm_oracle_dbk.inc"
+
 int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus)
 { return compress_impl(cfg, org, rec, ctus, 0, NULL, NULL); }
 int hmo_compress_rows(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus, int max_ctus)

@@ -79,6 +79,12 @@ typedef struct {
 int hmo_compress_slice_inter(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],
                              hmo_ctu *ctus, hmo_ctu_inter *ictus);
 
+/* ---- deblocking filter (TComLoopFilter::loopFilterPic, TComLoopFilter.cpp:130-158) on the picture compressSlice left:
+ * rec is filtered in place (vertical edges of the whole picture, then horizontal edges).  cfg->qp = slice QP; ref_poc = POCs of the
+ * slice's reference pictures [list][idx] (boundary strength compares pictures); ictus may be NULL for an I slice. ---- */
+int hmo_deblock(const hmo_cfg *cfg, int slice_type, const int32_t ref_poc[2][16], const hmo_ctu *ctus, const hmo_ctu_inter *ictus,
+                uint16_t *const rec[3]);
+
 /* ---- primitives, exported for the known-answer tests (TComRdCost.cpp / TComTrQuant.cpp) ---- */
 uint32_t hmo_sad(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int sub_shift, int bit_depth);
 uint32_t hmo_sse(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int bit_depth);

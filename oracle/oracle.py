@@ -141,3 +141,22 @@ def compress_inter(planes, bit_depth, srec, finals, trace=None, wpp=0):
     if rc != 0:
         raise RuntimeError(f"oracle (inter) failed rc={rc}")
     return rec, ctus, ictus
+
+
+def deblock(rec, bit_depth, qp, slice_type, ref_poc, ctus, ictus=None):
+    """TComLoopFilter::loopFilterPic on the pre-deblocking reconstruction `rec` (3 planes); returns the filtered planes.
+    ctus / ictus: arrays in CTU_DTYPE / CTU_INTER_DTYPE layout (ictus None for an I slice)."""
+    L = lib()
+    h, w = rec[0].shape
+    cfg = Cfg(w, h, bit_depth, int(qp), 0, 1.0, 1.0)
+    out = [np.ascontiguousarray(p, np.uint16).copy() for p in rec]
+    pr = (C.c_void_p * 3)(*[p.ctypes.data for p in out])
+    rp = np.ascontiguousarray(ref_poc, np.int32)
+    c = np.ascontiguousarray(ctus)
+    assert c.dtype == CTU_DTYPE
+    ic = np.ascontiguousarray(ictus) if ictus is not None else None
+    L.hmo_deblock.argtypes = [C.POINTER(Cfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.hmo_deblock(C.byref(cfg), int(slice_type), rp.ctypes.data, c.ctypes.data, ic.ctypes.data if ic is not None else None, pr)
+    if rc != 0:
+        raise RuntimeError(f"oracle deblock failed rc={rc}")
+    return out

@@ -125,3 +125,22 @@ def ldp_slice_inputs(r, finals):
                          ref_idx=[m["ref_idx0"], m["ref_idx1"]], num_ref_idx=f["num_ref_idx"], ref_poc=f["ref_poc"],
                          ref_long_term=f["ref_long_term"])
     return sp, refs
+
+
+DBK_CASES = ["dbk_ldp_200x136_8b_qp30", "dbk_ldb_192x128_10b_qp34"]    # SAO off: 'F' record = deblocked 'S' record
+
+
+def split_fixture_ctus(want):
+    """fixture CTU records (tests/hmd2.py CTU_DT) -> (ctus, ictus) arrays in the C-ABI / oracle layouts"""
+    import hm355
+    n = len(want)
+    ctus, ictus = np.zeros(n, hm355.CTU_DTYPE), np.zeros(n, hm355.CTU_INTER_DTYPE)
+    for f in ("total_cost", "total_bits", "total_dist", "depth", "part_size", "pred_mode", "intra_dir_luma", "intra_dir_chroma", "tr_idx",
+              "cbf", "tskip", "coeff_y", "coeff_cb", "coeff_cr"):
+        ctus[f] = want[f]
+    for f, g in INTER_PAIRS:
+        ictus[f] = want[g]
+    for l in range(2):
+        for f, g in (("mv", "mv%d"), ("mvd", "mvd%d"), ("ref_idx", "ref_idx%d"), ("mvp_idx", "mvp_idx%d"), ("mvp_num", "mvp_num%d")):
+            ictus[f][:, l] = want[g % l]
+    return ctus, ictus

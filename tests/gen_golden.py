@@ -113,12 +113,15 @@ LDP_CASES = [
     # B slices: random access (hierarchical GOP 8, both directions) and low-delay B (list 1 == list 0, mvd_l1_zero)
     ("ra_192x128_10b_qp32", 192, 128, 10, 9, 32, 4321, 0, "encoder_randomaccess_main10.cfg"),
     ("ldb_200x136_8b_qp30", 200, 136, 8, 4, 30, 99, 0, "encoder_lowdelay_main.cfg"),
+    # deblocking pins: SAO off, so the finished picture ('F' record) is the deblocked pre-deblock reconstruction of the 'S' record
+    ("dbk_ldp_200x136_8b_qp30", 200, 136, 8, 3, 30, 31, 0, "encoder_lowdelay_P_main.cfg", ("--SAO=0",)),
+    ("dbk_ldb_192x128_10b_qp34", 192, 128, 10, 3, 34, 32, 0, "encoder_lowdelay_main10.cfg", ("--SAO=0",)),
 ]
 S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
           "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
 
 
-def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_main.cfg"):
+def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_main.cfg", extra=()):
     import hmd2
     with tempfile.TemporaryDirectory() as td:
         yuv = os.path.join(td, "in.yuv")
@@ -126,7 +129,7 @@ def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_ma
         dump = os.path.join(td, "dump2.bin")
         cmd = [HM_DUMP, "enc2", "-c", os.path.join(REF_CFG, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h),
                "-fr", "50", "-f", str(nf), f"--InputBitDepth={bd}", "-q", str(qp), "-b", os.path.join(td, "o.bin"),
-               "-o", os.path.join(td, "r.yuv")] + (["--WaveFrontSynchro=1"] if wpp else []) + ["--", dump]
+               "-o", os.path.join(td, "r.yuv")] + (["--WaveFrontSynchro=1"] if wpp else []) + list(extra) + ["--", dump]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         recs = hmd2.parse(dump, w, h)
     out = {"width": w, "height": h, "bit_depth": bd, "frames": nf, "seed": seed, "wpp": wpp, "num_records": len(recs)}

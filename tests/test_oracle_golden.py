@@ -71,3 +71,18 @@ def test_oracle_matches_reference_p_and_b_slices(built, name):
             assert np.array_equal(rec[c], r["rec"][c]), f"{name} POC {int(r['poc'])}: reconstruction plane {c}"
         n_p += 1
     assert n_p >= 3
+
+
+@pytest.mark.parametrize("name", common.DBK_CASES)
+def test_oracle_deblocking_matches_reference(built, name):
+    """TComLoopFilter::loopFilterPic: the reference run with SAO off leaves the deblocked picture as the finished picture; the oracle's
+    deblocking of the pre-deblocking reconstruction (with the CU / TU / motion data of the same slice) must equal it (I, P and B slices)."""
+    import oracle
+    cfg, slices, finals = common.load_ldp_case(name)
+    for r in slices:
+        ctus, ictus = common.split_fixture_ctus(r["ctus"])
+        got = oracle.deblock(r["rec"], cfg["bit_depth"], int(r["qp"]), int(r["slice_type"]), r["ref_poc"], ctus, ictus)
+        want = finals[int(r["poc"])]["rec"]
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), f"{name} POC {int(r['poc'])}: deblocked plane {c} differs at {int((got[c] != want[c]).sum())} samples"
+        assert any(not np.array_equal(r["rec"][c], want[c]) for c in range(3)), "the fixture does not exercise the filter"
