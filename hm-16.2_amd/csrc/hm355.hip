@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include "hm355_core.h"
+#include "hm355_dbk.h"
 #include "hm355_host_common.h"
 #include "../../include/hm355.h"
 
@@ -117,6 +118,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_transform_kernel(int inve
 // ------------------------------------------------------------------------------------------------
 struct Slot {           // one picture resident in HBM
   FrameBuf fb;          // device pointers + slice parameters (host copy)
+  InterMeta *imeta;     // motion arrays of the slot (allocated on first inter use; kept for the deblocking pass)
 };
 struct hm355_ctx {
   hm355_seq_cfg cfg;
@@ -134,6 +136,7 @@ struct hm355_ctx {
   std::string err;
   int numCtus;
   void *staging; size_t stagingBytes;
+  DbkParams *dDbk;      // [max_batch] deblocking parameters of the pictures in the slots
 };
 
 #define HM_CHECK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HM355_ERR_DEVICE; } } while (0)
@@ -161,7 +164,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
-  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0;
+  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL;
   c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
@@ -185,6 +188,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   c->slots.resize(cfg->max_batch);
   for (int s = 0; s < cfg->max_batch; s++) {
     FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
+    c->slots[s].imeta = NULL;
     for (int k = 0; k < 3; k++) {
       const size_t bytes = (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel);
       HM_CHECK(c, hipMalloc((void **)&fb.org[k], bytes)); HM_CHECK(c, hipMemset(fb.org[k], 0, bytes));
@@ -212,10 +216,12 @@ extern "C" void hm355_destroy(hm355_ctx *c)
   for (size_t s = 0; s < c->slots.size(); s++) {
     FrameBuf &fb = c->slots[s].fb;
     for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
+    if (c->slots[s].imeta) hipFree(c->slots[s].imeta);
     if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState); if (fb.done) hipFree(fb.done);
   }
   if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems); if (c->dSched) hipFree(c->dSched);
   if (c->staging) hipHostFree(c->staging);
+  if (c->dDbk) hipFree(c->dDbk);
   if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -454,7 +460,8 @@ extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inte
     FrameBuf &fb = c->slots[f].fb;
     InterPic *dIp = NULL; MvD *dIntMv = NULL;
     if (e == hipSuccess) e = da.make(&dIp, 1, &hip);
-    if (e == hipSuccess) e = da.make(&dIm[f], (size_t)c->numCtus, NULL);
+    if (e == hipSuccess && !c->slots[f].imeta) e = hipMalloc((void **)&c->slots[f].imeta, sizeof(InterMeta) * c->numCtus);
+    if (e == hipSuccess) { dIm[f] = c->slots[f].imeta; e = hipMemset(dIm[f], 0, sizeof(InterMeta) * c->numCtus); }
     if (e == hipSuccess) e = da.make(&dIntMv, (size_t)c->numCtus * 32, NULL);
     fb.imeta = dIm[f]; fb.ip = dIp; fb.intMv = dIntMv;
     base[f] = sd->base; base[f].slice_type = 2;            // hm355_run validates the common fields
@@ -473,6 +480,72 @@ extern "C" int hm355_compress_slice_inter(hm355_ctx *c, const hm355_inter_slice_
 {
   hm355_ctu_out *cl[1] = { ctus }; hm355_ctu_inter_out *il[1] = { ictus };
   return hm355_compress_slices_inter(c, 1, sd, org, rec, ctus ? cl : NULL, ictus ? il : NULL, stats);
+}
+
+// ------------------------------------------------------------------------------------------------
+// deblocking (TComLoopFilter::loopFilterPic): in place on the reconstruction planes of the slots
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm355_deblock_run(hm355_ctx *c, int n, const hm355_dbk_desc *descs)
+{
+  if (!c || !descs || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp;
+  std::vector<FrameBuf> fbs(n); std::vector<DbkParams> dps(n);
+  for (int f = 0; f < n; f++) {
+    if (descs[f].slice_type < 0 || descs[f].slice_type > 2 || descs[f].qp < 0 || descs[f].qp > 51) return fail(c, HM355_ERR_ARG, "bad deblocking parameters");
+    if (descs[f].slice_type != 2 && !c->slots[f].imeta) return fail(c, HM355_ERR_ARG, "hm355_deblock_run: the slot holds no motion data (run hm355_compress_slices_inter first)");
+    fbs[f] = c->slots[f].fb; fbs[f].imeta = descs[f].slice_type != 2 ? c->slots[f].imeta : NULL;
+    dps[f].sliceType = descs[f].slice_type; dps[f].qp = descs[f].qp; memcpy(dps[f].refPoc, descs[f].ref_poc, sizeof(dps[f].refPoc));
+  }
+  if (!c->dDbk) HM_CHECK(c, hipMalloc((void **)&c->dDbk, sizeof(DbkParams) * c->slots.size()));
+  HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipMemcpyAsync(c->dDbk, dps.data(), sizeof(DbkParams) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
+  const int w = P.width, h = P.height;
+  const dim3 blk(64, 1, 1);
+  // vertical edges (luma, chroma), then horizontal edges: the stream orders the two directions
+  hipLaunchKernelGGL(hm355_dbk_kernel, dim3((w / 8 + 63) / 64, h / 4, n), blk, 0, c->stream, c->dP, c->dDbk, 0);
+  hipLaunchKernelGGL(hm355_dbk_kernel, dim3((w / 16 + 63) / 64, h / 4, n), blk, 0, c->stream, c->dP, c->dDbk, 1);
+  hipLaunchKernelGGL(hm355_dbk_kernel, dim3((w / 4 + 63) / 64, (h / 8 > 1 ? h / 8 : 1), n), blk, 0, c->stream, c->dP, c->dDbk, 2);
+  hipLaunchKernelGGL(hm355_dbk_kernel, dim3((w / 4 + 63) / 64, (h / 16 > 1 ? h / 16 : 1), n), blk, 0, c->stream, c->dP, c->dDbk, 3);
+  HM_CHECK(c, hipGetLastError());
+  HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->lastKernelMs = ms; c->lastLaunches = 4;
+  return HM355_OK;
+}
+
+// host buffers in and out: rec is filtered in place with the CU / TU / motion data of the same slice
+extern "C" int hm355_deblock(hm355_ctx *c, const hm355_dbk_desc *desc, const hm355_ctu_out *ctus, const hm355_ctu_inter_out *ictus, hm355_planes *rec)
+{
+  if (!c || !desc || !ctus || !rec) return HM355_ERR_ARG;
+  if (desc->slice_type != 2 && !ictus) return fail(c, HM355_ERR_ARG, "hm355_deblock: inter slices need the motion data");
+  const Params &P = c->hp; Slot &sl = c->slots[0]; FrameBuf &fb = sl.fb;
+  for (int k = 0; k < 3; k++) {
+    if (!rec->plane[k]) return fail(c, HM355_ERR_ARG, "null plane");
+    const int w = P.width >> (k ? 1 : 0), h = P.height >> (k ? 1 : 0);
+    HM_CHECK(c, hipMemcpy2D(fb.rec[k], (size_t)P.stride[k] * sizeof(Pel), rec->plane[k], (size_t)w * 2, (size_t)w * 2, h, hipMemcpyHostToDevice));
+  }
+  std::vector<CtuMeta> meta(c->numCtus);
+  for (int a = 0; a < c->numCtus; a++) {
+    const hm355_ctu_out *o = ctus + a; CtuMeta *m = &meta[a];
+    memcpy(m->depth, o->depth, 256); memcpy(m->part, o->part_size, 256); memcpy(m->pred, o->pred_mode, 256);
+    memcpy(m->dirL, o->intra_dir_luma, 256); memcpy(m->dirC, o->intra_dir_chroma, 256); memcpy(m->tr, o->tr_idx, 256);
+    memcpy(m->cbf, o->cbf, 768); memcpy(m->ts, o->tskip, 768);
+  }
+  HM_CHECK(c, hipMemcpy(fb.meta, meta.data(), sizeof(CtuMeta) * c->numCtus, hipMemcpyHostToDevice));
+  if (desc->slice_type != 2) {
+    if (!sl.imeta) HM_CHECK(c, hipMalloc((void **)&sl.imeta, sizeof(InterMeta) * c->numCtus));
+    HM_CHECK(c, hipMemcpy(sl.imeta, ictus, sizeof(InterMeta) * c->numCtus, hipMemcpyHostToDevice));
+  }
+  int rc = hm355_deblock_run(c, 1, desc);
+  if (rc != HM355_OK) return rc;
+  for (int k = 0; k < 3; k++) {
+    const int w = P.width >> (k ? 1 : 0), h = P.height >> (k ? 1 : 0);
+    HM_CHECK(c, hipMemcpy2D(rec->plane[k], (size_t)w * 2, fb.rec[k], (size_t)P.stride[k] * sizeof(Pel), (size_t)w * 2, h, hipMemcpyDeviceToHost));
+  }
+  return HM355_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1797,8 +1797,6 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
       if (checkFirst && f->checkFull) f->checkSplit = 0;              // HHI_RQT_INTRA_SPEEDUP
       f->singleCost = HM_MAX_DOUBLE; f->singleDist = 0; f->singleCbf = 0; f->bestModeId = 0;
       const int checkTS = (log2 == 2) && (m->part[z] == SIZE_NxN);    // TransformSkip + TransformSkipFast
-      const CabacHold root = cabac_hold(&e->cur);                     // the state this TU starts from, kept in registers for the restores below
-      CabacHold tempBest = root;
       if (f->checkFull) {
         if (checkTS) {
           cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
@@ -1811,15 +1809,15 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
             else { const uint32_t bits = HM_UCALL(intra_bits_qt(e, *t, 1, 0)); costTmp = calc_rd_cost(e, bits, distTmp); }
             if (costTmp < f->singleCost) {
               f->singleCost = costTmp; f->singleDist = distTmp; f->singleCbf = cbfTmp; f->bestModeId = (int8_t)modeId;
-              if (modeId == 0) { store_intra_result_qt(e, t, 0); tempBest = cabac_hold(&e->cur); }   // CI_TEMP_BEST of this depth, local to this block
+              if (modeId == 0) { store_intra_result_qt(e, t, 0); cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
             }
-            if (modeId == 0) cabac_put(&e->cur, root);
+            if (modeId == 0) cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
           }
           par_set8(m->ts[0] + z, f->bestModeId, t->parts);
           if (f->bestModeId == 0) {
             load_intra_result_qt(e, t, 0);
             par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
-            cabac_put(&e->cur, tempBest);
+            cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
           }
         } else {
           if (f->checkSplit) cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
@@ -1831,7 +1829,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
         }
       }
       if (!f->checkSplit) { retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue; }
-      if (f->checkFull) { cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_put(&e->cur, root); }
+      if (f->checkFull) { cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); }
       else cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
       f->splitCost = 0.0; f->splitDist = 0; f->splitCbf = 0; f->child = 0; f->phase = 1;
       retDist[sp + 1] = 0; retCost[sp + 1] = 0.0;
@@ -1985,10 +1983,8 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
   if (checkTS) { int nb = 0; for (int s = 0; s < 4; s++) nb += m->ts[0][z + s]; checkTS = nb > 0; }
   const int zc = t->cuZ + t->cRelZ;
   uint32_t dist = 0;
-  (void)fullDepth;
   for (int comp = 1; comp < 3; comp++) {
-    const CabacHold root = cabac_hold(&e->cur);                       // CI_QT_TRAFO_ROOT / CI_TEMP_BEST of this depth are local to this loop body:
-    CabacHold tempBest = root;                                        // held in registers instead of the HBM snapshot slots
+    cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
     double singleCost = HM_MAX_DOUBLE, costTmp = 0; uint32_t singleDistC = 0, singleCbfC = 0; int bestTS = 0, bestModeId = 0, currModeId = 0;
     const int total = checkTS ? 2 : 1;
     for (int tsMode = 0; tsMode < total; tsMode++) {
@@ -2001,14 +1997,14 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
       else if (!isOne) { reset_bits(&e->cur); enc_coeff_qt(e, t, comp); costTmp = calc_rd_cost(e, num_bits(&e->cur), distTmp); }   // xGetIntraBitsQTChroma
       if (costTmp < singleCost) {
         singleCost = costTmp; singleDistC = distTmp; bestTS = tsMode; bestModeId = currModeId; singleCbfC = cbfTmp;
-        if (!isOne && !isLast) { store_intra_result_qt(e, t, comp); tempBest = cabac_hold(&e->cur); }
+        if (!isOne && !isLast) { store_intra_result_qt(e, t, comp); cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)], &e->cur); }
       }
-      if (!isOne && !isLast) cabac_put(&e->cur, root);
+      if (!isOne && !isLast) cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
     }
     if (bestModeId < total) {
       load_intra_result_qt(e, t, comp);
       par_set8(m->cbf[comp] + zc, (int)(singleCbfC << t->trDepth), t->cParts);
-      cabac_put(&e->cur, tempBest);
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
     }
     par_set8(m->ts[comp] + zc, bestTS, t->cParts);
     dist += singleDistC;

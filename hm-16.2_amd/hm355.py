@@ -61,8 +61,12 @@ CTU_INTER_DTYPE = np.dtype([("skip", "u1", 256), ("merge_flag", "u1", 256), ("me
                             ("mv", "<i2", (2, 256, 2)), ("mvd", "<i2", (2, 256, 2)),
                             ("ref_idx", "i1", (2, 256)), ("mvp_idx", "i1", (2, 256)), ("mvp_num", "i1", (2, 256))])
 
+class DbkDesc(C.Structure):
+    _fields_ = [("slice_type", C.c_int32), ("qp", C.c_int32), ("ref_poc", (C.c_int32 * 16) * 2)]
+
+
 EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
-           "hm355_compress_slice_inter", "hm355_compress_slices_inter",
+           "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run",
            "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
@@ -88,6 +92,8 @@ def load_library(path=LIB_PATH):
                                                C.c_void_p, C.POINTER(SliceStats)]
     lib.hm355_compress_slices_inter.argtypes = [C.c_void_p, C.c_int, C.POINTER(InterSliceDesc), C.POINTER(Planes), C.POINTER(Planes),
                                                 C.c_void_p, C.c_void_p, C.POINTER(SliceStats)]
+    lib.hm355_deblock.argtypes = [C.c_void_p, C.POINTER(DbkDesc), C.c_void_p, C.c_void_p, C.POINTER(Planes)]
+    lib.hm355_deblock_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(DbkDesc)]
     lib.hm355_dist_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hm355_transform_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
@@ -229,6 +235,34 @@ class Encoder:
     def compress_inter(self, planes, slice_params, ref_pics):
         """One P slice (see compress_inter_batch)."""
         return self.compress_inter_batch([(planes, slice_params, ref_pics)])[0]
+
+    @staticmethod
+    def _dbk_desc(slice_type, qp, ref_poc):
+        d = DbkDesc(int(slice_type), int(qp))
+        for l in range(2):
+            for i in range(16):
+                d.ref_poc[l][i] = int(ref_poc[l][i]) if ref_poc is not None else 0
+        return d
+
+    def deblock(self, rec, slice_type, qp, ref_poc, ctus, ictus=None):
+        """hm355_deblock: TComLoopFilter::loopFilterPic on host buffers; returns the filtered planes"""
+        out = [np.ascontiguousarray(p, np.uint16).copy() for p in rec]
+        pr = _planes(out)
+        d = self._dbk_desc(slice_type, qp, ref_poc)
+        c = np.ascontiguousarray(ctus)
+        assert c.dtype == CTU_DTYPE
+        ic = np.ascontiguousarray(ictus) if ictus is not None else None
+        self._check(self.lib.hm355_deblock(self.h_, C.byref(d), c.ctypes.data, ic.ctypes.data if ic is not None else None, C.byref(pr)), "hm355_deblock")
+        return out
+
+    def deblock_run(self, descs):
+        """hm355_deblock_run on slots 0..n-1 (device-resident); descs: list of (slice_type, qp, ref_poc).  Returns kernel ms."""
+        n = len(descs)
+        arr = (DbkDesc * n)(*[self._dbk_desc(*d) for d in descs])
+        self._check(self.lib.hm355_deblock_run(self.h_, n, arr), "hm355_deblock_run")
+        ms, launches = C.c_double(), C.c_int()
+        self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
+        return ms.value
 
     def dist_batch(self, kind, org, cur, bit_depth):
         """org/cur: (count, n, n) int16; kind 0 SAD, 1 SSE, 2 SATD, 3 SAD with row sub-sampling"""

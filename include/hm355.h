@@ -126,6 +126,20 @@ int hm355_compress_slice_inter(hm355_ctx *ctx, const hm355_inter_slice_desc *sli
 int hm355_compress_slices_inter(hm355_ctx *ctx, int n, const hm355_inter_slice_desc *slices, const hm355_planes *org,
                                 hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_ctu_inter_out *const *ictus, hm355_slice_stats *stats);
 
+/* ---- deblocking filter: TComLoopFilter::loopFilterPic (TLibCommon/TComLoopFilter.cpp:130-158), the step TEncGOP runs after
+ * compressSlice (TEncGOP.cpp:1184) to turn the reconstruction into a reference picture.  Deblocking offsets 0, one slice,
+ * no PCM / lossless (every cfg of the reference); SAO is a separate, later stage. ---- */
+typedef struct {
+  int32_t slice_type, qp;             /* slice QP (no delta QP: every CU carries it) */
+  int32_t ref_poc[2][16];             /* POC of the slice's reference pictures [list][idx]: boundary strength compares pictures */
+} hm355_dbk_desc;
+/* host buffers: rec (the pre-deblocking reconstruction compressSlice left) is filtered in place, using ctus / ictus of the same slice
+ * (ictus may be NULL for an I slice) */
+int hm355_deblock(hm355_ctx *ctx, const hm355_dbk_desc *desc, const hm355_ctu_out *ctus, const hm355_ctu_inter_out *ictus, hm355_planes *rec);
+/* device-resident: filters the reconstruction of slots 0..n-1 in place, right after hm355_run / hm355_compress_slices(_inter) left
+ * their per-CTU data there; hm355_download then returns the deblocked picture */
+int hm355_deblock_run(hm355_ctx *ctx, int n, const hm355_dbk_desc *descs);
+
 /* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
  * Upload / run / download are separate so that a caller can keep pictures resident. */
 int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */

@@ -93,6 +93,36 @@ def test_hip_inter_slice_rejects_bad_parameters(hm):
     enc.close()
 
 
+@pytest.mark.parametrize("name", common.DBK_CASES)
+def test_hip_deblocking_matches_reference(hm, name):
+    """hm355_deblock on the reference's pre-deblocking reconstruction + per-CTU data == the reference's deblocked picture (SAO off),
+    for I, P and B slices; and the device-resident path (compress, then hm355_deblock_run in place, then download) gives the same."""
+    cfg, slices, finals = common.load_ldp_case(name)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 0, max_batch=1)
+    for r in slices:
+        ctus, ictus = common.split_fixture_ctus(r["ctus"])
+        st = int(r["slice_type"])
+        got = enc.deblock(r["rec"], st, int(r["qp"]), r["ref_poc"], ctus, ictus if st != 2 else None)
+        want = finals[int(r["poc"])]["rec"]
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), f"{name} POC {int(r['poc'])}: deblocked plane {c} differs at {int((got[c] != want[c]).sum())} samples"
+        # device-resident: search on the device, deblock in place, download
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"])
+        if st == 2:
+            enc.upload(0, planes)
+            lam, cw = float(r["lambda"]), float(r["weight_cb"])
+            sl = (hm.SliceDesc * 1)(hm.SliceDesc(2, int(r["qp"]), lam, cw))
+            enc._check(enc.lib.hm355_run(enc.h_, 1, sl), "hm355_run")
+        else:
+            sp, refs = common.ldp_slice_inputs(r, finals)
+            enc.compress_inter(planes, sp, refs)
+        enc.deblock_run([(st, int(r["qp"]), r["ref_poc"])])
+        rec2, _, _ = enc.download(0, want_ctus=False)
+        for c in range(3):
+            assert np.array_equal(rec2[c], want[c]), f"{name} POC {int(r['poc'])}: device-resident deblocking differs in plane {c}"
+    enc.close()
+
+
 def test_hip_batch_equals_single(hm):
     """pictures of a batch are independent: batched results == one-at-a-time results"""
     w, h, bd, qp = 128, 128, 8, 32
