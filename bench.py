@@ -235,9 +235,57 @@ def run_inter(args, torch):
     enc.close()
 
 
+def run_dbk(args, torch):
+    """Secondary workload: the deblocking filter (hm355_deblock_run) over `--frames` 3840x2160 10-bit pictures whose I-slice
+    search results are resident in their slots.  A step = one pass of the filter over the batch (four launches: vertical luma / chroma,
+    horizontal luma / chroma edges).  HBM-bound: algorithmic bytes = the picture read once + written once."""
+    import hm355
+    import synth
+    w, h, bd, qp, F = args.width, args.height, 10, args.qp, args.frames
+    enc = hm355.Encoder(w, h, bd, 1, F)
+    distinct = [synth.frame(w, h, bd, f, 1234) for f in range(min(4, F))]
+    for i in range(F):
+        enc.upload(i, distinct[i % len(distinct)])
+    descs = [(2, qp, None)] * F
+    ms_total = 0.0
+    for it in range(args.warmup + args.steps):
+        enc.run(F, qp)                                   # untimed: puts fresh pre-deblocking pictures + CU data into the slots
+        ms = enc.deblock_run(descs)
+        if it >= args.warmup:
+            ms_total += ms
+    n = enc.num_ctus * F * args.steps
+    pic_bytes = w * h * 3                               # 4:2:0, 16-bit samples: 1.5 samples x 2 B per luma position
+    alg = 2 * pic_bytes * F * args.steps                # read once + written once
+    ach = alg / (ms_total * 1e-3) / 1e9
+    line = {"metric": "CTUs/sec (deblocking filter) at 4K main10; bit-exact vs HM", "value": n / (ms_total * 1e-3), "unit": "CTU/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_total / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"TComLoopFilter::loopFilterPic on {F} I pictures {w}x{h} 10-bit (QP {qp}) resident in HBM with their CU / TU data",
+                       "frames_per_gpu": F, "pictures_per_s": F * args.steps / (ms_total * 1e-3)},
+            "roofline": {"bound": "hbm", "kernel": "hm355_dbk_kernel (4 launches per step)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "note": f"algorithmic bytes = {2 * pic_bytes} B per picture (read once + written once); the per-CTU decision arrays add 3 KB per CTU"}}
+    if not args.no_cpu_baseline:
+        import oracle
+        # CPU side: the C restatement of the filter (kind "port", 1 core) on one picture with the device's own CU data
+        enc.run(1, qp)
+        rec1, ctus1, _ = enc.download(0)
+        oc = np.zeros(len(ctus1), oracle.CTU_DTYPE)
+        for f in oc.dtype.names:
+            oc[f] = ctus1[f]
+        t0 = time.time()
+        oracle.deblock(rec1, bd, qp, 2, np.zeros((2, 16), np.int32), oc, None)
+        dt = time.time() - t0
+        line["cpu_baseline"] = {"value": enc.num_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
+                                "sample": f"one {w}x{h} picture ({enc.num_ctus} CTUs) through oracle/hm_oracle_dbk.inc"}
+        line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+    enc.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b"], help="intra4k = the BASELINE.json metric (default)")
+    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
@@ -257,8 +305,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if args.workload != "intra4k":
         if world > 1:
-            raise SystemExit("--workload ldp_p / ra_b are single-GPU measurements")
-        return run_inter(args, torch)
+            raise SystemExit("--workload ldp_p / ra_b / dbk are single-GPU measurements")
+        return run_dbk(args, torch) if args.workload == "dbk" else run_inter(args, torch)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -544,20 +544,24 @@ HM_DEV inline uint32_t pattern_refinement(Shared *e, TZ *z, const Pel *refAtInt,
   // The nine candidates are (tx, ty) in {-1,0,1}^2 around `base`.  Candidates with the same tx share the first (horizontal)
   // interpolation stage, so it is done once per tx over the rows all three ty need (two integer row offsets at most);
   // the costs are then compared in the reference's candidate order (strict <, first wins).
-  Pel *blk = e->ws->mcBlk, *tmp = e->ws->mcTmp;
   const int bd = e->bitDepth, w = z->w, h = z->h, rs = z->refStride;
   const int vyLo = (base.y - 1) * frac, rowLo = vyLo >> 2, rows = h + 8;      // rows rowLo-3 .. rowLo+h+4 of the reference
+  // the two interpolation buffers live in LDS (the transform buffers are idle during the motion search) whenever the block fits:
+  // every PU up to 32x32 and the 16-wide AMP parts; only the 48- and 64-wide PUs go through the HBM workspace
+  const int inLds = w * rows <= (int)(sizeof(e->bufA) / sizeof(Pel)) && w * h <= (int)(sizeof(e->u.bufB) / sizeof(Pel));
+  Pel *tmp = inLds ? (Pel *)e->bufA : e->ws->mcTmp, *blk = inLds ? (Pel *)e->u.bufB : e->ws->mcBlk;
+  const int ts = inLds ? w : 64;                                               // row stride of both buffers
   int32_t *cost9 = e->absCoeff;                                                // [(ty+1)*3 + tx+1]
   for (int tx = -1; tx <= 1; tx++) {
     const int hx = (tx + base.x) * frac, xFrac = hx & 3;
     const Pel *r = refAtInt + (ptrdiff_t)(rowLo - 3) * rs + (hx >> 2);
-    HM_PAR_FOR_XY(x, y, w, w * rows) tmp[y * 64 + x] = if_sample(bd, r + (ptrdiff_t)y * rs + x, 1, xFrac, 0, 1, 0);
+    HM_PAR_FOR_XY(x, y, w, w * rows) tmp[y * ts + x] = if_sample(bd, r + (ptrdiff_t)y * rs + x, 1, xFrac, 0, 1, 0);
     HM_SYNC();
     for (int ty = -1; ty <= 1; ty++) {
       const int vy = (ty + base.y) * frac, yFrac = vy & 3, ro = (vy >> 2) - rowLo;
-      HM_PAR_FOR_XY(x, y, w, w * h) blk[y * 64 + x] = if_sample(bd, tmp + (y + ro + 3) * 64 + x, 64, yFrac, 0, 0, 1);
+      HM_PAR_FOR_XY(x, y, w, w * h) blk[y * ts + x] = if_sample(bd, tmp + (y + ro + 3) * ts + x, ts, yFrac, 0, 0, 1);
       HM_SYNC();
-      uint32_t d = dist_hads_rect(z->org, z->orgStride, blk, 64, w, h, bd);
+      uint32_t d = dist_hads_rect(z->org, z->orgStride, blk, ts, w, h, bd);
       d += mc_cost32(e, mc_bits(e, tx + mvFrac->x, ty + mvFrac->y));
       cost9[(ty + 1) * 3 + tx + 1] = (int32_t)d;
     }
