@@ -116,6 +116,10 @@ extern "C" __global__ void __launch_bounds__(64) hm355_transform_kernel(int inve
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+struct hm355_ref {       // a finished picture as later pictures reference it (device buffers owned by this object)
+  RefPicDev dev;
+  std::vector<void *> owned;
+};
 struct Slot {           // one picture resident in HBM
   FrameBuf fb;          // device pointers + slice parameters (host copy)
   InterMeta *imeta;     // motion arrays of the slot (allocated on first inter use; kept for the deblocking pass)
@@ -429,6 +433,7 @@ extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inte
       return fail(c, HM355_ERR_ARG, "bad inter slice parameters");
     for (int l = 0; l < 2; l++) for (int i = 0; i < sd->num_ref_idx[l]; i++) {
       const hm355_ref_pic *hp = sd->ref[l][i];
+      if (sd->dev_ref[l][i]) continue;
       if (!hp || !hp->plane[0] || !hp->plane[1] || !hp->plane[2] || !hp->pred_mode || !hp->mv[0] || !hp->mv[1] || !hp->ref_idx[0] || !hp->ref_idx[1])
         return fail(c, HM355_ERR_ARG, "null reference picture data");
     }
@@ -448,6 +453,7 @@ extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inte
     hip.maxMergeCand = sd->max_merge_cand; hip.checkLDC = sd->check_ldc; hip.cabacInitType = sd->cabac_init_type;
     hip.lambdaMotionSAD = sd->lambda_motion_sad; hip.lambdaMotionSSE = sd->lambda_motion_sse;
     for (int l = 0; l < 2; l++) for (int i = 0; i < sd->num_ref_idx[l] && e == hipSuccess; i++) {
+      if (sd->dev_ref[l][i]) { hip.ref[l][i] = sd->dev_ref[l][i]->dev; continue; }
       const hm355_ref_pic *hp = sd->ref[l][i];
       size_t k = 0; for (; k < seen.size(); k++) if (seen[k] == hp) break;
       if (k == seen.size()) { RefPicDev r; e = upload_ref_pic(c, hp, da, &r); seen.push_back(hp); devRefs.push_back(r); }
@@ -455,7 +461,7 @@ extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inte
     }
     for (int i1 = 0; i1 < sd->num_ref_idx[1]; i1++) {            // TComSlice::setList1IdxToList0Idx
       hip.list1ToList0[i1] = -1;
-      for (int i0 = 0; i0 < sd->num_ref_idx[0]; i0++) if (sd->ref[0][i0]->poc == sd->ref[1][i1]->poc) { hip.list1ToList0[i1] = i0; break; }
+      for (int i0 = 0; i0 < sd->num_ref_idx[0]; i0++) if (hip.ref[0][i0].poc == hip.ref[1][i1].poc) { hip.list1ToList0[i1] = i0; break; }
     }
     FrameBuf &fb = c->slots[f].fb;
     InterPic *dIp = NULL; MvD *dIntMv = NULL;
@@ -480,6 +486,56 @@ extern "C" int hm355_compress_slice_inter(hm355_ctx *c, const hm355_inter_slice_
 {
   hm355_ctu_out *cl[1] = { ctus }; hm355_ctu_inter_out *il[1] = { ictus };
   return hm355_compress_slices_inter(c, 1, sd, org, rec, ctus ? cl : NULL, ictus ? il : NULL, stats);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-resident reference pictures
+// ------------------------------------------------------------------------------------------------
+extern "C" void hm355_ref_release(hm355_ctx *c, hm355_ref *r)
+{
+  (void)c;
+  if (!r) return;
+  for (size_t i = 0; i < r->owned.size(); i++) hipFree(r->owned[i]);
+  delete r;
+}
+extern "C" int hm355_ref_from_slot(hm355_ctx *c, int slot, int32_t poc, int32_t is_inter, const int32_t num_ref[2], const int32_t ref_poc[2][16],
+                                   const int32_t ref_lt[2][16], hm355_ref **out)
+{
+  if (!c || !out || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
+  if (is_inter && !c->slots[slot].imeta) return fail(c, HM355_ERR_ARG, "hm355_ref_from_slot: the slot holds no motion data");
+  const Params &P = c->hp;
+  hm355_ref *r = new hm355_ref(); memset(&r->dev, 0, sizeof(r->dev));
+  FrameBuf fbh = c->slots[slot].fb; fbh.imeta = is_inter ? c->slots[slot].imeta : NULL;
+  hipError_t e = hipMemcpy(c->dFrames + slot, &fbh, sizeof(FrameBuf), hipMemcpyHostToDevice);
+  const size_t np = (size_t)c->numCtus * 256;
+  Pel *pl[3] = {NULL, NULL, NULL}; uint8_t *pm = NULL; MvD *mv[2] = {NULL, NULL}; int8_t *ri[2] = {NULL, NULL};
+  for (int k = 0; k < 3 && e == hipSuccess; k++) {
+    const int cw = P.width >> (k ? 1 : 0), ch = P.height >> (k ? 1 : 0), mg = HM_REF_MARGIN >> (k ? 1 : 0), st = cw + 2 * mg;
+    e = hipMalloc((void **)&pl[k], (size_t)st * (ch + 2 * mg) * sizeof(Pel));
+    if (e == hipSuccess) { r->owned.push_back(pl[k]); r->dev.plane[k] = pl[k] + (size_t)mg * st + mg; r->dev.stride[k] = st; }
+  }
+  if (e == hipSuccess) { e = hipMalloc((void **)&pm, np); if (e == hipSuccess) r->owned.push_back(pm); }
+  for (int l = 0; l < 2 && e == hipSuccess; l++) {
+    e = hipMalloc((void **)&mv[l], np * sizeof(MvD)); if (e == hipSuccess) r->owned.push_back(mv[l]);
+    if (e == hipSuccess) { e = hipMalloc((void **)&ri[l], np); if (e == hipSuccess) r->owned.push_back(ri[l]); }
+  }
+  if (e == hipSuccess) {
+    for (int k = 0; k < 3; k++) {
+      const int cw = P.width >> (k ? 1 : 0), ch = P.height >> (k ? 1 : 0), mg = HM_REF_MARGIN >> (k ? 1 : 0), st = cw + 2 * mg;
+      hipLaunchKernelGGL(hm355_ref_kernel, dim3((st + 63) / 64, ch + 2 * mg, 1), dim3(64, 1, 1), 0, c->stream, c->dP, slot, k, pl[k], pm, mv[0], mv[1], ri[0], ri[1]);
+    }
+    hipLaunchKernelGGL(hm355_ref_kernel, dim3((unsigned)((np + 63) / 64), 1, 1), dim3(64, 1, 1), 0, c->stream, c->dP, slot, 3, pl[0], pm, mv[0], mv[1], ri[0], ri[1]);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  if (e != hipSuccess) { c->err = std::string("hm355_ref_from_slot: ") + hipGetErrorString(e); hm355_ref_release(c, r); return HM355_ERR_DEVICE; }
+  r->dev.predMode = pm; r->dev.mv[0] = mv[0]; r->dev.mv[1] = mv[1]; r->dev.refIdx[0] = ri[0]; r->dev.refIdx[1] = ri[1];
+  r->dev.poc = poc; r->dev.isLongTerm = 0;
+  if (ref_poc) memcpy(r->dev.refPoc, ref_poc, sizeof(r->dev.refPoc));
+  if (ref_lt) memcpy(r->dev.refLT, ref_lt, sizeof(r->dev.refLT));
+  (void)num_ref;
+  *out = r;
+  return HM355_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

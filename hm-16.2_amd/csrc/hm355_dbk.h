@@ -176,4 +176,29 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dbk_kernel(const Params *
     }
   }
 }
+
+// ---- device-resident reference pictures: what later pictures read of a finished one ----
+// mode 0..2: border extension of plane c (TComPicYuv::extendPicBorder, TComPicYuv.cpp:171) from the slot's reconstruction into a
+//            plane with HM_REF_MARGIN (>> 1 for chroma) samples on every side; one lane per destination sample, rows contiguous.
+// mode 3:    TComPic::compressMotion (TComDataCU::compressMV :3328, TComCUMvField::compress): every 16x16 block takes the prediction
+//            mode, MVs and reference indices of its first 4x4 partition; one lane per partition.
+extern "C" __global__ void __launch_bounds__(64) hm355_ref_kernel(const Params *P, int frame, int mode, Pel *dst, uint8_t *predMode, MvD *mv0, MvD *mv1, int8_t *ri0, int8_t *ri1)
+{
+  const FrameBuf *fb = P->frames + frame;
+  if (mode < 3) {
+    const int c = mode, cw = P->width >> (c ? 1 : 0), ch = P->height >> (c ? 1 : 0), mg = HM_REF_MARGIN >> (c ? 1 : 0), st = cw + 2 * mg;
+    const int x = (int)(blockIdx.x * 64 + threadIdx.x), y = (int)blockIdx.y;
+    if (x >= st) return;
+    const int sx = hm_clip3(0, cw - 1, x - mg), sy = hm_clip3(0, ch - 1, y - mg);
+    dst[(size_t)y * st + x] = fb->rec[c][(size_t)sy * P->stride[c] + sx];
+  } else {
+    const int i = (int)(blockIdx.x * 64 + threadIdx.x), n = P->wCtu * P->hCtu * 256;
+    if (i >= n) return;
+    const int a = i >> 8, z = i & 255, z0 = z & ~15;
+    predMode[i] = fb->meta[a].pred[z0];
+    MvD zero; zero.x = zero.y = 0;
+    if (fb->imeta) { const InterMeta *m = fb->imeta + a; mv0[i] = m->mv[0][z0]; mv1[i] = m->mv[1][z0]; ri0[i] = m->refIdx[0][z0]; ri1[i] = m->refIdx[1][z0]; }
+    else { mv0[i] = zero; mv1[i] = zero; ri0[i] = -1; ri1[i] = -1; }
+  }
+}
 #endif

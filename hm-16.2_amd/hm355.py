@@ -54,7 +54,7 @@ class InterSliceDesc(C.Structure):
                 ("ref", (C.POINTER(RefPic) * 16) * 2),
                 ("col_from_l0", C.c_int32), ("col_ref_idx", C.c_int32), ("tmvp", C.c_int32), ("mvd_l1_zero", C.c_int32),
                 ("max_merge_cand", C.c_int32), ("check_ldc", C.c_int32),
-                ("lambda_motion_sad", C.c_uint32), ("lambda_motion_sse", C.c_uint32)]
+                ("lambda_motion_sad", C.c_uint32), ("lambda_motion_sse", C.c_uint32), ("dev_ref", (C.c_void_p * 16) * 2)]
 
 
 CTU_INTER_DTYPE = np.dtype([("skip", "u1", 256), ("merge_flag", "u1", 256), ("merge_idx", "u1", 256), ("inter_dir", "u1", 256),
@@ -66,7 +66,7 @@ class DbkDesc(C.Structure):
 
 
 EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
-           "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run",
+           "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release",
            "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
@@ -94,6 +94,9 @@ def load_library(path=LIB_PATH):
                                                 C.c_void_p, C.c_void_p, C.POINTER(SliceStats)]
     lib.hm355_deblock.argtypes = [C.c_void_p, C.POINTER(DbkDesc), C.c_void_p, C.c_void_p, C.POINTER(Planes)]
     lib.hm355_deblock_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(DbkDesc)]
+    lib.hm355_ref_from_slot.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.hm355_ref_release.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hm355_ref_release.restype = None
     lib.hm355_dist_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hm355_transform_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
@@ -194,6 +197,9 @@ class Encoder:
             if id(ref_pics) not in conv:
                 refs = {}
                 for poc, f in ref_pics.items():
+                    if "dev" in f:                           # device-resident reference (ref_from_slot)
+                        refs[int(poc)] = f["dev"]
+                        continue
                     pl = [np.ascontiguousarray(p, np.uint16) for p in f["rec"]]
                     pm = np.ascontiguousarray(f["pred_mode"], np.uint8)
                     mv = [np.ascontiguousarray(f["mv"][l], np.int16) for l in range(2)]
@@ -217,7 +223,11 @@ class Encoder:
             for l in range(2):
                 s.num_ref_idx[l] = int(sp["num_ref_idx"][l])
                 for i in range(s.num_ref_idx[l]):
-                    s.ref[l][i] = C.pointer(refs[int(sp["ref_poc"][l][i])])
+                    rr = refs[int(sp["ref_poc"][l][i])]
+                    if isinstance(rr, RefPic):
+                        s.ref[l][i] = C.pointer(rr)
+                    else:
+                        s.dev_ref[l][i] = rr
             for key in ("col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "lambda_motion_sad",
                         "lambda_motion_sse"):
                 setattr(s, key, int(sp[key]))
@@ -254,6 +264,19 @@ class Encoder:
         ic = np.ascontiguousarray(ictus) if ictus is not None else None
         self._check(self.lib.hm355_deblock(self.h_, C.byref(d), c.ctypes.data, ic.ctypes.data if ic is not None else None, C.byref(pr)), "hm355_deblock")
         return out
+
+    def ref_from_slot(self, slot, poc, is_inter, num_ref_idx=(0, 0), ref_poc=None, ref_long_term=None):
+        """hm355_ref_from_slot: the slot's (deblocked) picture as a device-resident reference; returns {"dev": handle} for compress_inter"""
+        nr = (C.c_int32 * 2)(int(num_ref_idx[0]), int(num_ref_idx[1]))
+        rp = np.ascontiguousarray(ref_poc if ref_poc is not None else np.zeros((2, 16)), np.int32)
+        rl = np.ascontiguousarray(ref_long_term if ref_long_term is not None else np.zeros((2, 16)), np.int32)
+        h = C.c_void_p()
+        self._check(self.lib.hm355_ref_from_slot(self.h_, slot, int(poc), int(bool(is_inter)), nr, rp.ctypes.data, rl.ctypes.data, C.byref(h)),
+                    "hm355_ref_from_slot")
+        return {"dev": h.value}
+
+    def ref_release(self, ref):
+        self.lib.hm355_ref_release(self.h_, ref["dev"])
 
     def deblock_run(self, descs):
         """hm355_deblock_run on slots 0..n-1 (device-resident); descs: list of (slice_type, qp, ref_poc).  Returns kernel ms."""

@@ -103,6 +103,7 @@ typedef struct {
   const int8_t *ref_idx[2];           /* [numCtus*256] */
   int32_t num_ref[2], ref_poc[2][16], ref_lt[2][16];   /* reference lists that picture was coded with (TMVP scaling) */
 } hm355_ref_pic;
+struct hm355_ref;
 typedef struct {
   hm355_slice_desc base;              /* slice_type 1 (P) or 0 (B), qp, lambda, chroma weight */
   int32_t poc;
@@ -111,6 +112,7 @@ typedef struct {
   const hm355_ref_pic *ref[2][16];
   int32_t col_from_l0, col_ref_idx, tmvp, mvd_l1_zero, max_merge_cand, check_ldc;
   uint32_t lambda_motion_sad, lambda_motion_sse;       /* TComRdCost::m_uiLambdaMotionSAD / SSE[0] */
+  const struct hm355_ref *dev_ref[2][16];              /* device-resident alternative to ref[l][i] (hm355_ref_from_slot); used when non-NULL */
 } hm355_inter_slice_desc;
 /* per-CTU motion data: m_skipFlag, m_pbMergeFlag, m_puhMergeIndex, m_puhInterDir, m_acCUMvField[2] (mv, mvd, refIdx),
  * m_apiMVPIdx / m_apiMVPNum (TComDataCU.h:86-157) */
@@ -125,6 +127,15 @@ int hm355_compress_slice_inter(hm355_ctx *ctx, const hm355_inter_slice_desc *sli
  * evaluated concurrently; a hm355_ref_pic named by several slices is uploaded once.  n <= max_batch. */
 int hm355_compress_slices_inter(hm355_ctx *ctx, int n, const hm355_inter_slice_desc *slices, const hm355_planes *org,
                                 hm355_planes *rec, hm355_ctu_out *const *ctus, hm355_ctu_inter_out *const *ictus, hm355_slice_stats *stats);
+
+/* ---- device-resident reference pictures: the finished picture of a slot (after hm355_deblock_run) becomes a reference without a
+ * host round trip: border extension (TComPicYuv::extendPicBorder, TComPicYuv.cpp:171) and TComPic::compressMotion (TEncGOP.cpp:1660)
+ * run on the device.  is_inter = 0 for an I picture (no motion), else the slot's motion data of its last hm355_compress_slices_inter;
+ * num_ref / ref_poc / ref_lt = the reference lists that picture was coded with (TMVP scaling).  The slot can be reused afterwards. ---- */
+typedef struct hm355_ref hm355_ref;
+int hm355_ref_from_slot(hm355_ctx *ctx, int slot, int32_t poc, int32_t is_inter, const int32_t num_ref[2], const int32_t ref_poc[2][16],
+                        const int32_t ref_lt[2][16], hm355_ref **out);
+void hm355_ref_release(hm355_ctx *ctx, hm355_ref *ref);
 
 /* ---- deblocking filter: TComLoopFilter::loopFilterPic (TLibCommon/TComLoopFilter.cpp:130-158), the step TEncGOP runs after
  * compressSlice (TEncGOP.cpp:1184) to turn the reconstruction into a reference picture.  Deblocking offsets 0, one slice,

@@ -81,6 +81,44 @@ def test_hip_p_slice_batch_equals_single(hm):
     enc.close()
 
 
+@pytest.mark.parametrize("w,h,bd,wpp,kind", [(416, 240, 8, 1, "P"), (264, 200, 10, 0, "B"), (416, 240, 10, 1, "B")])
+def test_hip_inter_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, wpp, kind):
+    """P / B slices on freshly seeded pictures (no fixture): reference pictures = the HIP path's own I-slice reconstructions, two pictures
+    per list; the HIP result must equal the oracle's bit for bit (decisions, motion, coefficients, costs, reconstruction)."""
+    import math
+    import oracle
+    qp, seed = 30, 77
+    enc = hm.Encoder(w, h, bd, wpp, max_batch=2)
+    n = enc.num_ctus
+    res = enc.compress([synth.frame(w, h, bd, f, seed) for f in (0, 4)], qp)
+    mot = np.zeros(n, [("pred_mode", "u1", 256), ("mv0", "<i2", (256, 2)), ("ref_idx0", "i1", 256), ("mv1", "<i2", (256, 2)), ("ref_idx1", "i1", 256)])
+    mot["pred_mode"] = 1; mot["ref_idx0"] = -1; mot["ref_idx1"] = -1
+    zero = np.zeros((2, 16), np.int32)
+    finals = {poc: {"poc": poc, "slice_type": 2, "rec": res[k][0], "motion": mot, "num_ref_idx": (0, 0), "ref_poc": zero, "ref_long_term": zero}
+              for k, poc in enumerate((0, 4))}
+    ref_poc = np.zeros((2, 16), np.int32)
+    ref_poc[0, :2] = (0, 4)
+    if kind == "B":
+        ref_poc[1, :2] = (4, 0)
+    lam = 0.4624 * 2.0 ** ((qp + 2 - 12) / 3.0) * 2.0
+    srec = {"poc": 2, "slice_type": 1 if kind == "P" else 0, "qp": qp + 2, "lambda": lam, "weight_cb": hm.intra_lambda(qp + 2)[1],
+            "cabac_init_type": 1 if kind == "P" else 0, "num_ref_idx": (2, 0 if kind == "P" else 2), "ref_poc": ref_poc, "col_from_l0": 0 if kind == "B" else 1,
+            "col_ref_idx": 0, "tmvp": 1, "mvd_l1_zero": 0, "max_merge_cand": 5, "check_ldc": 0 if kind == "B" else 1,
+            "lambda_motion_sad": int(math.floor(65536.0 * math.sqrt(lam))), "lambda_motion_sse": int(math.floor(65536.0 * lam))}
+    cur = synth.frame(w, h, bd, 2, seed)
+    want_rec, want_ctus, want_ictus = oracle.compress_inter(cur, bd, srec, finals, wpp=wpp)
+    sp, refs = common.ldp_slice_inputs(srec, finals)
+    rec, ctus, ictus, _ = enc.compress_inter(cur, sp, refs)
+    enc.close()
+    for f in ("total_bits", "total_dist", "total_cost", "depth", "part_size", "pred_mode", "tr_idx", "cbf", "tskip", "coeff_y", "coeff_cb", "coeff_cr"):
+        assert np.array_equal(ctus[f], want_ctus[f]), f"{kind} {w}x{h}: {f} differs"
+    for f in ("skip", "merge_flag", "merge_idx", "inter_dir", "mv", "mvd", "ref_idx", "mvp_idx", "mvp_num"):
+        assert np.array_equal(ictus[f], want_ictus[f]), f"{kind} {w}x{h}: {f} differs"
+    for c in range(3):
+        assert np.array_equal(rec[c], want_rec[c])
+    assert (ictus["inter_dir"] != 0).any()
+
+
 def test_hip_inter_slice_rejects_bad_parameters(hm):
     cfg, slices, finals = common.load_ldp_case(common.LDP_CASES[0])
     r = [s for s in slices if int(s["slice_type"]) == 1][0]
@@ -120,6 +158,40 @@ def test_hip_deblocking_matches_reference(hm, name):
         rec2, _, _ = enc.download(0, want_ctus=False)
         for c in range(3):
             assert np.array_equal(rec2[c], want[c]), f"{name} POC {int(r['poc'])}: device-resident deblocking differs in plane {c}"
+    enc.close()
+
+
+@pytest.mark.parametrize("name", common.DBK_CASES)
+def test_hip_closed_loop_on_device_matches_reference(hm, name):
+    """A whole clip on the device, no host round trip of pictures between frames: search -> deblock in place -> device-resident
+    reference (border extension + compressMotion on the device) -> next picture's search.  The reference ran with SAO off, so every
+    stage can be compared: per-CTU data and pre-deblocking reconstruction of each slice, and the deblocked picture."""
+    cfg, slices, finals = common.load_ldp_case(name)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 0, max_batch=1)
+    dev_refs = {}
+    for r in slices:
+        st, poc = int(r["slice_type"]), int(r["poc"])
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], poc, cfg["seed"])
+        if st == 2:
+            enc.upload(0, planes)
+            sl = (hm.SliceDesc * 1)(hm.SliceDesc(2, int(r["qp"]), float(r["lambda"]), float(r["weight_cb"])))
+            enc._check(enc.lib.hm355_run(enc.h_, 1, sl), "hm355_run")
+            rec, ctus, _ = enc.download(0)
+            common.assert_ctus_equal(ctus, common.split_fixture_ctus(r["ctus"])[0], f"{name} POC {poc}")
+        else:
+            sp, _ = common.ldp_slice_inputs(r, finals)
+            refs = {int(p): dev_refs[int(p)] for l in range(2) for p in r["ref_poc"][l][:r["num_ref_idx"][l]]}
+            rec, ctus, ictus, _ = enc.compress_inter(planes, sp, refs)
+            common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], f"{name} POC {poc} (device-resident references)")
+        for c in range(3):
+            assert np.array_equal(rec[c], r["rec"][c]), f"{name} POC {poc}: pre-deblocking reconstruction plane {c}"
+        enc.deblock_run([(st, int(r["qp"]), r["ref_poc"])])
+        dbk, _, _ = enc.download(0, want_ctus=False)
+        for c in range(3):
+            assert np.array_equal(dbk[c], finals[poc]["rec"][c]), f"{name} POC {poc}: deblocked plane {c}"
+        dev_refs[poc] = enc.ref_from_slot(0, poc, st != 2, r["num_ref_idx"], r["ref_poc"], r["ref_long_term"])
+    for ref in dev_refs.values():
+        enc.ref_release(ref)
     enc.close()
 
 
