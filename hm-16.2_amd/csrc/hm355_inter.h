@@ -54,10 +54,12 @@ HM_DEV inline void interp_block(Shared *e, int chroma, const Pel *r, int refStri
   const int bd = e->bitDepth, last = !bi;
   if (!twoStage && yFrac == 0) { HM_PAR_FOR_XY(x, y, cw, cw * ch) dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, 1, xFrac, chroma, 1, last); HM_SYNC(); return; }
   if (!twoStage && xFrac == 0) { HM_PAR_FOR_XY(x, y, cw, cw * ch) dst[y * dstStride + x] = if_sample(bd, r + y * refStride + x, refStride, yFrac, chroma, 1, last); HM_SYNC(); return; }
-  Pel *tmp = e->ws->mcTmp; const int half = chroma ? 1 : 3, rows = ch + (chroma ? 3 : 7);
-  HM_PAR_FOR_XY(x, y, cw, cw * rows) tmp[y * 64 + x] = if_sample(bd, r + (y - half) * refStride + x, 1, xFrac, chroma, 1, 0);
+  const int half = chroma ? 1 : 3, rows = ch + (chroma ? 3 : 7);
+  const int inLds = cw * rows <= (int)(sizeof(e->bufA) / sizeof(Pel));         // intermediate rows in LDS (idle transform buffer) when they fit
+  Pel *tmp = inLds ? (Pel *)e->bufA : e->ws->mcTmp; const int ts = inLds ? cw : 64;
+  HM_PAR_FOR_XY(x, y, cw, cw * rows) tmp[y * ts + x] = if_sample(bd, r + (y - half) * refStride + x, 1, xFrac, chroma, 1, 0);
   HM_SYNC();
-  HM_PAR_FOR_XY(x, y, cw, cw * ch) dst[y * dstStride + x] = if_sample(bd, tmp + (y + half) * 64 + x, 64, yFrac, chroma, 0, last);
+  HM_PAR_FOR_XY(x, y, cw, cw * ch) dst[y * dstStride + x] = if_sample(bd, tmp + (y + half) * ts + x, ts, yFrac, chroma, 0, last);
   HM_SYNC();
 }
 HM_DEV inline MvD clip_mv(const Shared *e, MvD mv, int cuX, int cuY)
@@ -684,9 +686,10 @@ HM_DEV inline uint32_t template_cost(Shared *e, int cuZ, Rect r, MvD cand, int l
   const InterPic *s = e->fb.ip;
   const int rz = hm_z2r(cuZ), cuX = e->ctuX * 64 + (rz & 15) * 4, cuY = e->ctuY * 64 + (rz >> 4) * 4;
   const int px = e->ctuX * 64 + r.x, py = e->ctuY * 64 + r.y;
-  Pel *blk = e->ws->mcBlk;
-  pred_inter_blk(e, 0, &s->ref[list][refIdx], px, py, clip_mv(e, cand, cuX, cuY), r.w, r.h, blk, 64);
-  const uint32_t sad = dist_sad_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], blk, 64, r.w, r.h, 0, e->bitDepth);
+  const int inLds = r.w * r.h <= (int)(sizeof(e->u.bufB) / sizeof(Pel));
+  Pel *blk = inLds ? (Pel *)e->u.bufB : e->ws->mcBlk; const int bs = inLds ? r.w : 64;
+  pred_inter_blk(e, 0, &s->ref[list][refIdx], px, py, clip_mv(e, cand, cuX, cuY), r.w, r.h, blk, bs);
+  const uint32_t sad = dist_sad_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], blk, bs, r.w, r.h, 0, e->bitDepth);
   HM_TRACE(e, 9, ((uint32_t)(uint16_t)cand.x << 16) | (uint16_t)cand.y, sad, 0.0);
   const double t = floor(((double)1 * (double)s->lambdaMotionSAD) + 0.5) / 65536.0;
   return (uint32_t)floor((double)sad + t);
