@@ -68,7 +68,7 @@ extern "C" __global__ void __launch_bounds__(64, 4) hm355_ctu_kernel(const Param
       if (cx > 0) dep0 = a - 1;
       if (cy > 0) dep1 = (cy - 1) * wCtu + (cx + 1 < wCtu ? cx + 1 : cx);
     } else if (a > 0) dep0 = a - 1;
-    // P slice: a picture-boundary CTU takes the 2Nx2N integer-MV state of its predecessor in coding order (process_ctu)
+    // inter slice: a picture-boundary CTU takes the 2Nx2N integer-MV state of its predecessor in coding order (process_ctu)
     const int dep2 = (P->wpp && cx == 0 && cy > 0 && P->frames[curItem.frame].imeta && (63 >= P->width || cy * 64 + 63 >= P->height)) ? a - 1 : -1;
     int bad = 0;
     if (dep0 >= 0) bad = hm355_wait_flag(done + dep0, sched + 1, epoch);

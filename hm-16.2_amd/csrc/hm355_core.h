@@ -282,7 +282,7 @@ struct RqtFrame {
   TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf; double singleCost, splitCost;
 };
 struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary, parentPart; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
-// inter (P slice) helpers kept in LDS
+// inter (P / B slice) helpers kept in LDS
 struct MvFieldD { MvD mv; int ref; };
 struct MergeList { MvFieldD f[5][2]; uint8_t dir[5]; int num; };
 struct AmvpInfo { MvD cand[3]; int n; };
@@ -341,7 +341,7 @@ struct Shared {
   double outCost; uint32_t outBits, outDist; double outRdCost; uint32_t outDistY;
   uint32_t satd[36];                   // SATD of the 35 intra modes of the PU under test
   int32_t mpmZ, mpmNum, mpmPreds[3];   // most-probable-mode list of the PU under test (same for all its candidates)
-  // inter (P slice) state
+  // inter (P / B slice) state
   InterMeta *im;                       // motion arrays of the CTU under search (HBM)
   uint32_t mcost; MvD mvPredictor; int32_t costScale;   // TComRdCost motion-cost state
   MvD intMv[2][16];                    // TEncSearch::m_integerMv2Nx2N[list][refIdx]
@@ -1639,7 +1639,7 @@ template <class C> HM_DEV inline void enc_intra_header(Shared *e, C *c, const TU
 {
   const CtuMeta *m = (&e->meta); const int relZ = t->relZ;
   if (bLuma) {
-    if (relZ == 0 && e->im) { code_skip_flag(e, c, t->cuZ); enc_bin(e, c, C_PRED_MODE, 1); }   // P slices: skip flag + pred mode, TEncSearch.cpp:975-984
+    if (relZ == 0 && e->im) { code_skip_flag(e, c, t->cuZ); enc_bin(e, c, C_PRED_MODE, 1); }   // P / B slices: skip flag + pred mode, TEncSearch.cpp:975-984
     if (relZ == 0 && t->cuDepth == 3) enc_bin(e, c, C_PART, m->part[t->cuZ] == SIZE_2Nx2N);
     if (m->part[t->cuZ] == SIZE_2Nx2N) { if (relZ == 0) code_intra_dir_luma(e, c, t->cuZ, 0); }
     else { const int q = t->cuParts >> 2; if (t->trDepth > 0 && (relZ & (q - 1)) == 0) code_intra_dir_luma(e, c, t->cuZ + relZ, 0); }
@@ -2239,7 +2239,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
       const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
       f->boundary = !((lx + size - 1 < e->width) && (ty + size - 1 < e->height));
       f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
-      if (!f->boundary && e->im) { // P slice: TEncCu.cpp:628-836
+      if (!f->boundary && e->im) { // P / B slice: TEncCu.cpp:628-836
         { HM_PROF_BEGIN(e, PR_INTERCU); compress_cu_inter_modes(e, cuZ, cuDepth, sp); HM_PROF_END(e, PR_INTERCU); }
         reset_bits(&e->cur);
         if (cuDepth != 3) enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
@@ -2349,7 +2349,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   if (e->im) {
     // TEncSearch::m_integerMv2Nx2N persists from CTU to CTU in coding order.  A CTU whose 64x64 CU lies inside the picture
     // overwrites every entry (2Nx2N search at depth 0, all reference indices) before it reads one, so only picture-boundary
-    // CTUs take the state of their predecessor -- which is what lets P slices run as a WPP wavefront.
+    // CTUs take the state of their predecessor -- which is what lets inter slices run as a WPP wavefront.
     const int bnd = it->ctuX * 64 + 63 >= P->width || it->ctuY * 64 + 63 >= P->height;
     const MvD *src = e->ctuAddr == 0 ? e->fb.ip->integerMv2Nx2N[0] : e->fb.intMv + (size_t)(e->ctuAddr - 1) * 32;
     HM_PAR_FOR(i, 32) { MvD v; v.x = v.y = 0; if (bnd) v = src[i]; e->intMv[i >> 4][i & 15] = v; }

@@ -82,7 +82,7 @@ static inline void hm355_intra_lambda(int qp, double *lambda, double *chromaWeig
 //   WaveFrontSynchro=1 : CTU (x,y) runs at step x + 2y   (2-CTU lag wavefront, TEncSlice.cpp:740-755)
 //   WaveFrontSynchro=0 : the CABAC state chains through every CTU in raster order -> step = address
 // All pictures of a batch are independent, so step s carries the CTUs of every picture.
-// carryLastRow (P slices under WPP whose last CTU row is cut by the picture edge): CTU (0, last row) also needs the
+// carryLastRow (inter slices under WPP whose last CTU row is cut by the picture edge): CTU (0, last row) also needs the
 // 2Nx2N integer-MV state of the last CTU of the row above, so that row is ordered behind the whole row above it.
 static inline int hm355_schedule_step(int wCtu, int hCtu, int wpp, int carryLastRow, int x, int y)
 {

@@ -1,4 +1,4 @@
-// hm355 -- inter (P slice) part of the CTU search: merge / AMVP / temporal candidates, TZ integer search, fractional
+// hm355 -- inter (P / B slice) part of the CTU search: merge / AMVP / temporal candidates, TZ integer search, fractional
 // refinement, motion compensation, inter residual quadtree and inter syntax.  Included by hm355_core.h; same execution
 // model (one wavefront per CTU, wave-uniform decisions, lane-parallel sample work).  Reference file:line as in the rest.
 #pragma once
@@ -260,7 +260,7 @@ HM_DEV inline int temporal_mv(const Shared *e, Rect r, int list, int refIdx, MvD
 }
 
 // ------------------------------------------------------------------------------------------------
-// merge candidates (getInterMergeCandidates :2309-2662), P slice
+// merge candidates (getInterMergeCandidates :2309-2662)
 // ------------------------------------------------------------------------------------------------
 HM_DEV inline int equal_motion(const Shared *e, int ca, int za, int cb, int zb)
 { // hasEqualMotion :2278

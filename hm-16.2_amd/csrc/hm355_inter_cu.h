@@ -1,4 +1,4 @@
-// hm355 -- CU-level mode tests of P slices (included by hm355_core.h after the intra CU check)
+// hm355 -- CU-level mode tests of P / B slices (included by hm355_core.h after the intra CU check)
 #pragma once
 
 HM_DEV inline void check_best_mode(Shared *e, CuFrame *f, int cuZ, int cuDepth)
@@ -53,7 +53,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_inter(Shared *e, int cuZ, int cuDepth, int
   { HM_PROF_BEGIN(e, PR_IRES); encode_res_and_calc_rd_inter(e, cuZ, cuDepth, 0); HM_PROF_END(e, PR_IRES); }
   check_best_mode(e, f, cuZ, cuDepth);
 }
-// the mode tests of one CU in a P slice (TEncCu::xCompressCU :600-857 with ESD/CFM/ECU off)
+// the mode tests of one CU in a P / B slice (TEncCu::xCompressCU :600-857 with ESD/CFM/ECU off)
 HM_DEV HM_NOINLINE void compress_cu_inter_modes(Shared *e, int cuZ, int cuDepth, int sp)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp);

@@ -26,7 +26,7 @@ struct CtuMeta {
   uint8_t depth[256], part[256], pred[256], dirL[256], dirC[256], tr[256], cbf[3][256], ts[3][256];
 };
 struct CtuStat { double cost; uint32_t bits, dist; };
-// ---- inter (P slice) per-CTU arrays: TComDataCU m_skipFlag, m_pbMergeFlag, m_puhMergeIndex, m_puhInterDir, m_acCUMvField[2], m_apiMVPIdx/Num ----
+// ---- inter (P / B slice) per-CTU arrays: TComDataCU m_skipFlag, m_pbMergeFlag, m_puhMergeIndex, m_puhInterDir, m_acCUMvField[2], m_apiMVPIdx/Num ----
 struct MvD { int16_t x, y; };
 struct InterMeta {
   uint8_t skip[256], mrg[256], mrgIdx[256], interDir[256];
@@ -107,7 +107,7 @@ struct FrameBuf {
   CtuStat *stat;                     // [numCtus]
   Cabac *endState;                   // [numCtus] estimator state after encodeCtu of that CTU
   uint32_t *done;                    // [numCtus] == run epoch once the CTU's results are published (persistent scheduler)
-  InterMeta *imeta;                  // [numCtus] (P slices; NULL for I slices)
+  InterMeta *imeta;                  // [numCtus] (P / B slices; NULL for I slices)
   InterPic *ip;                      // slice-level inter parameters (NULL for I slices)
   MvD *intMv;                        // [numCtus][2][16] m_integerMv2Nx2N as each CTU left it (carried in coding order)
   // slice parameters (TEncSlice::setUpLambda, TEncSlice.cpp:132-159)

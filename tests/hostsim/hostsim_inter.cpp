@@ -1,7 +1,7 @@
-// DEBUGGING AID, NOT PRODUCT: the P-slice path of hm-16.2_amd/csrc/hm355_core.h compiled for the host with one "lane"
+// DEBUGGING AID, NOT PRODUCT: the inter-slice (P / B) path of hm-16.2_amd/csrc/hm355_core.h compiled for the host with one "lane"
 // (see hostsim.cpp), driven by an HMD2 record stream of the real reference (oracle/ref_harness.cpp, `hm_dump enc2`):
 // every P or B slice is re-run with the slice parameters and reference pictures of its record and compared in place.
-//   hostsim_inter <in.yuv> <dump2.bin> <w> <h> <bitdepth> [wpp]   exit code 0 = every P slice bit-exact
+//   hostsim_inter <in.yuv> <dump2.bin> <w> <h> <bitdepth> [wpp]   exit code 0 = every inter slice bit-exact
 #define HM355_HOSTSIM 1
 #include "../../hm-16.2_amd/csrc/hm355_core.h"
 #include "../../hm-16.2_amd/csrc/hm355_host_common.h"
