@@ -292,6 +292,7 @@ struct TZ {                            // state of one integer motion search (In
   uint32_t bestSad; int bestX, bestY, bestDist, bestRound, pointNr;
   int l, r, t, b;
   int subShift;
+  int16_t lx[16], ly[16]; int8_t lp[16], ld[16];   // search points queued for one batched evaluation (x, y, point number, distance)
 };
 struct IrqFrame {                      // one level of the inter residual quadtree (xEstimateResidualQT)
   TU t; int8_t phase, child, checkFull, checkSplit, zero; uint8_t bestTS[3];

@@ -424,74 +424,109 @@ HM_DEV inline uint32_t mc_cost32(const Shared *e, uint32_t b) { return (uint32_t
 // ------------------------------------------------------------------------------------------------
 // integer search: TZ (xTZSearch :4027-4228, helpers :333-795)
 // ------------------------------------------------------------------------------------------------
-// one search point (xTZSearchHelp :333): not inlined -- the diamond / raster patterns call it from ~60 places
-HM_DEV HM_NOINLINE void tz_help(Shared *e, int sx, int sy, int pointNr, int dist)
+// Search points (xTZSearchHelp :333) are queued and evaluated in batches: the points of one diamond / 2-point / raster pattern do not
+// depend on each other's result, only the running best does, so the SADs of up to four points are accumulated together (one read of
+// the original block per four reference reads, four loads in flight) and the best is then updated in the reference's point order.
+#define TZ_PUSH(z, n, X, Y, PN, D) do { (z)->lx[n] = (int16_t)(X); (z)->ly[n] = (int16_t)(Y); (z)->lp[n] = (int8_t)(PN); (z)->ld[n] = (int8_t)(D); (n)++; } while (0)
+HM_DEV HM_NOINLINE void tz_eval_list(Shared *e, int n)
 {
-  HM_ENTRY(e); sx = HM_UNI(sx); sy = HM_UNI(sy); pointNr = HM_UNI(pointNr); dist = HM_UNI(dist);
+  HM_ENTRY(e); n = HM_UNI(n);
   TZ *z = &e->tz;
   const Pel *org = hm_uni_ptr(z->org), *ref = hm_uni_ptr(z->ref);
-  uint32_t sad = dist_sad_rect(org, z->orgStride, ref + (ptrdiff_t)sy * z->refStride + sx, z->refStride, z->w, z->h, z->subShift, e->bitDepth);
-  HM_TRACE(e, 11, ((uint32_t)(uint16_t)sx << 16) | (uint16_t)sy, sad, (double)z->bestSad);
-  sad += mc_cost32(e, mc_bits(e, sx, sy));
-  if (sad < z->bestSad) { z->bestSad = sad; z->bestX = sx; z->bestY = sy; z->bestDist = dist; z->bestRound = 0; z->pointNr = pointNr; }
+  const int so = HM_UNI(z->orgStride), sr = HM_UNI(z->refStride), w = HM_UNI(z->w), h = HM_UNI(z->h), sub = HM_UNI(z->subShift), bd = e->bitDepth;
+  const int rows = h >> sub, so2 = so << sub, sr2 = sr << sub;
+  for (int b = 0; b < n; b += 4) {
+    const int k = n - b < 4 ? n - b : 4;
+    int px[4], py[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int jj = j < k ? b + j : b; px[j] = HM_UNI(z->lx[jj]); py[j] = HM_UNI(z->ly[jj]); }
+    const Pel *r0 = ref + (ptrdiff_t)py[0] * sr + px[0], *r1 = ref + (ptrdiff_t)py[1] * sr + px[1];
+    const Pel *r2 = ref + (ptrdiff_t)py[2] * sr + px[2], *r3 = ref + (ptrdiff_t)py[3] * sr + px[3];
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (k == 4) {
+      HM_PAR_FOR_XY(x, yy, w, rows * w) { const int o = org[yy * so2 + x], q = yy * sr2 + x; s0 += (uint32_t)hm_abs(o - r0[q]); s1 += (uint32_t)hm_abs(o - r1[q]); s2 += (uint32_t)hm_abs(o - r2[q]); s3 += (uint32_t)hm_abs(o - r3[q]); }
+    } else if (k >= 2) {
+      HM_PAR_FOR_XY(x, yy, w, rows * w) { const int o = org[yy * so2 + x], q = yy * sr2 + x; s0 += (uint32_t)hm_abs(o - r0[q]); s1 += (uint32_t)hm_abs(o - r1[q]); if (k == 3) s2 += (uint32_t)hm_abs(o - r2[q]); }
+    } else {
+      HM_PAR_FOR_XY(x, yy, w, rows * w) s0 += (uint32_t)hm_abs(org[yy * so2 + x] - r0[yy * sr2 + x]);
+    }
+    uint32_t sad[4];
+    sad[0] = (hm_wave_sum(s0) << sub) >> (bd - 8);
+    sad[1] = k > 1 ? (hm_wave_sum(s1) << sub) >> (bd - 8) : 0;
+    sad[2] = k > 2 ? (hm_wave_sum(s2) << sub) >> (bd - 8) : 0;
+    sad[3] = k > 3 ? (hm_wave_sum(s3) << sub) >> (bd - 8) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j >= k) break;
+      uint32_t v = sad[j];
+      HM_TRACE(e, 11, ((uint32_t)(uint16_t)px[j] << 16) | (uint16_t)py[j], v, (double)z->bestSad);
+      v += mc_cost32(e, mc_bits(e, px[j], py[j]));
+      if (v < z->bestSad) { z->bestSad = v; z->bestX = px[j]; z->bestY = py[j]; z->bestDist = z->ld[b + j]; z->bestRound = 0; z->pointNr = z->lp[b + j]; }
+    }
+  }
 }
+HM_DEV inline void tz_help(Shared *e, int sx, int sy, int pointNr, int dist)
+{ TZ *z = &e->tz; int n = 0; TZ_PUSH(z, n, sx, sy, pointNr, dist); tz_eval_list(e, n); }
 HM_DEV inline void tz_2point(Shared *e, TZ *z)
 {
-  const int x = z->bestX, y = z->bestY;
+  const int x = z->bestX, y = z->bestY; int n_ = 0;
   switch (z->pointNr) {
-    case 1: if (x - 1 >= z->l) tz_help(e, x - 1, y, 0, 2); if (y - 1 >= z->t) tz_help(e, x, y - 1, 0, 2); break;
-    case 2: if (y - 1 >= z->t) { if (x - 1 >= z->l) tz_help(e, x - 1, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, x + 1, y - 1, 0, 2); } break;
-    case 3: if (y - 1 >= z->t) tz_help(e, x, y - 1, 0, 2); if (x + 1 <= z->r) tz_help(e, x + 1, y, 0, 2); break;
-    case 4: if (x - 1 >= z->l) { if (y + 1 <= z->b) tz_help(e, x - 1, y + 1, 0, 2); if (y - 1 >= z->t) tz_help(e, x - 1, y - 1, 0, 2); } break;
-    case 5: if (x + 1 <= z->r) { if (y - 1 >= z->t) tz_help(e, x + 1, y - 1, 0, 2); if (y + 1 <= z->b) tz_help(e, x + 1, y + 1, 0, 2); } break;
-    case 6: if (x - 1 >= z->l) tz_help(e, x - 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, x, y + 1, 0, 2); break;
-    case 7: if (y + 1 <= z->b) { if (x - 1 >= z->l) tz_help(e, x - 1, y + 1, 0, 2); if (x + 1 <= z->r) tz_help(e, x + 1, y + 1, 0, 2); } break;
-    case 8: if (x + 1 <= z->r) tz_help(e, x + 1, y, 0, 2); if (y + 1 <= z->b) tz_help(e, x, y + 1, 0, 2); break;
+    case 1: if (x - 1 >= z->l) TZ_PUSH(z, n_, x - 1, y, 0, 2); if (y - 1 >= z->t) TZ_PUSH(z, n_, x, y - 1, 0, 2); break;
+    case 2: if (y - 1 >= z->t) { if (x - 1 >= z->l) TZ_PUSH(z, n_, x - 1, y - 1, 0, 2); if (x + 1 <= z->r) TZ_PUSH(z, n_, x + 1, y - 1, 0, 2); } break;
+    case 3: if (y - 1 >= z->t) TZ_PUSH(z, n_, x, y - 1, 0, 2); if (x + 1 <= z->r) TZ_PUSH(z, n_, x + 1, y, 0, 2); break;
+    case 4: if (x - 1 >= z->l) { if (y + 1 <= z->b) TZ_PUSH(z, n_, x - 1, y + 1, 0, 2); if (y - 1 >= z->t) TZ_PUSH(z, n_, x - 1, y - 1, 0, 2); } break;
+    case 5: if (x + 1 <= z->r) { if (y - 1 >= z->t) TZ_PUSH(z, n_, x + 1, y - 1, 0, 2); if (y + 1 <= z->b) TZ_PUSH(z, n_, x + 1, y + 1, 0, 2); } break;
+    case 6: if (x - 1 >= z->l) TZ_PUSH(z, n_, x - 1, y, 0, 2); if (y + 1 <= z->b) TZ_PUSH(z, n_, x, y + 1, 0, 2); break;
+    case 7: if (y + 1 <= z->b) { if (x - 1 >= z->l) TZ_PUSH(z, n_, x - 1, y + 1, 0, 2); if (x + 1 <= z->r) TZ_PUSH(z, n_, x + 1, y + 1, 0, 2); } break;
+    case 8: if (x + 1 <= z->r) TZ_PUSH(z, n_, x + 1, y, 0, 2); if (y + 1 <= z->b) TZ_PUSH(z, n_, x, y + 1, 0, 2); break;
     default: break;
   }
+  if (n_) tz_eval_list(e, n_);
 }
 HM_DEV inline void tz_diamond(Shared *e, TZ *z, int sx, int sy, int d)
 {
   const int top = sy - d, bot = sy + d, lef = sx - d, rig = sx + d;
   z->bestRound += 1;
+  int n_ = 0;
   const int zl_ = HM_UNI(z->l), zr_ = HM_UNI(z->r), zt_ = HM_UNI(z->t), zb_ = HM_UNI(z->b);
   if (d == 1) {
-    if (top >= zt_) tz_help(e, sx, top, 2, d);
-    if (lef >= zl_) tz_help(e, lef, sy, 4, d);
-    if (rig <= zr_) tz_help(e, rig, sy, 5, d);
-    if (bot <= zb_) tz_help(e, sx, bot, 7, d);
+    if (top >= zt_) TZ_PUSH(z, n_, sx, top, 2, d);
+    if (lef >= zl_) TZ_PUSH(z, n_, lef, sy, 4, d);
+    if (rig <= zr_) TZ_PUSH(z, n_, rig, sy, 5, d);
+    if (bot <= zb_) TZ_PUSH(z, n_, sx, bot, 7, d);
   } else if (d <= 8) {
     const int top2 = sy - (d >> 1), bot2 = sy + (d >> 1), lef2 = sx - (d >> 1), rig2 = sx + (d >> 1);
     if (top >= zt_ && lef >= zl_ && rig <= zr_ && bot <= zb_) {
-      tz_help(e, sx, top, 2, d); tz_help(e, lef2, top2, 1, d >> 1); tz_help(e, rig2, top2, 3, d >> 1); tz_help(e, lef, sy, 4, d);
-      tz_help(e, rig, sy, 5, d); tz_help(e, lef2, bot2, 6, d >> 1); tz_help(e, rig2, bot2, 8, d >> 1); tz_help(e, sx, bot, 7, d);
+      TZ_PUSH(z, n_, sx, top, 2, d); TZ_PUSH(z, n_, lef2, top2, 1, d >> 1); TZ_PUSH(z, n_, rig2, top2, 3, d >> 1); TZ_PUSH(z, n_, lef, sy, 4, d);
+      TZ_PUSH(z, n_, rig, sy, 5, d); TZ_PUSH(z, n_, lef2, bot2, 6, d >> 1); TZ_PUSH(z, n_, rig2, bot2, 8, d >> 1); TZ_PUSH(z, n_, sx, bot, 7, d);
     } else {
-      if (top >= zt_) tz_help(e, sx, top, 2, d);
-      if (top2 >= zt_) { if (lef2 >= zl_) tz_help(e, lef2, top2, 1, d >> 1); if (rig2 <= zr_) tz_help(e, rig2, top2, 3, d >> 1); }
-      if (lef >= zl_) tz_help(e, lef, sy, 4, d);
-      if (rig <= zr_) tz_help(e, rig, sy, 5, d);
-      if (bot2 <= zb_) { if (lef2 >= zl_) tz_help(e, lef2, bot2, 6, d >> 1); if (rig2 <= zr_) tz_help(e, rig2, bot2, 8, d >> 1); }
-      if (bot <= zb_) tz_help(e, sx, bot, 7, d);
+      if (top >= zt_) TZ_PUSH(z, n_, sx, top, 2, d);
+      if (top2 >= zt_) { if (lef2 >= zl_) TZ_PUSH(z, n_, lef2, top2, 1, d >> 1); if (rig2 <= zr_) TZ_PUSH(z, n_, rig2, top2, 3, d >> 1); }
+      if (lef >= zl_) TZ_PUSH(z, n_, lef, sy, 4, d);
+      if (rig <= zr_) TZ_PUSH(z, n_, rig, sy, 5, d);
+      if (bot2 <= zb_) { if (lef2 >= zl_) TZ_PUSH(z, n_, lef2, bot2, 6, d >> 1); if (rig2 <= zr_) TZ_PUSH(z, n_, rig2, bot2, 8, d >> 1); }
+      if (bot <= zb_) TZ_PUSH(z, n_, sx, bot, 7, d);
     }
   } else {
     if (top >= zt_ && lef >= zl_ && rig <= zr_ && bot <= zb_) {
-      tz_help(e, sx, top, 0, d); tz_help(e, lef, sy, 0, d); tz_help(e, rig, sy, 0, d); tz_help(e, sx, bot, 0, d);
+      TZ_PUSH(z, n_, sx, top, 0, d); TZ_PUSH(z, n_, lef, sy, 0, d); TZ_PUSH(z, n_, rig, sy, 0, d); TZ_PUSH(z, n_, sx, bot, 0, d);
       for (int i = 1; i < 4; i++) {
         const int yt = top + ((d >> 2) * i), yb = bot - ((d >> 2) * i), xl = sx - ((d >> 2) * i), xr = sx + ((d >> 2) * i);
-        tz_help(e, xl, yt, 0, d); tz_help(e, xr, yt, 0, d); tz_help(e, xl, yb, 0, d); tz_help(e, xr, yb, 0, d);
+        TZ_PUSH(z, n_, xl, yt, 0, d); TZ_PUSH(z, n_, xr, yt, 0, d); TZ_PUSH(z, n_, xl, yb, 0, d); TZ_PUSH(z, n_, xr, yb, 0, d);
       }
     } else {
-      if (top >= zt_) tz_help(e, sx, top, 0, d);
-      if (lef >= zl_) tz_help(e, lef, sy, 0, d);
-      if (rig <= zr_) tz_help(e, rig, sy, 0, d);
-      if (bot <= zb_) tz_help(e, sx, bot, 0, d);
+      if (top >= zt_) TZ_PUSH(z, n_, sx, top, 0, d);
+      if (lef >= zl_) TZ_PUSH(z, n_, lef, sy, 0, d);
+      if (rig <= zr_) TZ_PUSH(z, n_, rig, sy, 0, d);
+      if (bot <= zb_) TZ_PUSH(z, n_, sx, bot, 0, d);
       for (int i = 1; i < 4; i++) {
         const int yt = top + ((d >> 2) * i), yb = bot - ((d >> 2) * i), xl = sx - ((d >> 2) * i), xr = sx + ((d >> 2) * i);
-        if (yt >= zt_) { if (xl >= zl_) tz_help(e, xl, yt, 0, d); if (xr <= zr_) tz_help(e, xr, yt, 0, d); }
-        if (yb <= zb_) { if (xl >= zl_) tz_help(e, xl, yb, 0, d); if (xr <= zr_) tz_help(e, xr, yb, 0, d); }
+        if (yt >= zt_) { if (xl >= zl_) TZ_PUSH(z, n_, xl, yt, 0, d); if (xr <= zr_) TZ_PUSH(z, n_, xr, yt, 0, d); }
+        if (yb <= zb_) { if (xl >= zl_) TZ_PUSH(z, n_, xl, yb, 0, d); if (xr <= zr_) TZ_PUSH(z, n_, xr, yb, 0, d); }
       }
     }
   }
+  if (n_) tz_eval_list(e, n_);
 }
 HM_DEV inline void set_search_range(const Shared *e, MvD pred, int rng, int cuX, int cuY, MvD *lt, MvD *rb)
 { // xSetSearchRange :3911
@@ -522,7 +557,9 @@ HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, Mv
   if (z->bestDist == 1) { z->bestDist = 0; tz_2point(e, z); }
   if (z->bestDist > raster) {
     z->bestDist = raster;
-    for (sy = rt; sy <= rbm; sy += raster) for (sx = rl; sx <= rr; sx += raster) tz_help(e, sx, sy, 0, raster);
+    int n_ = 0;
+    for (sy = rt; sy <= rbm; sy += raster) for (sx = rl; sx <= rr; sx += raster) { TZ_PUSH(z, n_, sx, sy, 0, raster); if (n_ == 16) { tz_eval_list(e, n_); n_ = 0; } }
+    if (n_) tz_eval_list(e, n_);
   }
   while (z->bestDist > 0) {
     sx = z->bestX; sy = z->bestY;
@@ -584,7 +621,9 @@ HM_DEV inline uint32_t pattern_refinement(Shared *e, TZ *z, const Pel *refAtInt,
 HM_DEV inline uint32_t pattern_search(Shared *e, TZ *z, MvD *mv, MvD lt, MvD rb)
 {
   z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0;
-  for (int y = lt.y; y <= rb.y; y++) for (int x = lt.x; x <= rb.x; x++) tz_help(e, x, y, 0, 0);
+  int n_ = 0;
+  for (int y = lt.y; y <= rb.y; y++) for (int x = lt.x; x <= rb.x; x++) { TZ_PUSH(z, n_, x, y, 0, 0); if (n_ == 16) { tz_eval_list(e, n_); n_ = 0; } }
+  if (n_) tz_eval_list(e, n_);
   mv->x = (int16_t)z->bestX; mv->y = (int16_t)z->bestY;
   return z->bestSad - mc_cost32(e, mc_bits(e, z->bestX, z->bestY));
 }
