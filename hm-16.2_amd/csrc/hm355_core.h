@@ -164,7 +164,7 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 #define HM_PROF_END(e, id) ((void)0)
 #endif
 enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBLK, PR_SAVE, PR_CHROMA, PR_LUMA, PR_ENCCU, PR_TOTAL,
-       PR_ME_INT = 16, PR_ME_FRAC, PR_AMVP, PR_MRG_EST, PR_MC, PR_IRQ, PR_IRES, PR_MRG2N, PR_INTERCU, PR_INTRA_IN_P, PR_MRGCAND };
+       PR_ME_INT = 16, PR_ME_FRAC, PR_AMVP, PR_MRG_EST, PR_MC, PR_IRQ, PR_IRES, PR_MRG2N, PR_INTERCU, PR_INTRA_IN_P, PR_IQ_FULL, PR_IQ_FWD, PR_IQ_RDOQ, PR_IQ_BITS, PR_IQ_INV, PR_IQ_ENC };
 
 #define HM_MAX_DOUBLE 1.7e+308
 #define PLANAR_IDX 0

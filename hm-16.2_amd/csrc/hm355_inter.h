@@ -1203,8 +1203,9 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
       if (!isOne && !isFirst) { HM_PAR_FOR(i, 16) { e->tsCoef[comp][i] = coef[i]; e->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; } HM_SYNC(); }
       HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int r = resi[y * st + x]; e->bufA[y * HM_TSTRIDE + x] = tsMode ? (r << tshift) : r; }
       HM_SYNC();
-      if (!tsMode) fwd_transform(e, n, 0, bd);
-      int absSum = (int)HM_UCALL(rdoq(e, coef, n, comp, SCAN_DIAG, cbfCtx));
+      { HM_PROF_BEGIN(e, PR_IQ_FWD); if (!tsMode) fwd_transform(e, n, 0, bd); HM_PROF_END(e, PR_IQ_FWD); }
+      int absSum;
+      { HM_PROF_BEGIN(e, PR_IQ_RDOQ); absSum = (int)HM_UCALL(rdoq(e, coef, n, comp, SCAN_DIAG, cbfCtx)); HM_PROF_END(e, PR_IQ_RDOQ); }
       par_set8(m->cbf[comp] + zc, (absSum > 0 ? 1 : 0) << trMode, parts);
       if (isFirst || absSum == 0) {
         const int shiftSse = (bd - 8) << 1; uint32_t sq = 0;
@@ -1219,8 +1220,8 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
       if (f->zero && isFirst) e->irqZeroDist += nonCoeffDist;
       if (absSum > 0) {
         if (isFirst) { cabac_put(&e->cur, root); reset_bits(&e->cur); }
-        code_qt_cbf(e, &e->cur, t, comp, 1);
-        code_coeff_nxn(e, &e->cur, coef, n, comp, SCAN_DIAG, tsMode);
+        { HM_PROF_BEGIN(e, PR_IQ_BITS); code_qt_cbf(e, &e->cur, t, comp, 1);
+        code_coeff_nxn(e, &e->cur, coef, n, comp, SCAN_DIAG, tsMode); HM_PROF_END(e, PR_IQ_BITS); }
         currBits = num_bits(&e->cur);
         { // xDeQuant + inverse transform (:1423-1545)
           const int rightShift = 6 - (tshift + e->fb.qpPer[comp != 0]);
@@ -1297,7 +1298,7 @@ HM_DEV HM_NOINLINE void estimate_residual_qt(Shared *e, TU rootv)
       f->checkFull = t->log2 <= 5; f->checkSplit = t->log2 > minLog2;
       f->singleCost = HM_MAX_DOUBLE; f->singleBits = 0; f->singleDist = 0;
       cabac_copy(&ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
-      if (f->checkFull) irq_check_full(e, sp);
+      if (f->checkFull) { HM_PROF_BEGIN(e, PR_IQ_FULL); irq_check_full(e, sp); HM_PROF_END(e, PR_IQ_FULL); }
       if (!f->checkSplit) { retCost = f->singleCost; retBits = f->singleBits; retDist = f->singleDist; sp--; continue; }
       if (f->checkFull) { cabac_copy(&ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); }
       f->subCost = 0.0; f->subBits = 0; f->subDist = 0; f->child = 0;
@@ -1320,8 +1321,8 @@ HM_DEV HM_NOINLINE void estimate_residual_qt(Shared *e, TU rootv)
       HM_SYNC();
       cabac_copy(&e->cur, &ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
       reset_bits(&e->cur);
-      encode_residual_qt(e, t, 3);
-      for (int comp = 0; comp < 3; comp++) encode_residual_qt(e, t, comp);
+      { HM_PROF_BEGIN(e, PR_IQ_ENC); encode_residual_qt(e, t, 3);
+      for (int comp = 0; comp < 3; comp++) encode_residual_qt(e, t, comp); HM_PROF_END(e, PR_IQ_ENC); }
       const uint32_t subdivBits = num_bits(&e->cur);
       const double subdivCost = calc_rd_cost(e, subdivBits, f->subDist);
       if (!f->checkFull || (cbfAny && subdivCost < f->singleCost)) { retCost = subdivCost; retBits = subdivBits; retDist = f->subDist; }

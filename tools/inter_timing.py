@@ -37,7 +37,7 @@ if lib is not None and hasattr(lib, "hm355_read_profile"):
     lib.hm355_read_profile.argtypes = [hm355.C.c_void_p, hm355.C.c_void_p]
     lib.hm355_read_profile(enc.h_, out)
     names = {0: "RDOQ", 1: "BITS", 2: "ADI", 3: "PRED", 4: "FWD", 5: "INV", 6: "SATD35", 8: "SAVE", 9: "CHROMA", 10: "LUMA", 11: "ENCCU", 12: "TOTAL",
-             16: "ME_INT", 17: "ME_FRAC", 18: "AMVP", 19: "MRG_EST", 20: "MC", 21: "IRQ", 22: "IRES", 23: "MRG2N", 24: "INTERCU", 25: "INTRA_IN_P"}
+             16: "ME_INT", 17: "ME_FRAC", 18: "AMVP", 19: "MRG_EST", 20: "MC", 21: "IRQ", 22: "IRES", 23: "MRG2N", 24: "INTERCU", 25: "INTRA_IN_P", 26: "IQ_FULL", 27: "IQ_FWD", 28: "IQ_RDOQ", 29: "IQ_BITS", 30: "IQ_INV", 31: "IQ_ENC"}
     tot = out[12]
     for i, nm in names.items():
         print(f"{nm:10s} {100.0 * out[i] / tot:6.2f}%  calls {out[NP + i]:9d}  cyc/call {out[i] / max(1, out[NP + i]):10.0f}")
