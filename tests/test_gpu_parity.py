@@ -119,6 +119,32 @@ def test_hip_inter_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, wpp, kind
     assert (ictus["inter_dir"] != 0).any()
 
 
+def test_hip_slot_reuse_across_slice_types(hm):
+    """a slot used for an inter slice carries nothing over into a later I slice (and back), and P and B slices can share one batch"""
+    cfgp, slp, finp = common.load_ldp_case(common.LDP_CASES[0])
+    w, h, bd = cfgp["width"], cfgp["height"], cfgp["bit_depth"]
+    enc = hm.Encoder(w, h, bd, 0, max_batch=2)
+    i_planes = synth.frame(w, h, bd, 0, cfgp["seed"])
+    (rec_a, ctus_a, _), = enc.compress([i_planes], 32)
+    rp = [r for r in slp if int(r["slice_type"]) == 1][1]
+    sp, refs = common.ldp_slice_inputs(rp, finp)
+    p_planes = synth.frame(w, h, bd, int(rp["poc"]), cfgp["seed"])
+    # the same P slice twice in one batch, once declared as a B slice whose list 1 repeats list 0's first picture (different search, same entry point)
+    spb = dict(sp); spb["slice_type"] = 0; spb["cabac_init_type"] = 0
+    spb["num_ref_idx"] = (sp["num_ref_idx"][0], 1)
+    spb["ref_poc"] = np.array(sp["ref_poc"]); spb["ref_poc"][1][0] = spb["ref_poc"][0][0]
+    out = enc.compress_inter_batch([(p_planes, sp, refs), (p_planes, spb, refs)])
+    common.assert_inter_ctus_equal(out[0][1], out[0][2], rp["ctus"], "P slice next to a B slice in one batch")
+    assert (out[1][2]["inter_dir"] == 3).any(), "the B variant found no bi-predicted partition"
+    (rec_b, ctus_b, _), = enc.compress([i_planes], 32)
+    common.assert_ctus_equal(ctus_b, ctus_a, "I slice after inter slices in the same slot")
+    for c in range(3):
+        assert np.array_equal(rec_a[c], rec_b[c])
+    rec, ctus, ictus, _ = enc.compress_inter(p_planes, sp, refs)
+    common.assert_inter_ctus_equal(ctus, ictus, rp["ctus"], "P slice after an I slice in the same slot")
+    enc.close()
+
+
 def test_hip_inter_slice_rejects_bad_parameters(hm):
     cfg, slices, finals = common.load_ldp_case(common.LDP_CASES[0])
     r = [s for s in slices if int(s["slice_type"]) == 1][0]
