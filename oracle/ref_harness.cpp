@@ -242,6 +242,22 @@ extern "C" void __wrap__ZN7TComPic14compressMotionEv(TComPic *self)
     fwrite(pm, 1, 256, f);
     putMotion(f, ctu, 0, false); putMotion(f, ctu, 1, false);
   }
+  // 'A' : what TEncSampleAdaptiveOffset::SAOProcess decided for this picture (TEncGOP.cpp:1483): i32 poc, i32 depth (temporal depth the
+  //       picture-level on/off rule uses), i32 enabled[2] (luma, chroma slice flags), u32 numCtus, then per CTU and component
+  //       i32 modeIdc, typeIdc, typeAuxInfo, offset[32]  (SAOBlkParam of TComPicSym)
+  fputc('A', f);
+  fwrite(&poc, 4, 1, f);
+  int32_t dep = (int32_t)sl->getDepth(); fwrite(&dep, 4, 1, f);
+  int32_t en[2] = { (int32_t)sl->getSaoEnabledFlag(CHANNEL_TYPE_LUMA), (int32_t)sl->getSaoEnabledFlag(CHANNEL_TYPE_CHROMA) }; fwrite(en, 4, 2, f);
+  put32(f, numCtus);
+  SAOBlkParam *sao = self->getPicSym()->getSAOBlkParam();
+  for (UInt a = 0; a < numCtus; a++)
+    for (int c = 0; c < 3; c++)
+    {
+      const SAOOffset &o = sao[a][c];
+      int32_t v[35]; v[0] = o.modeIdc; v[1] = o.typeIdc; v[2] = o.typeAuxInfo; for (int k = 0; k < 32; k++) v[3 + k] = o.offset[k];
+      fwrite(v, 4, 35, f);
+    }
 }
 
 static int runEnc(int argc, char **argv, const char *dumpName)

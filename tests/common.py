@@ -75,14 +75,21 @@ _S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "wei
            "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
 
 
-def load_ldp_case(name, records=None):
+def load_ldp_case(name, records=None, sao=None):
     """-> (cfg dict, list of 'S' records, {poc: 'F' record}) in the layout of tests/hmd2.py; `records` (a list) receives
-    every record in stream order"""
+    every record in stream order, `sao` (a dict) the SAO decisions by POC"""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     cfg = {k: int(g[k]) for k in ("width", "height", "bit_depth", "frames", "seed")}
     cfg["wpp"] = int(g["wpp"]) if "wpp" in g else 0
     slices, finals = [], {}
     for i in range(int(g["num_records"])):
+        if chr(int(g[f"r{i}_tag"])) == "A":                      # SAO decisions of the picture (tests/hmd2.py 'A' record)
+            r = {"tag": "A", "poc": int(g[f"r{i}_poc"]), "depth": int(g[f"r{i}_depth"]), "enabled": tuple(int(v) for v in g[f"r{i}_enabled"]), "sao": g[f"r{i}_sao"]}
+            if sao is not None:
+                sao[r["poc"]] = r
+            if records is not None:
+                records.append(r)
+            continue
         r = {"tag": chr(int(g[f"r{i}_tag"])), "num_ref_idx": tuple(int(v) for v in g[f"r{i}_num_ref_idx"]),
              "ref_poc": g[f"r{i}_ref_poc"], "ref_long_term": g[f"r{i}_ref_long_term"], "rec": [g[f"r{i}_rec{c}"] for c in range(3)]}
         if r["tag"] == "S":

@@ -135,6 +135,10 @@ def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_ma
     out = {"width": w, "height": h, "bit_depth": bd, "frames": nf, "seed": seed, "wpp": wpp, "num_records": len(recs)}
     for i, r in enumerate(recs):
         out[f"r{i}_tag"] = np.array(ord(r["tag"]))
+        if r["tag"] == "A":
+            out[f"r{i}_poc"] = np.array(r["poc"]); out[f"r{i}_depth"] = np.array(r["depth"])
+            out[f"r{i}_enabled"] = np.array(r["enabled"]); out[f"r{i}_sao"] = r["sao"]
+            continue
         out[f"r{i}_num_ref_idx"] = np.array(r["num_ref_idx"]); out[f"r{i}_ref_poc"] = r["ref_poc"]; out[f"r{i}_ref_long_term"] = r["ref_long_term"]
         for c in range(3):
             out[f"r{i}_rec{c}"] = r["rec"][c]

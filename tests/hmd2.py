@@ -57,6 +57,11 @@ def parse(path, width, height):
             rl, off = _ref_lists(buf, off); r.update(rl)
             n, = struct.unpack_from("<I", buf, off); off += 4
             r["motion"] = np.frombuffer(buf, MOT_DT, n, off).copy(); off += n * MOT_DT.itemsize
+        elif tag == b"A":
+            r = {"tag": "A"}
+            r["poc"], r["depth"], en0, en1, n = struct.unpack_from("<4iI", buf, off); off += 20
+            r["enabled"] = (en0, en1)
+            r["sao"] = np.frombuffer(buf, "<i4", n * 3 * 35, off).reshape(n, 3, 35).copy(); off += n * 3 * 35 * 4
         else:
             raise ValueError(f"bad record tag {tag!r} at {off - 1}")
         recs.append(r)
@@ -71,6 +76,8 @@ def write(path, recs):
     with open(path, "wb") as f:
         f.write(b"HMD2")
         for r in recs:
+            if r["tag"] == "A":
+                continue                                  # SAO decisions: not part of what the search replays
             f.write(r["tag"].encode())
             rec = b"".join(np.ascontiguousarray(p, "<u2").tobytes() for p in r["rec"])
             if r["tag"] == "S":

@@ -61,6 +61,7 @@ int main(int argc, char **argv)
       finals[f.poc] = f;
       continue;
     }
+    if (tag == 'A') { g_off += 16; const uint32_t n = rd<uint32_t>(); g_off += (size_t)n * 3 * 35 * 4; continue; }   // SAO decisions: not replayed here
     if (tag != 'S') { fprintf(stderr, "bad tag at %zu\n", g_off - 1); return 1; }
     const int poc = rd<int32_t>(), sliceType = rd<int32_t>(), qp = rd<int32_t>(); rd<int32_t>(); rd<int32_t>();
     const double lambda = rd<double>(); rd<double>(); const double wcb = rd<double>(); rd<double>();
