@@ -85,6 +85,13 @@ int hmo_compress_slice_inter(const hmo_cfg *cfg, const hmo_inter_slice *slice, c
 int hmo_deblock(const hmo_cfg *cfg, int slice_type, const int32_t ref_poc[2][16], const hmo_ctu *ctus, const hmo_ctu_inter *ictus,
                 uint16_t *const rec[3]);
 
+/* ---- sample adaptive offset, encoder side (TEncSampleAdaptiveOffset::SAOProcess, TEncGOP.cpp:1483) on the deblocked picture:
+ * rec is replaced by the SAO output.  cfg: qp, lambda, chroma_weight of the slice; depth = temporal depth of the picture;
+ * disabled_rate[comp][depth] = m_saoDisabledRate, read for depth-1 and written for depth (carried from picture to picture by the caller);
+ * sao_params (may be NULL) receives numCtus x 3 x 35 int32: modeIdc, typeIdc, typeAuxInfo, offset[32] as coded. ---- */
+int hmo_sao(const hmo_cfg *cfg, int cabac_init_type, int depth, double disabled_rate[3][8], const uint16_t *const org[3], uint16_t *const rec[3],
+            int32_t *sao_params, int32_t enabled_out[3]);
+
 /* ---- primitives, exported for the known-answer tests (TComRdCost.cpp / TComTrQuant.cpp) ---- */
 uint32_t hmo_sad(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int sub_shift, int bit_depth);
 uint32_t hmo_sse(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int bit_depth);

@@ -160,3 +160,22 @@ def deblock(rec, bit_depth, qp, slice_type, ref_poc, ctus, ictus=None):
     if rc != 0:
         raise RuntimeError(f"oracle deblock failed rc={rc}")
     return out
+
+
+def sao(org, rec, bit_depth, qp, lam, chroma_weight, cabac_init_type, depth, disabled_rate):
+    """TEncSampleAdaptiveOffset::SAOProcess on the deblocked planes `rec`; disabled_rate: float64 array (3, 8), updated in place.
+    Returns (output planes, sao params int32 (numCtus, 3, 35), enabled flags)."""
+    L = lib()
+    h, w = rec[0].shape
+    cfg = Cfg(w, h, bit_depth, int(qp), 0, float(lam), float(chroma_weight))
+    o = [np.ascontiguousarray(p, np.uint16) for p in org]
+    out = [np.ascontiguousarray(p, np.uint16).copy() for p in rec]
+    po = (C.c_void_p * 3)(*[p.ctypes.data for p in o]); pr = (C.c_void_p * 3)(*[p.ctypes.data for p in out])
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    params = np.zeros((n, 3, 35), np.int32); en = np.zeros(3, np.int32)
+    assert disabled_rate.dtype == np.float64 and disabled_rate.shape == (3, 8) and disabled_rate.flags["C_CONTIGUOUS"]
+    L.hmo_sao.argtypes = [C.POINTER(Cfg), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.hmo_sao(C.byref(cfg), int(cabac_init_type), int(depth), disabled_rate.ctypes.data, po, pr, params.ctypes.data, en.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle sao failed rc={rc}")
+    return out, params, en

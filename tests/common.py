@@ -151,3 +151,12 @@ def split_fixture_ctus(want):
         for f, g in (("mv", "mv%d"), ("mvd", "mvd%d"), ("ref_idx", "ref_idx%d"), ("mvp_idx", "mvp_idx%d"), ("mvp_num", "mvp_num%d")):
             ictus[f][:, l] = want[g % l]
     return ctus, ictus
+
+
+def normalise_sao(params):
+    """SAO block parameters (n, 3, 35) reduced to the fields the mode defines: OFF -> nothing, MERGE -> direction, NEW -> type, band position, offsets"""
+    p = np.array(params, np.int32).copy()
+    off, mrg = p[:, :, 0] == 0, p[:, :, 0] == 2
+    p[off, 1:] = 0
+    p[mrg, 2:] = 0
+    return p

@@ -86,3 +86,28 @@ def test_oracle_deblocking_matches_reference(built, name):
         for c in range(3):
             assert np.array_equal(got[c], want[c]), f"{name} POC {int(r['poc'])}: deblocked plane {c} differs at {int((got[c] != want[c]).sum())} samples"
         assert any(not np.array_equal(r["rec"][c], want[c]) for c in range(3)), "the fixture does not exercise the filter"
+
+
+@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES)
+def test_oracle_sao_matches_reference(built, name):
+    """TEncSampleAdaptiveOffset::SAOProcess: deblocking + SAO of the oracle on the pre-deblocking reconstruction must give the reference's
+    finished picture, the same per-CTU SAO parameters and the same slice-level enable flags for every picture of the clip (the
+    picture-level on/off rule carries the disabled rates from picture to picture)."""
+    import oracle
+    saod = {}
+    cfg, slices, finals = common.load_ldp_case(name, sao=saod)
+    rate = np.zeros((3, 8), np.float64)
+    n_new = 0
+    for r in slices:
+        poc = int(r["poc"])
+        ctus, ictus = common.split_fixture_ctus(r["ctus"])
+        dbk = oracle.deblock(r["rec"], cfg["bit_depth"], int(r["qp"]), int(r["slice_type"]), r["ref_poc"], ctus, ictus)
+        org = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], poc, cfg["seed"])
+        a = saod[poc]
+        out, params, en = oracle.sao(org, dbk, cfg["bit_depth"], int(r["qp"]), float(r["lambda"]), float(r["weight_cb"]), int(r["cabac_init_type"]), a["depth"], rate)
+        assert (int(en[0]), int(en[1])) == tuple(a["enabled"]) and en[1] == en[2], f"{name} POC {poc}: slice-level SAO flags"
+        assert np.array_equal(common.normalise_sao(params), common.normalise_sao(a["sao"])), f"{name} POC {poc}: SAO parameters"
+        for c in range(3):
+            assert np.array_equal(out[c], finals[poc]["rec"][c]), f"{name} POC {poc}: finished picture plane {c}"
+        n_new += int((a["sao"][:, :, 0] == 1).sum())
+    assert n_new > 0, "the fixture never chose new offsets"
