@@ -14,6 +14,7 @@
 #include <vector>
 #include "hm355_core.h"
 #include "hm355_dbk.h"
+#include "hm355_sao.h"
 #include "hm355_host_common.h"
 #include "../../include/hm355.h"
 
@@ -123,6 +124,7 @@ struct hm355_ref {       // a finished picture as later pictures reference it (d
 struct Slot {           // one picture resident in HBM
   FrameBuf fb;          // device pointers + slice parameters (host copy)
   InterMeta *imeta;     // motion arrays of the slot (allocated on first inter use; kept for the deblocking pass)
+  Pel *saoSrc[3]; SaoStat *saoStat; SaoBlk *saoCoded, *saoRecon;   // SAO working buffers (allocated on first use)
 };
 struct hm355_ctx {
   hm355_seq_cfg cfg;
@@ -141,6 +143,7 @@ struct hm355_ctx {
   int numCtus;
   void *staging; size_t stagingBytes;
   DbkParams *dDbk;      // [max_batch] deblocking parameters of the pictures in the slots
+  SaoParams *dSao;      // [max_batch] SAO parameters / results of the pictures in the slots
 };
 
 #define HM_CHECK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HM355_ERR_DEVICE; } } while (0)
@@ -168,7 +171,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
-  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL;
+  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL;
   c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
@@ -192,7 +195,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   c->slots.resize(cfg->max_batch);
   for (int s = 0; s < cfg->max_batch; s++) {
     FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
-    c->slots[s].imeta = NULL;
+    c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
     for (int k = 0; k < 3; k++) {
       const size_t bytes = (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel);
       HM_CHECK(c, hipMalloc((void **)&fb.org[k], bytes)); HM_CHECK(c, hipMemset(fb.org[k], 0, bytes));
@@ -221,11 +224,14 @@ extern "C" void hm355_destroy(hm355_ctx *c)
     FrameBuf &fb = c->slots[s].fb;
     for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
     if (c->slots[s].imeta) hipFree(c->slots[s].imeta);
+    for (int k = 0; k < 3; k++) if (c->slots[s].saoSrc[k]) hipFree(c->slots[s].saoSrc[k]);
+    if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
     if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState); if (fb.done) hipFree(fb.done);
   }
   if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems); if (c->dSched) hipFree(c->dSched);
   if (c->staging) hipHostFree(c->staging);
   if (c->dDbk) hipFree(c->dDbk);
+  if (c->dSao) hipFree(c->dSao);
   if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -569,6 +575,59 @@ extern "C" int hm355_deblock_run(hm355_ctx *c, int n, const hm355_dbk_desc *desc
   HM_CHECK(c, hipStreamSynchronize(c->stream));
   float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->lastKernelMs = ms; c->lastLaunches = 4;
+  return HM355_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample adaptive offset (TEncSampleAdaptiveOffset::SAOProcess) on the deblocked pictures of the slots
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm355_sao_run(hm355_ctx *c, int n, hm355_sao_desc *descs)
+{
+  if (!c || !descs || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp;
+  std::vector<FrameBuf> fbs(n); std::vector<SaoParams> sps(n);
+  for (int f = 0; f < n; f++) {
+    hm355_sao_desc &d = descs[f];
+    if (d.qp < 0 || d.qp > 51 || d.cabac_init_type < 0 || d.cabac_init_type > 2 || d.depth < 0 || d.depth > 7 || !(d.lambda > 0) || !(d.chroma_weight > 0))
+      return fail(c, HM355_ERR_ARG, "bad SAO parameters");
+    Slot &sl = c->slots[f];
+    for (int k = 0; k < 3; k++) if (!sl.saoSrc[k]) HM_CHECK(c, hipMalloc((void **)&sl.saoSrc[k], (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel)));
+    if (!sl.saoStat) HM_CHECK(c, hipMalloc((void **)&sl.saoStat, sizeof(SaoStat) * 3 * c->numCtus));
+    if (!sl.saoCoded) HM_CHECK(c, hipMalloc((void **)&sl.saoCoded, sizeof(SaoBlk) * c->numCtus));
+    if (!sl.saoRecon) HM_CHECK(c, hipMalloc((void **)&sl.saoRecon, sizeof(SaoBlk) * c->numCtus));
+    fbs[f] = sl.fb;
+    SaoParams &sp = sps[f]; memset(&sp, 0, sizeof(sp));
+    sp.qp = d.qp; sp.cabacInitType = d.cabac_init_type; sp.depth = d.depth;
+    sp.lambda[0] = d.lambda; sp.lambda[1] = sp.lambda[2] = d.lambda / d.chroma_weight;
+    for (int k = 0; k < 3; k++) { sp.disabledPrev[k] = d.depth > 0 ? d.disabled_rate[k][d.depth - 1] : 0.0; sp.src[k] = sl.saoSrc[k]; }
+    sp.stat = sl.saoStat; sp.coded = sl.saoCoded; sp.recon = sl.saoRecon;
+    for (int k = 0; k < 3; k++)
+      HM_CHECK(c, hipMemcpyAsync(sl.saoSrc[k], sl.fb.rec[k], (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel), hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (!c->dSao) HM_CHECK(c, hipMalloc((void **)&c->dSao, sizeof(SaoParams) * c->slots.size()));
+  HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipMemcpyAsync(c->dSao, sps.data(), sizeof(SaoParams) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(hm355_sao_stats_kernel, dim3(c->numCtus, 3, n), dim3(64, 1, 1), 0, c->stream, c->dP, c->dSao);
+  hipLaunchKernelGGL(hm355_sao_decide_kernel, dim3(n, 1, 1), dim3(64, 1, 1), 0, c->stream, c->dP, c->dSao);
+  hipLaunchKernelGGL(hm355_sao_apply_kernel, dim3((P.width + 63) / 64, P.height, 3 * n), dim3(64, 1, 1), 0, c->stream, c->dP, c->dSao);
+  HM_CHECK(c, hipGetLastError());
+  HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->lastKernelMs = ms; c->lastLaunches = 3;
+  HM_CHECK(c, hipMemcpy(sps.data(), c->dSao, sizeof(SaoParams) * n, hipMemcpyDeviceToHost));
+  for (int f = 0; f < n; f++) {
+    hm355_sao_desc &d = descs[f];
+    for (int k = 0; k < 3; k++) { d.enabled[k] = sps[f].enabled[k]; d.disabled_rate[k][d.depth] = (double)sps[f].numOff[k] / (double)c->numCtus; }
+    if (d.params) {
+      std::vector<SaoBlk> blk(c->numCtus);
+      HM_CHECK(c, hipMemcpy(blk.data(), c->slots[f].saoCoded, sizeof(SaoBlk) * c->numCtus, hipMemcpyDeviceToHost));
+      static_assert(sizeof(SaoBlk) == 3 * 35 * 4, "SaoBlk is 3 x (mode, type, aux, offset[32])");
+      memcpy(d.params, blk.data(), sizeof(SaoBlk) * c->numCtus);
+    }
+  }
   return HM355_OK;
 }
 

@@ -65,8 +65,13 @@ class DbkDesc(C.Structure):
     _fields_ = [("slice_type", C.c_int32), ("qp", C.c_int32), ("ref_poc", (C.c_int32 * 16) * 2)]
 
 
+class SaoDesc(C.Structure):
+    _fields_ = [("qp", C.c_int32), ("cabac_init_type", C.c_int32), ("depth", C.c_int32), ("lambda_", C.c_double), ("chroma_weight", C.c_double),
+                ("disabled_rate", (C.c_double * 8) * 3), ("enabled", C.c_int32 * 3), ("params", C.c_void_p)]
+
+
 EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
-           "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release",
+           "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_sao_run",
            "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
@@ -97,6 +102,7 @@ def load_library(path=LIB_PATH):
     lib.hm355_ref_from_slot.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.hm355_ref_release.argtypes = [C.c_void_p, C.c_void_p]
     lib.hm355_ref_release.restype = None
+    lib.hm355_sao_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SaoDesc)]
     lib.hm355_dist_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hm355_transform_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
@@ -277,6 +283,29 @@ class Encoder:
 
     def ref_release(self, ref):
         self.lib.hm355_ref_release(self.h_, ref["dev"])
+
+    def sao_run(self, descs):
+        """hm355_sao_run on slots 0..n-1 (deblocked pictures + originals resident).  descs: list of dicts with qp, lambda, chroma_weight,
+        cabac_init_type, depth, disabled_rate (float64 array (3, 8), updated in place).  Returns [(enabled flags, params (numCtus, 3, 35))]."""
+        n = len(descs)
+        arr = (SaoDesc * n)()
+        params = [np.zeros((self.num_ctus, 3, 35), np.int32) for _ in range(n)]
+        for k, d in enumerate(descs):
+            a = arr[k]
+            a.qp, a.cabac_init_type, a.depth = int(d["qp"]), int(d["cabac_init_type"]), int(d["depth"])
+            a.lambda_, a.chroma_weight = float(d["lambda"]), float(d["chroma_weight"])
+            for c in range(3):
+                for t in range(8):
+                    a.disabled_rate[c][t] = float(d["disabled_rate"][c][t])
+            a.params = params[k].ctypes.data
+        self._check(self.lib.hm355_sao_run(self.h_, n, arr), "hm355_sao_run")
+        out = []
+        for k, d in enumerate(descs):
+            for c in range(3):
+                for t in range(8):
+                    d["disabled_rate"][c][t] = arr[k].disabled_rate[c][t]
+            out.append((tuple(int(v) for v in arr[k].enabled), params[k]))
+        return out
 
     def deblock_run(self, descs):
         """hm355_deblock_run on slots 0..n-1 (device-resident); descs: list of (slice_type, qp, ref_poc).  Returns kernel ms."""

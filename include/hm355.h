@@ -151,6 +151,19 @@ int hm355_deblock(hm355_ctx *ctx, const hm355_dbk_desc *desc, const hm355_ctu_ou
  * their per-CTU data there; hm355_download then returns the deblocked picture */
 int hm355_deblock_run(hm355_ctx *ctx, int n, const hm355_dbk_desc *descs);
 
+/* ---- sample adaptive offset, encoder side: TEncSampleAdaptiveOffset::SAOProcess (TEncGOP.cpp:1483) on the deblocked pictures of slots
+ * 0..n-1 (after hm355_deblock_run), against the originals uploaded to the same slots: statistics, picture-level on/off, per-CTU
+ * off / new / merge decision with the SAO syntax on the CABAC estimator, offsets applied in place.  One slice, no tiles,
+ * SAOLcuBoundary 0, offset bit shifts 0 (every cfg of the reference). ---- */
+typedef struct {
+  int32_t qp, cabac_init_type, depth;  /* slice QP; context table of the slice (0 B, 1 P, 2 I); temporal depth (TComSlice::getDepth) */
+  double lambda, chroma_weight;        /* TComSlice::getLambdas(): luma lambda, chroma lambda = lambda / chroma_weight */
+  double disabled_rate[3][8];          /* in/out: TEncSampleAdaptiveOffset::m_saoDisabledRate[component][depth], carried from picture to picture */
+  int32_t enabled[3];                  /* out: slice-level SAO flags (luma, Cb, Cr) */
+  int32_t *params;                     /* out, may be NULL: numCtus x 3 x 35 int32 (modeIdc, typeIdc, typeAuxInfo, offset[32]) as coded */
+} hm355_sao_desc;
+int hm355_sao_run(hm355_ctx *ctx, int n, hm355_sao_desc *descs);
+
 /* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
  * Upload / run / download are separate so that a caller can keep pictures resident. */
 int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */

@@ -221,6 +221,37 @@ def test_hip_closed_loop_on_device_matches_reference(hm, name):
     enc.close()
 
 
+@pytest.mark.parametrize("name", [common.LDP_CASES[1], common.LDP_CASES[2], common.B_CASES[0], common.B_CASES[1]])
+def test_hip_deblock_and_sao_match_reference(hm, name):
+    """search -> hm355_deblock_run -> hm355_sao_run on the device, picture by picture of a clip the reference encoded with its default loop
+    filters: the finished picture, the per-CTU SAO parameters and the slice-level SAO flags must equal the reference's (the disabled
+    rates are carried from picture to picture as TEncSampleAdaptiveOffset does)."""
+    saod = {}
+    cfg, slices, finals = common.load_ldp_case(name, sao=saod)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=1)
+    rate = np.zeros((3, 8), np.float64)
+    for r in slices:
+        st, poc = int(r["slice_type"]), int(r["poc"])
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], poc, cfg["seed"])
+        if st == 2:
+            enc.upload(0, planes)
+            sl = (hm.SliceDesc * 1)(hm.SliceDesc(2, int(r["qp"]), float(r["lambda"]), float(r["weight_cb"])))
+            enc._check(enc.lib.hm355_run(enc.h_, 1, sl), "hm355_run")
+        else:
+            sp, refs = common.ldp_slice_inputs(r, finals)
+            enc.compress_inter(planes, sp, refs)
+        enc.deblock_run([(st, int(r["qp"]), r["ref_poc"])])
+        a = saod[poc]
+        (en, params), = enc.sao_run([dict(qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), depth=a["depth"], disabled_rate=rate,
+                                          chroma_weight=float(r["weight_cb"]), **{"lambda": float(r["lambda"])})])
+        assert (en[0], en[1]) == tuple(a["enabled"]) and en[1] == en[2], f"{name} POC {poc}: slice-level SAO flags {en} vs {a['enabled']}"
+        assert np.array_equal(common.normalise_sao(params), common.normalise_sao(a["sao"])), f"{name} POC {poc}: SAO parameters"
+        out, _, _ = enc.download(0, want_ctus=False)
+        for c in range(3):
+            assert np.array_equal(out[c], finals[poc]["rec"][c]), f"{name} POC {poc}: finished picture plane {c} differs at {int((out[c] != finals[poc]['rec'][c]).sum())} samples"
+    enc.close()
+
+
 def test_hip_batch_equals_single(hm):
     """pictures of a batch are independent: batched results == one-at-a-time results"""
     w, h, bd, qp = 128, 128, 8, 32
