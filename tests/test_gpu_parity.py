@@ -187,13 +187,17 @@ def test_hip_deblocking_matches_reference(hm, name):
     enc.close()
 
 
-@pytest.mark.parametrize("name", common.DBK_CASES)
+@pytest.mark.parametrize("name", common.DBK_CASES + [common.LDP_CASES[0], common.B_CASES[0]])
 def test_hip_closed_loop_on_device_matches_reference(hm, name):
     """A whole clip on the device, no host round trip of pictures between frames: search -> deblock in place -> device-resident
-    reference (border extension + compressMotion on the device) -> next picture's search.  The reference ran with SAO off, so every
-    stage can be compared: per-CTU data and pre-deblocking reconstruction of each slice, and the deblocked picture."""
-    cfg, slices, finals = common.load_ldp_case(name)
-    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], 0, max_batch=1)
+    reference (border extension + compressMotion on the device) -> next picture's search.  Clips the reference ran with SAO off compare
+    the deblocked picture; clips with the default loop filters also run hm355_sao_run and compare the finished picture, so the whole
+    per-picture pipeline of the reference's default configuration runs on the device."""
+    saod = {}
+    cfg, slices, finals = common.load_ldp_case(name, sao=saod)
+    with_sao = not name.startswith("dbk_")
+    rate = np.zeros((3, 8), np.float64)
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=1)
     dev_refs = {}
     for r in slices:
         st, poc = int(r["slice_type"]), int(r["poc"])
@@ -212,9 +216,12 @@ def test_hip_closed_loop_on_device_matches_reference(hm, name):
         for c in range(3):
             assert np.array_equal(rec[c], r["rec"][c]), f"{name} POC {poc}: pre-deblocking reconstruction plane {c}"
         enc.deblock_run([(st, int(r["qp"]), r["ref_poc"])])
+        if with_sao:
+            enc.sao_run([dict(qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), depth=saod[poc]["depth"], disabled_rate=rate,
+                              chroma_weight=float(r["weight_cb"]), **{"lambda": float(r["lambda"])})])
         dbk, _, _ = enc.download(0, want_ctus=False)
         for c in range(3):
-            assert np.array_equal(dbk[c], finals[poc]["rec"][c]), f"{name} POC {poc}: deblocked plane {c}"
+            assert np.array_equal(dbk[c], finals[poc]["rec"][c]), f"{name} POC {poc}: finished picture plane {c}"
         dev_refs[poc] = enc.ref_from_slot(0, poc, st != 2, r["num_ref_idx"], r["ref_poc"], r["ref_long_term"])
     for ref in dev_refs.values():
         enc.ref_release(ref)
