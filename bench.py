@@ -247,24 +247,36 @@ def run_dbk(args, torch):
     for i in range(F):
         enc.upload(i, distinct[i % len(distinct)])
     descs = [(2, qp, None)] * F
+    lam, cw = hm355.intra_lambda(qp)
     ms_total = 0.0
     for it in range(args.warmup + args.steps):
         enc.run(F, qp)                                   # untimed: puts fresh pre-deblocking pictures + CU data into the slots
         ms = enc.deblock_run(descs)
+        if args.workload == "sao":                       # timed part = hm355_sao_run on the deblocked pictures
+            sd = [dict(qp=qp, cabac_init_type=2, depth=0, disabled_rate=np.zeros((3, 8)), chroma_weight=cw, **{"lambda": lam}) for _ in range(F)]
+            enc.sao_run(sd)
+            k, l = hm355.C.c_double(), hm355.C.c_int()
+            enc.lib.hm355_last_run_info(enc.h_, hm355.C.byref(k), hm355.C.byref(l))
+            ms = k.value
         if it >= args.warmup:
             ms_total += ms
     n = enc.num_ctus * F * args.steps
     pic_bytes = w * h * 3                               # 4:2:0, 16-bit samples: 1.5 samples x 2 B per luma position
-    alg = 2 * pic_bytes * F * args.steps                # read once + written once
+    per_pic = (3 if args.workload == "sao" else 2) * pic_bytes      # deblocking: read + write; SAO: original + deblocked read, output written
+    alg = per_pic * F * args.steps
     ach = alg / (ms_total * 1e-3) / 1e9
-    line = {"metric": "CTUs/sec (deblocking filter) at 4K main10; bit-exact vs HM", "value": n / (ms_total * 1e-3), "unit": "CTU/s", "n_gpus": 1,
+    is_sao = args.workload == "sao"
+    line = {"metric": f"CTUs/sec ({'SAO, encoder side' if is_sao else 'deblocking filter'}) at 4K main10; bit-exact vs HM", "value": n / (ms_total * 1e-3), "unit": "CTU/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_total / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"TComLoopFilter::loopFilterPic on {F} I pictures {w}x{h} 10-bit (QP {qp}) resident in HBM with their CU / TU data",
+            "config": {"workload": (f"TEncSampleAdaptiveOffset::SAOProcess on {F} deblocked I pictures {w}x{h} 10-bit (QP {qp}) resident in HBM with their originals"
+                                    if is_sao else f"TComLoopFilter::loopFilterPic on {F} I pictures {w}x{h} 10-bit (QP {qp}) resident in HBM with their CU / TU data"),
                        "frames_per_gpu": F, "pictures_per_s": F * args.steps / (ms_total * 1e-3)},
-            "roofline": {"bound": "hbm", "kernel": "hm355_dbk_kernel (4 launches per step)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "note": f"algorithmic bytes = {2 * pic_bytes} B per picture (read once + written once); the per-CTU decision arrays add 3 KB per CTU"}}
+            "roofline": {"bound": "hbm", "kernel": "hm355_sao_stats / decide / apply kernels (3 launches per step)" if is_sao else "hm355_dbk_kernel (4 launches per step)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "note": (f"algorithmic bytes = {per_pic} B per picture (original and deblocked picture read, output written); the per-CTU decision walks "
+                                  "the picture on one lane (CABAC state chains from CTU to CTU) and bounds the step, not HBM") if is_sao else
+                                 f"algorithmic bytes = {per_pic} B per picture (read once + written once); the per-CTU decision arrays add 3 KB per CTU"}}
     if not args.no_cpu_baseline:
         import oracle
         # CPU side: the C restatement of the filter (kind "port", 1 core) on one picture with the device's own CU data
@@ -274,10 +286,13 @@ def run_dbk(args, torch):
         for f in oc.dtype.names:
             oc[f] = ctus1[f]
         t0 = time.time()
-        oracle.deblock(rec1, bd, qp, 2, np.zeros((2, 16), np.int32), oc, None)
+        dbk1 = oracle.deblock(rec1, bd, qp, 2, np.zeros((2, 16), np.int32), oc, None)
+        if is_sao:
+            t0 = time.time()
+            oracle.sao(distinct[0], dbk1, bd, qp, lam, cw, 2, 0, np.zeros((3, 8)))
         dt = time.time() - t0
         line["cpu_baseline"] = {"value": enc.num_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
-                                "sample": f"one {w}x{h} picture ({enc.num_ctus} CTUs) through oracle/hm_oracle_dbk.inc"}
+                                "sample": f"one {w}x{h} picture ({enc.num_ctus} CTUs) through oracle/hm_oracle_{'sao' if is_sao else 'dbk'}.inc"}
         line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
     print(json.dumps(line))
     enc.close()
@@ -285,7 +300,7 @@ def run_dbk(args, torch):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk"], help="intra4k = the BASELINE.json metric (default)")
+    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
@@ -306,7 +321,7 @@ def main():
     if args.workload != "intra4k":
         if world > 1:
             raise SystemExit("--workload ldp_p / ra_b / dbk are single-GPU measurements")
-        return run_dbk(args, torch) if args.workload == "dbk" else run_inter(args, torch)
+        return run_dbk(args, torch) if args.workload in ("dbk", "sao") else run_inter(args, torch)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -124,7 +124,7 @@ struct hm355_ref {       // a finished picture as later pictures reference it (d
 struct Slot {           // one picture resident in HBM
   FrameBuf fb;          // device pointers + slice parameters (host copy)
   InterMeta *imeta;     // motion arrays of the slot (allocated on first inter use; kept for the deblocking pass)
-  Pel *saoSrc[3]; SaoStat *saoStat; SaoBlk *saoCoded, *saoRecon;   // SAO working buffers (allocated on first use)
+  Pel *saoSrc[3]; SaoStat *saoStat; SaoCand *saoCand; SaoBlk *saoCoded, *saoRecon;   // SAO working buffers (allocated on first use)
 };
 struct hm355_ctx {
   hm355_seq_cfg cfg;
@@ -195,7 +195,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   c->slots.resize(cfg->max_batch);
   for (int s = 0; s < cfg->max_batch; s++) {
     FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
-    c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
+    c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCand = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
     for (int k = 0; k < 3; k++) {
       const size_t bytes = (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel);
       HM_CHECK(c, hipMalloc((void **)&fb.org[k], bytes)); HM_CHECK(c, hipMemset(fb.org[k], 0, bytes));
@@ -225,7 +225,7 @@ extern "C" void hm355_destroy(hm355_ctx *c)
     for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
     if (c->slots[s].imeta) hipFree(c->slots[s].imeta);
     for (int k = 0; k < 3; k++) if (c->slots[s].saoSrc[k]) hipFree(c->slots[s].saoSrc[k]);
-    if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
+    if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCand) hipFree(c->slots[s].saoCand); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
     if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState); if (fb.done) hipFree(fb.done);
   }
   if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems); if (c->dSched) hipFree(c->dSched);
@@ -593,6 +593,7 @@ extern "C" int hm355_sao_run(hm355_ctx *c, int n, hm355_sao_desc *descs)
     Slot &sl = c->slots[f];
     for (int k = 0; k < 3; k++) if (!sl.saoSrc[k]) HM_CHECK(c, hipMalloc((void **)&sl.saoSrc[k], (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel)));
     if (!sl.saoStat) HM_CHECK(c, hipMalloc((void **)&sl.saoStat, sizeof(SaoStat) * 3 * c->numCtus));
+    if (!sl.saoCand) HM_CHECK(c, hipMalloc((void **)&sl.saoCand, sizeof(SaoCand) * 3 * SAO_NUM_TYPES * c->numCtus));
     if (!sl.saoCoded) HM_CHECK(c, hipMalloc((void **)&sl.saoCoded, sizeof(SaoBlk) * c->numCtus));
     if (!sl.saoRecon) HM_CHECK(c, hipMalloc((void **)&sl.saoRecon, sizeof(SaoBlk) * c->numCtus));
     fbs[f] = sl.fb;
@@ -600,7 +601,7 @@ extern "C" int hm355_sao_run(hm355_ctx *c, int n, hm355_sao_desc *descs)
     sp.qp = d.qp; sp.cabacInitType = d.cabac_init_type; sp.depth = d.depth;
     sp.lambda[0] = d.lambda; sp.lambda[1] = sp.lambda[2] = d.lambda / d.chroma_weight;
     for (int k = 0; k < 3; k++) { sp.disabledPrev[k] = d.depth > 0 ? d.disabled_rate[k][d.depth - 1] : 0.0; sp.src[k] = sl.saoSrc[k]; }
-    sp.stat = sl.saoStat; sp.coded = sl.saoCoded; sp.recon = sl.saoRecon;
+    sp.stat = sl.saoStat; sp.cand = sl.saoCand; sp.coded = sl.saoCoded; sp.recon = sl.saoRecon;
     for (int k = 0; k < 3; k++)
       HM_CHECK(c, hipMemcpyAsync(sl.saoSrc[k], sl.fb.rec[k], (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel), hipMemcpyDeviceToDevice, c->stream));
   }

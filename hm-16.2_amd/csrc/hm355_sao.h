@@ -13,10 +13,12 @@ enum { SAO_OFF = 0, SAO_NEW = 1, SAO_MERGE = 2, SAO_EO_0 = 0, SAO_EO_90, SAO_EO_
 struct SaoOff { int32_t mode, type, aux, offset[32]; };        // SAOOffset (TypeDef.h)
 struct SaoBlk { SaoOff c[3]; };                                 // SAOBlkParam
 struct SaoStat { int32_t diff[SAO_NUM_TYPES][32], count[SAO_NUM_TYPES][32]; };    // SAOStatData of the five types of one (CTU, component)
+struct SaoCand { int32_t aux; int32_t offset[32]; int64_t dist; };   // best offsets of one (CTU, component, type) and their distortion: independent of the CABAC state
 struct SaoParams {                                             // one picture of the batch
   int32_t qp, cabacInitType, depth, enabled[3], numOff[3];
   double lambda[3], disabledPrev[3];                           // m_lambda; m_saoDisabledRate[comp][depth - 1]
   SaoStat *stat;                                               // [numCtus][3]
+  SaoCand *cand;                                               // [numCtus][3][SAO_NUM_TYPES]
   SaoBlk *coded, *recon;                                       // [numCtus] parameters as coded / with reconstructed offsets
   Pel *src[3];                                                 // copy of the deblocked planes (same padded layout as FrameBuf::rec)
 };
@@ -25,6 +27,66 @@ HM_CONST int8_t HM_SAO_DY[4][2] = { {0, 0}, {-1, 1}, {-1, 1}, {-1, 1} };
 HM_DEV inline int sao_sgn(int v) { return (v > 0) - (v < 0); }
 
 #if !defined(HM355_HOSTSIM)
+__device__ inline int64_t sao_est_dist(int64_t count, int64_t offset, int64_t diffSum, int shift) { return (count * offset * offset - diffSum * offset * 2) >> shift; }
+__device__ int64_t sao_distortion(int bd, int type, int aux, const int32_t *invQuantOffset, const int32_t *diff, const int32_t *count)
+{ // getDistortion :399
+  const int shift = 2 * (bd - 8); int64_t dist = 0;
+  if (type != SAO_BO) { for (int i = 0; i < 5; i++) dist += sao_est_dist(count[i], invQuantOffset[i], diff[i], shift); }
+  else for (int i = aux; i < aux + 4; i++) { const int b = i % 32; dist += sao_est_dist(count[b], invQuantOffset[b], diff[b], shift); }
+  return dist;
+}
+__device__ int sao_est_iter_offset(int type, double lambda, int offsetInput, int64_t count, int64_t diffSum, int shift, int64_t *bestDist, double *bestCost, int offsetTh)
+{ // estIterOffset :443
+  int iterOffset = offsetInput, offsetOutput = 0;
+  double tempMinCost = lambda;
+  while (iterOffset != 0) {
+    int64_t tempRate = (type == SAO_BO) ? (hm_abs(iterOffset) + 2) : (hm_abs(iterOffset) + 1);
+    if (hm_abs(iterOffset) == offsetTh) tempRate--;
+    const int64_t tempDist = sao_est_dist(count, iterOffset, diffSum, shift);
+    const double tempCost = (double)tempDist + lambda * (double)tempRate;
+    if (tempCost < tempMinCost) { tempMinCost = tempCost; offsetOutput = iterOffset; *bestDist = tempDist; *bestCost = tempCost; }
+    iterOffset = (iterOffset > 0) ? (iterOffset - 1) : (iterOffset + 1);
+  }
+  return offsetOutput;
+}
+__device__ inline double sao_round_ibdi(int bitDepth, double x)
+{ // xRoundIbdi / xRoundIbdi2 :51-59
+  if (bitDepth > 8) return (x > 0) ? (int)(((int)x + (1 << (bitDepth - 8 - 1))) / (1 << (bitDepth - 8))) : (int)(((int)x - (1 << (bitDepth - 8 - 1))) / (1 << (bitDepth - 8)));
+  return x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);
+}
+__device__ void sao_derive_offsets(int bd, int offsetTh, double lambda, int type, const int32_t *diff, const int32_t *count, int32_t *quantOffsets, int32_t *aux)
+{ // deriveOffsets :476-580
+  const int shift = 2 * (bd - 8);
+  for (int k = 0; k < 32; k++) quantOffsets[k] = 0;
+  const int numClasses = type == SAO_BO ? 32 : 5;
+  for (int k = 0; k < numClasses; k++) {
+    if (type != SAO_BO && k == 2) continue;
+    if (count[k] == 0) continue;
+    int q = (int)sao_round_ibdi(bd, (double)((int64_t)diff[k] << (bd - 8)) / (double)((int64_t)count[k]));
+    quantOffsets[k] = hm_clip3(-offsetTh, offsetTh, q);
+  }
+  if (type != SAO_BO) {
+    int64_t classDist; double classCost;
+    for (int k = 0; k < 5; k++) {
+      if ((k == 0 || k == 1) && quantOffsets[k] < 0) quantOffsets[k] = 0;
+      if ((k == 3 || k == 4) && quantOffsets[k] > 0) quantOffsets[k] = 0;
+      if (quantOffsets[k] != 0) quantOffsets[k] = sao_est_iter_offset(type, lambda, quantOffsets[k], count[k], diff[k], shift, &classDist, &classCost, offsetTh);
+    }
+    *aux = 0;
+  } else {
+    double costBO[32];
+    for (int k = 0; k < 32; k++) {
+      int64_t distK = 0; costBO[k] = lambda;
+      if (quantOffsets[k] != 0) quantOffsets[k] = sao_est_iter_offset(type, lambda, quantOffsets[k], count[k], diff[k], shift, &distK, &costBO[k], offsetTh);
+    }
+    double minCost = HM_MAX_DOUBLE;
+    for (int band = 0; band < 32 - 4 + 1; band++) {
+      double cost = costBO[band]; cost += costBO[band + 1]; cost += costBO[band + 2]; cost += costBO[band + 3];
+      if (cost < minCost) { minCost = cost; *aux = band; }
+    }
+    for (int k = 0; k < 32; k++) { const int rel = (k - *aux + 32) % 32; if (rel >= 4) quantOffsets[k] = 0; }
+  }
+}
 // grid: x = CTU, y = component, z = picture
 extern "C" __global__ void __launch_bounds__(64) hm355_sao_stats_kernel(const Params *P, SaoParams *sps)
 {
@@ -59,6 +121,16 @@ extern "C" __global__ void __launch_bounds__(64) hm355_sao_stats_kernel(const Pa
   __syncthreads();
   SaoStat *out = sp->stat + (size_t)a * 3 + comp;
   for (int i = lane; i < SAO_NUM_TYPES * 32; i += 64) { (&out->diff[0][0])[i] = (&hist[0][0][0])[i]; (&out->count[0][0])[i] = (&hist[1][0][0])[i]; }
+  // the "new offsets" candidate of every type (deriveOffsets :476, getDistortion :399) depends only on these statistics and lambda,
+  // not on the CABAC state, so it is prepared here, one lane per type, and the serial decision only counts bits and compares
+  if (lane < SAO_NUM_TYPES) {
+    const int type = lane, bd = P->bitDepth, maxOffQ = (1 << ((bd < 10 ? bd : 10) - 5)) - 1;
+    SaoCand *cd = sp->cand + ((size_t)a * 3 + comp) * SAO_NUM_TYPES + type;
+    int32_t off[32], aux = 0;
+    sao_derive_offsets(bd, maxOffQ, sp->lambda[comp], type, hist[0][type], hist[1][type], off, &aux);
+    cd->aux = aux; cd->dist = sao_distortion(bd, type, aux, off, hist[0][type], hist[1][type]);
+    for (int k = 0; k < 32; k++) cd->offset[k] = off[k];
+  }
 }
 
 // ---- decision (one lane per picture) ----
@@ -90,66 +162,6 @@ __device__ void sao_code_blk_param(SaoCab *c, const SaoBlk *p, const int *sliceE
   if (aboveAvail && !isLeft) { isAbove = p->c[0].mode == SAO_MERGE && p->c[0].type == 1; sao_bin(c, 0, isAbove); }
   if (onlyMergeInfo) return;
   if (!isLeft && !isAbove) for (int comp = 0; comp < 3; comp++) sao_code_offset_param(c, comp, &p->c[comp], sliceEnabled[comp], maxOffQ);
-}
-__device__ inline int64_t sao_est_dist(int64_t count, int64_t offset, int64_t diffSum, int shift) { return (count * offset * offset - diffSum * offset * 2) >> shift; }
-__device__ int64_t sao_distortion(int bd, int type, int aux, const int32_t *invQuantOffset, const SaoStat *sd)
-{ // getDistortion :399
-  const int shift = 2 * (bd - 8); int64_t dist = 0;
-  if (type != SAO_BO) { for (int i = 0; i < 5; i++) dist += sao_est_dist(sd->count[type][i], invQuantOffset[i], sd->diff[type][i], shift); }
-  else for (int i = aux; i < aux + 4; i++) { const int b = i % 32; dist += sao_est_dist(sd->count[type][b], invQuantOffset[b], sd->diff[type][b], shift); }
-  return dist;
-}
-__device__ int sao_est_iter_offset(int type, double lambda, int offsetInput, int64_t count, int64_t diffSum, int shift, int64_t *bestDist, double *bestCost, int offsetTh)
-{ // estIterOffset :443
-  int iterOffset = offsetInput, offsetOutput = 0;
-  double tempMinCost = lambda;
-  while (iterOffset != 0) {
-    int64_t tempRate = (type == SAO_BO) ? (hm_abs(iterOffset) + 2) : (hm_abs(iterOffset) + 1);
-    if (hm_abs(iterOffset) == offsetTh) tempRate--;
-    const int64_t tempDist = sao_est_dist(count, iterOffset, diffSum, shift);
-    const double tempCost = (double)tempDist + lambda * (double)tempRate;
-    if (tempCost < tempMinCost) { tempMinCost = tempCost; offsetOutput = iterOffset; *bestDist = tempDist; *bestCost = tempCost; }
-    iterOffset = (iterOffset > 0) ? (iterOffset - 1) : (iterOffset + 1);
-  }
-  return offsetOutput;
-}
-__device__ inline double sao_round_ibdi(int bitDepth, double x)
-{ // xRoundIbdi / xRoundIbdi2 :51-59
-  if (bitDepth > 8) return (x > 0) ? (int)(((int)x + (1 << (bitDepth - 8 - 1))) / (1 << (bitDepth - 8))) : (int)(((int)x - (1 << (bitDepth - 8 - 1))) / (1 << (bitDepth - 8)));
-  return x >= 0 ? (int)(x + 0.5) : (int)(x - 0.5);
-}
-__device__ void sao_derive_offsets(int bd, int offsetTh, double lambda, int type, const SaoStat *sd, int32_t *quantOffsets, int32_t *aux)
-{ // deriveOffsets :476-580
-  const int shift = 2 * (bd - 8);
-  for (int k = 0; k < 32; k++) quantOffsets[k] = 0;
-  const int numClasses = type == SAO_BO ? 32 : 5;
-  for (int k = 0; k < numClasses; k++) {
-    if (type != SAO_BO && k == 2) continue;
-    if (sd->count[type][k] == 0) continue;
-    int q = (int)sao_round_ibdi(bd, (double)((int64_t)sd->diff[type][k] << (bd - 8)) / (double)((int64_t)sd->count[type][k]));
-    quantOffsets[k] = hm_clip3(-offsetTh, offsetTh, q);
-  }
-  if (type != SAO_BO) {
-    int64_t classDist; double classCost;
-    for (int k = 0; k < 5; k++) {
-      if ((k == 0 || k == 1) && quantOffsets[k] < 0) quantOffsets[k] = 0;
-      if ((k == 3 || k == 4) && quantOffsets[k] > 0) quantOffsets[k] = 0;
-      if (quantOffsets[k] != 0) quantOffsets[k] = sao_est_iter_offset(type, lambda, quantOffsets[k], sd->count[type][k], sd->diff[type][k], shift, &classDist, &classCost, offsetTh);
-    }
-    *aux = 0;
-  } else {
-    double costBO[32];
-    for (int k = 0; k < 32; k++) {
-      int64_t distK = 0; costBO[k] = lambda;
-      if (quantOffsets[k] != 0) quantOffsets[k] = sao_est_iter_offset(type, lambda, quantOffsets[k], sd->count[type][k], sd->diff[type][k], shift, &distK, &costBO[k], offsetTh);
-    }
-    double minCost = HM_MAX_DOUBLE;
-    for (int band = 0; band < 32 - 4 + 1; band++) {
-      double cost = costBO[band]; cost += costBO[band + 1]; cost += costBO[band + 2]; cost += costBO[band + 3];
-      if (cost < minCost) { minCost = cost; *aux = band; }
-    }
-    for (int k = 0; k < 32; k++) { const int rel = (k - *aux + 32) % 32; if (rel >= 4) quantOffsets[k] = 0; }
-  }
 }
 extern "C" __global__ void __launch_bounds__(64) hm355_sao_decide_kernel(const Params *P, SaoParams *sps)
 {
@@ -183,7 +195,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_sao_decide_kernel(const P
     SaoBlk *mode = recon;                                                                   // scratch for the candidate under test (overwritten below)
     { // deriveModeNewRDO :583-723
       double mc, cost; uint32_t prevBits; int64_t dist[3], modeDist[3] = {0, 0, 0};
-      SaoOff test[3]; int32_t inv[32];
+      SaoOff test[3];
       for (int c = 0; c < 3; c++) { mode->c[c].mode = SAO_OFF; mode->c[c].type = mode->c[c].aux = 0; for (int k = 0; k < 32; k++) mode->c[c].offset[k] = 0; test[c] = mode->c[c]; }
       cur = cabCur;
       sao_code_blk_param(&cur, mode, sliceEnabled, hasL, hasA, 1, maxOffQ);
@@ -195,10 +207,9 @@ extern "C" __global__ void __launch_bounds__(64) hm355_sao_decide_kernel(const P
         cabTemp = cur;
         if (sliceEnabled[comp]) for (int type = 0; type < SAO_NUM_TYPES; type++) {
           test[comp].mode = SAO_NEW; test[comp].type = type;
-          const SaoStat *sd = sp->stat + (size_t)a * 3 + comp;
-          sao_derive_offsets(bd, maxOffQ, sp->lambda[comp], type, sd, test[comp].offset, &test[comp].aux);
-          for (int k = 0; k < 32; k++) inv[k] = test[comp].offset[k];                         // invertQuantOffsets with a zero shift
-          dist[comp] = sao_distortion(bd, type, test[comp].aux, inv, sd);
+          const SaoCand *cd = sp->cand + ((size_t)a * 3 + comp) * SAO_NUM_TYPES + type;          // deriveOffsets + getDistortion, prepared by the statistics kernel
+          test[comp].aux = cd->aux; for (int k = 0; k < 32; k++) test[comp].offset[k] = cd->offset[k];
+          dist[comp] = cd->dist;
           cur = cabMid; sao_reset_bits(&cur);
           sao_code_offset_param(&cur, comp, &test[comp], sliceEnabled[comp], maxOffQ);
           cost = (double)dist[comp] + sp->lambda[comp] * (double)(int)sao_bits(&cur);
@@ -217,10 +228,9 @@ extern "C" __global__ void __launch_bounds__(64) hm355_sao_decide_kernel(const P
         for (int comp = 1; comp < 3; comp++) {
           if (!sliceEnabled[comp]) { test[comp].mode = SAO_OFF; dist[comp] = 0; continue; }
           test[comp].mode = SAO_NEW; test[comp].type = type;
-          const SaoStat *sd = sp->stat + (size_t)a * 3 + comp;
-          sao_derive_offsets(bd, maxOffQ, sp->lambda[comp], type, sd, test[comp].offset, &test[comp].aux);
-          for (int k = 0; k < 32; k++) inv[k] = test[comp].offset[k];
-          dist[comp] = sao_distortion(bd, type, test[comp].aux, inv, sd);
+          const SaoCand *cd = sp->cand + ((size_t)a * 3 + comp) * SAO_NUM_TYPES + type;
+          test[comp].aux = cd->aux; for (int k = 0; k < 32; k++) test[comp].offset[k] = cd->offset[k];
+          dist[comp] = cd->dist;
           sao_code_offset_param(&cur, comp, &test[comp], sliceEnabled[comp], maxOffQ);
           const uint32_t cw = sao_bits(&cur); cost += dist[comp] + (sp->lambda[comp] * (cw - prevBits)); prevBits = cw;
         }
@@ -240,7 +250,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_sao_decide_kernel(const P
         double normDist = 0;
         for (int comp = 0; comp < 3; comp++) {
           const SaoOff *m = &mrg[mt]->c[comp];
-          if (m->mode != SAO_OFF) normDist += ((double)sao_distortion(bd, m->type, m->aux, m->offset, sp->stat + (size_t)a * 3 + comp)) / sp->lambda[comp];
+          if (m->mode != SAO_OFF) { const SaoStat *sd = sp->stat + (size_t)a * 3 + comp; normDist += ((double)sao_distortion(bd, m->type, m->aux, m->offset, sd->diff[m->type], sd->count[m->type])) / sp->lambda[comp]; }
         }
         SaoBlk *t = mode;                                                                      // merged copy: only mode / type of component 0 matter to the syntax
         for (int comp = 0; comp < 3; comp++) { t->c[comp] = mrg[mt]->c[comp]; t->c[comp].mode = SAO_MERGE; t->c[comp].type = mt; }
