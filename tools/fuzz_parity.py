@@ -21,6 +21,7 @@ for k in range(cases):
             (rec, ctus, _), = enc.compress([planes], qp)
             common.assert_ctus_equal(ctus, want_ctus, "I")
             what = ""
+            ictus = None
         else:
             n0, n1 = int(rng.integers(1, 4)), int(rng.integers(1, 3))
             pocs = sorted(set([0, 2, 6, 8][:max(n0, n1) + 1]))
@@ -56,6 +57,36 @@ for k in range(cases):
             what = f"L0={l0} L1={l1 if kind == 'B' else []} mrg={srec['max_merge_cand']} tmvp={srec['tmvp']} mvdL1Zero={mvd0} bi={float((ictus['inter_dir'] == 3).mean()):.2f}"
         for c in range(3):
             assert np.array_equal(rec[c], want_rec[c]), f"rec{c}"
+        # loop filters on the device (the slot still holds this picture) against the oracle's
+        st = {"I": 2, "P": 1, "B": 0}[kind]
+        sqp = qp if kind == "I" else int(srec["qp"])
+        rp = np.zeros((2, 16), np.int32) if kind == "I" else ref_poc
+        lam_s, cw_s = (hm355.intra_lambda(qp) if kind == "I" else (srec["lambda"], srec["weight_cb"]))
+        oc = np.zeros(len(ctus), oracle.CTU_DTYPE)
+        for f in oc.dtype.names:
+            oc[f] = ctus[f]
+        oi = None
+        if kind != "I":
+            oi = np.zeros(len(ctus), oracle.CTU_INTER_DTYPE)
+            for f in oi.dtype.names:
+                oi[f] = ictus[f]
+        want_dbk = oracle.deblock(rec, bd, sqp, st, rp, oc, oi)
+        depth = int(rng.integers(0, 3)); rate = rng.random((3, 8)); rate_o = rate.copy()
+        cit = 2 if kind == "I" else int(srec["cabac_init_type"])
+        cur_planes = planes if kind == "I" else cur
+        want_sao, want_par, want_en = oracle.sao(cur_planes, want_dbk, bd, sqp, lam_s, cw_s, cit, depth, rate_o)
+        enc.deblock_run([(st, sqp, rp)])
+        got_dbk, _, _ = enc.download(0, want_ctus=False)
+        for c in range(3):
+            assert np.array_equal(got_dbk[c], want_dbk[c]), f"deblocked plane {c}"
+        (en, par), = enc.sao_run([dict(qp=sqp, cabac_init_type=cit, depth=depth, disabled_rate=rate, chroma_weight=cw_s, **{"lambda": lam_s})])
+        got_sao, _, _ = enc.download(0, want_ctus=False)
+        assert tuple(en) == tuple(int(v) for v in want_en), "SAO slice flags"
+        assert np.array_equal(common.normalise_sao(par), common.normalise_sao(want_par)), "SAO parameters"
+        assert np.allclose(rate, rate_o), "SAO disabled rates"
+        for c in range(3):
+            assert np.array_equal(got_sao[c], want_sao[c]), f"SAO output plane {c}"
+        what += f" sao(depth {depth}, en {tuple(en)}, new {int((par[:, :, 0] == 1).sum())}, merge {int((par[:, :, 0] == 2).sum())})"
         print(f"case {k}: {kind} {w}x{h} {bd}b qp{qp} wpp{wpp} seed{seed} {what} ok ({time.time() - t0:.1f}s)", flush=True)
     except AssertionError as ex:
         bad += 1
