@@ -23,7 +23,7 @@ Void TEncTop::create()
   }
 }
 Void TEncTop::destroy() { for (auto p : m_cListPic) delete p; m_cListPic.clear(); if (m_ctx) hm355_destroy(m_ctx); m_ctx = nullptr; }
-Void TEncTop::init() { m_cGOPEncoder.init(this); m_cSliceEncoder.init(this); }
+Void TEncTop::init() { m_cGOPEncoder.init(this); m_cSliceEncoder.init(this); m_cLoopFilter.init(this); m_cEncSAO.init(this); }
 Void TEncTop::encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &rcListPicOut, Int &iNumEncoded)
 {
   iNumEncoded = 0;
@@ -43,7 +43,7 @@ Void TEncTop::encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &
 }
 
 // ---- TEncGOP ----
-Void TEncGOP::init(TEncTop *t) { m_pcEncTop = t; m_pcSliceEncoder = t->getSliceEncoder(); }
+Void TEncGOP::init(TEncTop *t) { m_pcEncTop = t; m_pcSliceEncoder = t->getSliceEncoder(); m_pcLoopFilter = t->getLoopFilter(); m_pcSAO = t->getSAO(); }
 Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &rcListPic)
 {
   Int iGOPid = 0;
@@ -53,7 +53,33 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
     m_pcSliceEncoder->precompressSlice(pcPic);                                                        // :1137
     m_pcSliceEncoder->compressSlice(pcPic);                                                           // :1138
     pcSlice->setSliceBits((UInt)m_pcSliceEncoder->getTotalBits());
+    // loop filters (TEncGOP.cpp:1184, :1475-1497), then the finished picture back into getPicYuvRec()
+    const Bool bLF = !m_pcEncTop->getLoopFilterDisable(), bSAO = m_pcEncTop->getUseSAO();
+    if (bLF) m_pcLoopFilter->loopFilterPic(pcPic);
+    if (bSAO) { Bool sliceEnabled[3]; m_pcSAO->SAOProcess(pcPic, sliceEnabled, m_pcSliceEncoder->getLambdas()); }
+    if (bLF || bSAO) {
+      hm355_planes rec; for (Int c = 0; c < 3; c++) rec.plane[c] = pcPic->getPicYuvRec()->getAddr(ComponentID(c));
+      if (hm355_download(m_pcEncTop->getDeviceContext(), 0, &rec, NULL, NULL) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: download failed: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
+    }
   }
+}
+
+// ---- loop filters: the picture is still resident in device slot 0 after TEncSlice::compressSlice ----
+Void TComLoopFilter::loopFilterPic(TComPic *pcPic)
+{
+  hm355_dbk_desc dd; memset(&dd, 0, sizeof(dd));
+  dd.slice_type = (int32_t)pcPic->getSlice(0)->getSliceType(); dd.qp = pcPic->getSlice(0)->getSliceQp();
+  if (hm355_deblock_run(m_pcEncTop->getDeviceContext(), 1, &dd) != HM355_OK) { fprintf(stderr, "TComLoopFilter::loopFilterPic: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
+}
+Void TEncSampleAdaptiveOffset::SAOProcess(TComPic *pPic, Bool *sliceEnabled, const Double *lambdas)
+{
+  hm355_sao_desc sd; memset(&sd, 0, sizeof(sd));
+  sd.qp = pPic->getSlice(0)->getSliceQp(); sd.cabac_init_type = (int32_t)pPic->getSlice(0)->getSliceType(); sd.depth = 0;   // all-intra GOP: temporal depth 0
+  sd.lambda = lambdas[0]; sd.chroma_weight = lambdas[0] / lambdas[1];
+  memcpy(sd.disabled_rate, m_saoDisabledRate, sizeof(m_saoDisabledRate));
+  if (hm355_sao_run(m_pcEncTop->getDeviceContext(), 1, &sd) != HM355_OK) { fprintf(stderr, "TEncSampleAdaptiveOffset::SAOProcess: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
+  memcpy(m_saoDisabledRate, sd.disabled_rate, sizeof(m_saoDisabledRate));
+  for (Int c = 0; c < 3; c++) sliceEnabled[c] = sd.enabled[c] != 0;
 }
 
 // ---- TEncSlice ----
@@ -64,6 +90,7 @@ Void TEncSlice::setUpLambda(TComSlice *, const Double dLambda, Int iQP)
   const Int q = iQP < 0 ? 0 : (iQP > 57 ? 57 : iQP);
   const Int qpc = kChromaScale420[q];                       // chroma QP offsets are 0 in every config
   m_dChromaWeight = pow(2.0, (iQP - qpc) / 3.0);
+  m_dLambdas[0] = dLambda; m_dLambdas[1] = m_dLambdas[2] = dLambda / m_dChromaWeight;   // :150-155
 }
 Void TEncSlice::initEncSlice(TComPic *pcPic, Int, Int, Int, Int, TComSlice *&rpcSlice)
 {

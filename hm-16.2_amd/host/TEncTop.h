@@ -4,8 +4,10 @@
 //   TEncSlice(TEncSlice.h:60-127)                        initEncSlice / setUpLambda / compressSlice
 // Same class and method names, argument meaning and call order as the reference; the bodies are ours and
 // TEncSlice::compressSlice forwards to the C ABI (include/hm355.h) instead of running the CPU search.
-// Everything the reference does outside the hot path (RPS, SEI, NAL, deblocking, SAO, entropy pass, rate
-// control) is out of scope and absent here.
+//   TComLoopFilter (TLibCommon/TComLoopFilter.h)              loopFilterPic          -> hm355_deblock_run
+//   TEncSampleAdaptiveOffset (TEncSampleAdaptiveOffset.h)     initRDOCabacCoder / SAOProcess -> hm355_sao_run
+// Everything else the reference does outside the hot path (RPS, SEI, NAL, entropy pass, rate control) is out of scope
+//  and absent here.
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
@@ -62,11 +64,14 @@ public:
   Void setInternalBitDepth(Int v) { m_bitDepth = v; } Void setQP(Int v) { m_iQP = v; }
   Void setIntraPeriod(Int v) { m_uiIntraPeriod = v; } Void setGOPSize(Int v) { m_iGOPSize = v; }
   Void setWaveFrontSynchro(Int v) { m_iWaveFrontSynchro = v; } Void setFramesToBeEncoded(Int v) { m_framesToBeEncoded = v; }
+  Void setLoopFilterDisable(Bool b) { m_bLoopFilterDisable = b; } Bool getLoopFilterDisable() const { return m_bLoopFilterDisable; }
+  Void setUseSAO(Bool b) { m_bUseSAO = b; } Bool getUseSAO() const { return m_bUseSAO; }
   Int getSourceWidth() const { return m_iSourceWidth; } Int getSourceHeight() const { return m_iSourceHeight; }
   Int getQP() const { return m_iQP; } Int getGOPSize() const { return m_iGOPSize; } Int getIntraPeriod() const { return m_uiIntraPeriod; }
   Int getWaveFrontsynchro() const { return m_iWaveFrontSynchro; } Int getInternalBitDepth() const { return m_bitDepth; }
 protected:
   Int m_iSourceWidth = 0, m_iSourceHeight = 0, m_bitDepth = 8, m_iQP = 32, m_uiIntraPeriod = 1, m_iGOPSize = 1, m_iWaveFrontSynchro = 0, m_framesToBeEncoded = 0;
+  Bool m_bLoopFilterDisable = true, m_bUseSAO = false;      // the loop filters are opt-in here (the reference's cfg files switch both on)
 };
 
 class TEncTop;
@@ -77,6 +82,7 @@ public:
   // TEncSlice::initEncSlice (TEncSlice.cpp:180-481): slice type, QP and lambda of the picture
   Void initEncSlice(TComPic *pcPic, Int pocLast, Int pocCurr, Int iNumPicRcvd, Int iGOPid, TComSlice *&rpcSlice);
   Void setUpLambda(TComSlice *slice, const Double dLambda, Int iQP);                 // TEncSlice.cpp:132-159
+  const Double *getLambdas() const { return m_dLambdas; }                            // TComSlice::getLambdas of the current slice
   Void precompressSlice(TComPic *) {}                                                // DeltaQpRD = 0 in every config: no-op
   Void compressSlice(TComPic *pcPic);                                                // TEncSlice.cpp:640 -> hm355_compress_slice
   uint64_t getTotalBits() const { return m_uiPicTotalBits; }
@@ -84,8 +90,25 @@ public:
   uint64_t getPicDist() const { return m_uiPicDist; }
 private:
   TEncTop *m_pcEncTop = nullptr;
-  Double m_dLambda = 0, m_dChromaWeight = 1;
+  Double m_dLambda = 0, m_dChromaWeight = 1, m_dLambdas[3] = {0, 0, 0};
   uint64_t m_uiPicTotalBits = 0, m_uiPicDist = 0; Double m_dPicRdCost = 0;
+};
+
+// TComLoopFilter::loopFilterPic (TComLoopFilter.cpp:130): deblocks the picture compressSlice just left in the device slot
+class TComLoopFilter {
+public:
+  Void init(TEncTop *pcEncTop) { m_pcEncTop = pcEncTop; }
+  Void loopFilterPic(TComPic *pcPic);
+private:
+  TEncTop *m_pcEncTop = nullptr;
+};
+// TEncSampleAdaptiveOffset::SAOProcess (TEncSampleAdaptiveOffset.cpp:259); m_saoDisabledRate lives here as in the reference
+class TEncSampleAdaptiveOffset {
+public:
+  Void init(TEncTop *pcEncTop) { m_pcEncTop = pcEncTop; }
+  Void SAOProcess(TComPic *pPic, Bool *sliceEnabled, const Double *lambdas);
+private:
+  TEncTop *m_pcEncTop = nullptr; Double m_saoDisabledRate[3][8] = {};
 };
 
 class TEncGOP {
@@ -94,7 +117,7 @@ public:
   // TEncGOP::compressGOP (TEncGOP.cpp:527): one picture per call for the all-intra GOP (GOPSize 1)
   Void compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &rcListPic);
 private:
-  TEncTop *m_pcEncTop = nullptr; TEncSlice *m_pcSliceEncoder = nullptr;
+  TEncTop *m_pcEncTop = nullptr; TEncSlice *m_pcSliceEncoder = nullptr; TComLoopFilter *m_pcLoopFilter = nullptr; TEncSampleAdaptiveOffset *m_pcSAO = nullptr;
 };
 
 class TEncTop : public TEncCfg {
@@ -105,8 +128,10 @@ public:
   // TEncTop::encode (TEncTop.cpp:259): takes one original picture, encodes when a GOP is complete
   Void encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &rcListPicOut, Int &iNumEncoded);
   TEncSlice *getSliceEncoder() { return &m_cSliceEncoder; }
+  TComLoopFilter *getLoopFilter() { return &m_cLoopFilter; }
+  TEncSampleAdaptiveOffset *getSAO() { return &m_cEncSAO; }
   hm355_ctx *getDeviceContext() { return m_ctx; }
 private:
-  hm355_ctx *m_ctx = nullptr; TEncGOP m_cGOPEncoder; TEncSlice m_cSliceEncoder;
+  hm355_ctx *m_ctx = nullptr; TEncGOP m_cGOPEncoder; TEncSlice m_cSliceEncoder; TComLoopFilter m_cLoopFilter; TEncSampleAdaptiveOffset m_cEncSAO;
   std::list<TComPic *> m_cListPic; Int m_iPOCLast = -1, m_iNumPicRcvd = 0;
 };

@@ -1,7 +1,7 @@
 // Small driver in the shape of the reference's TAppEncoder loop (TAppEncTop.cpp:407-520): reads a planar
 // 4:2:0 file, feeds TEncTop::encode picture by picture and dumps what compressSlice left behind in the
 // same "HMD1" format the reference harness writes (oracle/ref_harness.cpp), for the parity tests.
-//   hm355_encmain <in.yuv> <w> <h> <bitdepth> <frames> <qp> <wpp> <dump.bin>
+//   hm355_encmain <in.yuv> <w> <h> <bitdepth> <frames> <qp> <wpp> <dump.bin> [lf]     lf: run deblocking + SAO, the dump then holds the finished pictures
 #include "TEncTop.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,6 +16,7 @@ int main(int argc, char **argv)
   TEncTop enc;
   enc.setSourceWidth(w); enc.setSourceHeight(h); enc.setInternalBitDepth(bd); enc.setQP(qp); enc.setIntraPeriod(1); enc.setGOPSize(1);
   enc.setWaveFrontSynchro(wpp); enc.setFramesToBeEncoded(frames);
+  if (argc > 9 && !strcmp(argv[9], "lf")) { enc.setLoopFilterDisable(false); enc.setUseSAO(true); }
   enc.create(); enc.init();
   fwrite("HMD1", 1, 4, fo);
   uint32_t hdr[5] = { (uint32_t)w, (uint32_t)h, (uint32_t)bd, 64, (uint32_t)frames }; fwrite(hdr, 4, 5, fo);

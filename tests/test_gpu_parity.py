@@ -359,3 +359,29 @@ def test_cpp_host_mirror_drop_in(tmp_path):
     for i, (ctus, rec) in enumerate(frames):
         common.assert_ctus_equal(got[i][0], ctus, f"frame {i}", (cfg["width"], cfg["height"]))
         assert np.array_equal(got[i][1], rec)
+
+
+def test_cpp_host_mirror_with_loop_filters(built, tmp_path):
+    """the same C++ mirror with TComLoopFilter::loopFilterPic and TEncSampleAdaptiveOffset::SAOProcess in TEncGOP::compressGOP: the finished
+    pictures equal search + deblocking + SAO of the oracle (each pinned against the reference separately; all-intra: temporal depth 0)"""
+    import os, subprocess
+    import gen_golden, oracle
+    w, h, bd, qp, wpp, nf, seed = 200, 136, 10, 30, 1, 2, 9
+    yuv = tmp_path / "in.yuv"
+    synth.write_yuv(str(yuv), w, h, bd, nf, seed)
+    dump = tmp_path / "dump.bin"
+    exe = os.path.join(common.ROOT, "hm-16.2_amd", "hm355_encmain")
+    subprocess.run([exe, str(yuv), str(w), str(h), str(bd), str(nf), str(qp), str(wpp), str(dump), "lf"], check=True)
+    got = gen_golden.parse_dump(str(dump))
+    import hm355
+    lam, cw = hm355.intra_lambda(qp)
+    rate = np.zeros((3, 8), np.float64)
+    for i in range(nf):
+        planes = synth.frame(w, h, bd, i, seed)
+        rec, ctus = oracle.compress(planes, bd, qp, wpp)
+        common.assert_ctus_equal(got[i][0], ctus, f"frame {i}")
+        dbk = oracle.deblock(rec, bd, qp, 2, np.zeros((2, 16), np.int32), ctus, None)
+        fin, _, _ = oracle.sao(planes, dbk, bd, qp, lam, cw, 2, 0, rate)
+        want = np.concatenate([p.ravel() for p in fin])
+        assert np.array_equal(got[i][1], want), f"frame {i}: finished picture differs at {int((got[i][1] != want).sum())} samples"
+
