@@ -3,8 +3,8 @@
 //   hm355_sao_stats_kernel   per-CTU statistics of every SAO type (getBlkStats :910), one workgroup per (CTU, component), lanes over
 //                            the samples, class histograms in LDS
 //   hm355_sao_decide_kernel  picture-level on/off (decidePicParams :365) and the per-CTU off / new / merge decision in CTU order
-//                            (decideBlkParams :780): the CABAC estimator state chains from CTU to CTU, so one lane walks the picture;
-//                            pictures of a batch run side by side
+//                            (decideBlkParams :780): the CABAC estimator state chains from CTU to CTU, so one lane walks the picture
+//                            while the wavefront stages its inputs and outputs through LDS; pictures of a batch run side by side
 //   hm355_sao_apply_kernel   offsets applied per sample (TComSampleAdaptiveOffset::offsetBlock, TComSampleAdaptiveOffset.cpp:311)
 // One slice, no tiles, SAOLcuBoundary = 0, offset bit shifts 0 (every cfg of the reference).
 #pragma once
@@ -163,14 +163,22 @@ __device__ void sao_code_blk_param(SaoCab *c, const SaoBlk *p, const int *sliceE
   if (onlyMergeInfo) return;
   if (!isLeft && !isAbove) for (int comp = 0; comp < 3; comp++) sao_code_offset_param(c, comp, &p->c[comp], sliceEnabled[comp], maxOffQ);
 }
+// One workgroup per picture.  The decision itself is serial (lane 0: the estimator state and the merge candidates chain from CTU to
+// CTU), but everything it reads and writes for a CTU is moved between HBM and LDS by the whole wavefront, so the serial part never waits
+// on a dependent HBM access: candidates of the 15 (component, type) pairs, the reconstructed parameters of the left / above CTU, the
+// statistics of this CTU for the neighbours' types (merge distortion), and the coded / reconstructed parameters going out.
 extern "C" __global__ void __launch_bounds__(64) hm355_sao_decide_kernel(const Params *P, SaoParams *sps)
 {
-  if (threadIdx.x != 0) return;
+  __shared__ SaoCand sCand[3 * SAO_NUM_TYPES];
+  __shared__ SaoBlk sNb[2], sMode, sCoded, sRecon;
+  __shared__ int32_t sMrg[2][3][2][32];                           // [merge candidate][component][diff, count][class] of the neighbour's type
   SaoParams *sp = sps + blockIdx.x;
+  const int lane = (int)threadIdx.x;
   const int bd = P->bitDepth, numCtus = P->wCtu * P->hCtu, wCtu = P->wCtu;
   const int maxOffQ = (1 << ((bd < 10 ? bd : 10) - 5)) - 1;                                   // g_saoMaxOffsetQVal
   int sliceEnabled[3];                                                                      // decidePicParams :365
-  for (int c = 0; c < 3; c++) { sliceEnabled[c] = !(sp->depth > 0 && sp->disabledPrev[c] > (c == 0 ? 0.75 : 0.5)); sp->enabled[c] = sliceEnabled[c]; }
+  for (int c = 0; c < 3; c++) sliceEnabled[c] = !(sp->depth > 0 && sp->disabledPrev[c] > (c == 0 ? 0.75 : 0.5));
+  int numOff[3] = {0, 0, 0};
   SaoCab cur, cabCur, cabNext, cabMid, cabTemp;
   { // initRDOCabacCoder :247 (INIT_SAO_MERGE_FLAG / INIT_SAO_TYPE_IDX, ContextTables.h:445-458: rows B, P, I)
     const int qp = hm_clip3(0, 51, sp->qp);
@@ -185,92 +193,114 @@ extern "C" __global__ void __launch_bounds__(64) hm355_sao_decide_kernel(const P
   }
   cabNext = cabTemp = cur;
   const int allDisabled = !sliceEnabled[0] && !sliceEnabled[1] && !sliceEnabled[2];
+  const int nW = (int)(sizeof(SaoBlk) / 4), nC = (int)(sizeof(sCand) / 4);
   for (int a = 0; a < numCtus; a++) {                                                        // decideBlkParams :780-860
-    SaoBlk *coded = sp->coded + a, *recon = sp->recon + a;
-    if (allDisabled) { for (int c = 0; c < 3; c++) { coded->c[c].mode = SAO_OFF; coded->c[c].type = coded->c[c].aux = 0; recon->c[c] = coded->c[c]; } continue; }
-    cabCur = cur;
-    const SaoBlk *mrg[2] = { (a % wCtu) > 0 ? sp->recon + a - 1 : (const SaoBlk *)0, (a / wCtu) > 0 ? sp->recon + a - wCtu : (const SaoBlk *)0 };
     const int hasL = (a % wCtu) > 0, hasA = (a / wCtu) > 0;
-    double minCost = HM_MAX_DOUBLE, modeCost;
-    SaoBlk *mode = recon;                                                                   // scratch for the candidate under test (overwritten below)
-    { // deriveModeNewRDO :583-723
-      double mc, cost; uint32_t prevBits; int64_t dist[3], modeDist[3] = {0, 0, 0};
-      SaoOff test[3];
-      for (int c = 0; c < 3; c++) { mode->c[c].mode = SAO_OFF; mode->c[c].type = mode->c[c].aux = 0; for (int k = 0; k < 32; k++) mode->c[c].offset[k] = 0; test[c] = mode->c[c]; }
-      cur = cabCur;
-      sao_code_blk_param(&cur, mode, sliceEnabled, hasL, hasA, 1, maxOffQ);
-      cabMid = cur;
-      { const int comp = 0;
-        sao_reset_bits(&cur);
-        sao_code_offset_param(&cur, comp, &mode->c[comp], sliceEnabled[comp], maxOffQ);
-        mc = sp->lambda[comp] * (double)sao_bits(&cur);
-        cabTemp = cur;
-        if (sliceEnabled[comp]) for (int type = 0; type < SAO_NUM_TYPES; type++) {
-          test[comp].mode = SAO_NEW; test[comp].type = type;
-          const SaoCand *cd = sp->cand + ((size_t)a * 3 + comp) * SAO_NUM_TYPES + type;          // deriveOffsets + getDistortion, prepared by the statistics kernel
-          test[comp].aux = cd->aux; for (int k = 0; k < 32; k++) test[comp].offset[k] = cd->offset[k];
-          dist[comp] = cd->dist;
-          cur = cabMid; sao_reset_bits(&cur);
-          sao_code_offset_param(&cur, comp, &test[comp], sliceEnabled[comp], maxOffQ);
-          cost = (double)dist[comp] + sp->lambda[comp] * (double)(int)sao_bits(&cur);
-          if (cost < mc) { mc = cost; modeDist[comp] = dist[comp]; mode->c[comp] = test[comp]; cabTemp = cur; }
+    if (!allDisabled) {
+      const int32_t *gc = (const int32_t *)(sp->cand + (size_t)a * 3 * SAO_NUM_TYPES);
+      for (int i = lane; i < nC; i += 64) ((int32_t *)sCand)[i] = gc[i];
+      if (hasL) { const int32_t *g = (const int32_t *)(sp->recon + a - 1); for (int i = lane; i < nW; i += 64) ((int32_t *)&sNb[0])[i] = g[i]; }
+      if (hasA) { const int32_t *g = (const int32_t *)(sp->recon + a - wCtu); for (int i = lane; i < nW; i += 64) ((int32_t *)&sNb[1])[i] = g[i]; }
+      __syncthreads();
+      for (int i = lane; i < 2 * 3 * 64; i += 64) {                                             // this CTU's statistics for the neighbours' types
+        const int mt = i / 192, r = i - mt * 192, comp = r >> 6, k = r & 63;
+        if (mt == 0 ? hasL : hasA) {
+          const SaoOff *m = &sNb[mt].c[comp];
+          if (m->mode != SAO_OFF) { const SaoStat *sd = sp->stat + (size_t)a * 3 + comp; sMrg[mt][comp][k >> 5][k & 31] = k < 32 ? sd->diff[m->type][k] : sd->count[m->type][k - 32]; }
         }
-        cur = cabTemp; cabMid = cur;
       }
-      cost = 0; prevBits = 0; sao_reset_bits(&cur);
-      for (int comp = 1; comp < 3; comp++) {
-        sao_code_offset_param(&cur, comp, &mode->c[comp], sliceEnabled[comp], maxOffQ);
-        const uint32_t cw = sao_bits(&cur); cost += sp->lambda[comp] * (cw - prevBits); prevBits = cw;
-      }
-      mc = cost;
-      for (int type = 0; type < SAO_NUM_TYPES; type++) {
-        cur = cabMid; sao_reset_bits(&cur); prevBits = 0; cost = 0;
-        for (int comp = 1; comp < 3; comp++) {
-          if (!sliceEnabled[comp]) { test[comp].mode = SAO_OFF; dist[comp] = 0; continue; }
-          test[comp].mode = SAO_NEW; test[comp].type = type;
-          const SaoCand *cd = sp->cand + ((size_t)a * 3 + comp) * SAO_NUM_TYPES + type;
-          test[comp].aux = cd->aux; for (int k = 0; k < 32; k++) test[comp].offset[k] = cd->offset[k];
-          dist[comp] = cd->dist;
-          sao_code_offset_param(&cur, comp, &test[comp], sliceEnabled[comp], maxOffQ);
-          const uint32_t cw = sao_bits(&cur); cost += dist[comp] + (sp->lambda[comp] * (cw - prevBits)); prevBits = cw;
-        }
-        if (cost < mc) { mc = cost; for (int comp = 1; comp < 3; comp++) { modeDist[comp] = dist[comp]; mode->c[comp] = test[comp]; } }
-      }
-      modeCost = 0;
-      for (int comp = 0; comp < 3; comp++) modeCost += (double)modeDist[comp] / sp->lambda[comp];
-      cur = cabCur; sao_reset_bits(&cur);
-      sao_code_blk_param(&cur, mode, sliceEnabled, hasL, hasA, 0, maxOffQ);
-      modeCost += (double)sao_bits(&cur);
+      __syncthreads();
     }
-    if (modeCost < minCost) { minCost = modeCost; *coded = *mode; cabNext = cur; }
-    { // deriveModeMergeRDO :726-777
-      double best = HM_MAX_DOUBLE; int bestType = -1;
-      for (int mt = 0; mt < 2; mt++) {
-        if (!mrg[mt]) continue;
-        double normDist = 0;
-        for (int comp = 0; comp < 3; comp++) {
-          const SaoOff *m = &mrg[mt]->c[comp];
-          if (m->mode != SAO_OFF) { const SaoStat *sd = sp->stat + (size_t)a * 3 + comp; normDist += ((double)sao_distortion(bd, m->type, m->aux, m->offset, sd->diff[m->type], sd->count[m->type])) / sp->lambda[comp]; }
+    if (lane == 0) {
+      SaoBlk *coded = &sCoded, *recon = &sRecon, *mode = &sMode;
+      if (allDisabled) { for (int c = 0; c < 3; c++) { coded->c[c].mode = SAO_OFF; coded->c[c].type = coded->c[c].aux = 0; for (int k = 0; k < 32; k++) coded->c[c].offset[k] = 0; recon->c[c] = coded->c[c]; } }
+      else {
+        cabCur = cur;
+        double minCost = HM_MAX_DOUBLE, modeCost;
+        { // deriveModeNewRDO :583-723
+          double mc, cost; uint32_t prevBits; int64_t dist[3], modeDist[3] = {0, 0, 0};
+          SaoOff test[3];
+          for (int c = 0; c < 3; c++) { mode->c[c].mode = SAO_OFF; mode->c[c].type = mode->c[c].aux = 0; for (int k = 0; k < 32; k++) mode->c[c].offset[k] = 0; test[c] = mode->c[c]; }
+          cur = cabCur;
+          sao_code_blk_param(&cur, mode, sliceEnabled, hasL, hasA, 1, maxOffQ);
+          cabMid = cur;
+          { const int comp = 0;
+            sao_reset_bits(&cur);
+            sao_code_offset_param(&cur, comp, &mode->c[comp], sliceEnabled[comp], maxOffQ);
+            mc = sp->lambda[comp] * (double)sao_bits(&cur);
+            cabTemp = cur;
+            if (sliceEnabled[comp]) for (int type = 0; type < SAO_NUM_TYPES; type++) {
+              const SaoCand *cd = &sCand[comp * SAO_NUM_TYPES + type];                              // deriveOffsets + getDistortion, prepared by the statistics kernel
+              test[comp].mode = SAO_NEW; test[comp].type = type; test[comp].aux = cd->aux; for (int k = 0; k < 32; k++) test[comp].offset[k] = cd->offset[k];
+              dist[comp] = cd->dist;
+              cur = cabMid; sao_reset_bits(&cur);
+              sao_code_offset_param(&cur, comp, &test[comp], sliceEnabled[comp], maxOffQ);
+              cost = (double)dist[comp] + sp->lambda[comp] * (double)(int)sao_bits(&cur);
+              if (cost < mc) { mc = cost; modeDist[comp] = dist[comp]; mode->c[comp] = test[comp]; cabTemp = cur; }
+            }
+            cur = cabTemp; cabMid = cur;
+          }
+          cost = 0; prevBits = 0; sao_reset_bits(&cur);
+          for (int comp = 1; comp < 3; comp++) {
+            sao_code_offset_param(&cur, comp, &mode->c[comp], sliceEnabled[comp], maxOffQ);
+            const uint32_t cw = sao_bits(&cur); cost += sp->lambda[comp] * (cw - prevBits); prevBits = cw;
+          }
+          mc = cost;
+          for (int type = 0; type < SAO_NUM_TYPES; type++) {
+            cur = cabMid; sao_reset_bits(&cur); prevBits = 0; cost = 0;
+            for (int comp = 1; comp < 3; comp++) {
+              if (!sliceEnabled[comp]) { test[comp].mode = SAO_OFF; dist[comp] = 0; continue; }
+              const SaoCand *cd = &sCand[comp * SAO_NUM_TYPES + type];
+              test[comp].mode = SAO_NEW; test[comp].type = type; test[comp].aux = cd->aux; for (int k = 0; k < 32; k++) test[comp].offset[k] = cd->offset[k];
+              dist[comp] = cd->dist;
+              sao_code_offset_param(&cur, comp, &test[comp], sliceEnabled[comp], maxOffQ);
+              const uint32_t cw = sao_bits(&cur); cost += dist[comp] + (sp->lambda[comp] * (cw - prevBits)); prevBits = cw;
+            }
+            if (cost < mc) { mc = cost; for (int comp = 1; comp < 3; comp++) { modeDist[comp] = dist[comp]; mode->c[comp] = test[comp]; } }
+          }
+          modeCost = 0;
+          for (int comp = 0; comp < 3; comp++) modeCost += (double)modeDist[comp] / sp->lambda[comp];
+          cur = cabCur; sao_reset_bits(&cur);
+          sao_code_blk_param(&cur, mode, sliceEnabled, hasL, hasA, 0, maxOffQ);
+          modeCost += (double)sao_bits(&cur);
         }
-        SaoBlk *t = mode;                                                                      // merged copy: only mode / type of component 0 matter to the syntax
-        for (int comp = 0; comp < 3; comp++) { t->c[comp] = mrg[mt]->c[comp]; t->c[comp].mode = SAO_MERGE; t->c[comp].type = mt; }
-        cur = cabCur; sao_reset_bits(&cur);
-        sao_code_blk_param(&cur, t, sliceEnabled, hasL, hasA, 0, maxOffQ);
-        const double cost = normDist + (double)(int)sao_bits(&cur);
-        if (cost < best) { best = cost; bestType = mt; cabTemp = cur; }
+        if (modeCost < minCost) { minCost = modeCost; *coded = *mode; cabNext = cur; }
+        { // deriveModeMergeRDO :726-777
+          double best = HM_MAX_DOUBLE; int bestType = -1;
+          for (int mt = 0; mt < 2; mt++) {
+            if (!(mt == 0 ? hasL : hasA)) continue;
+            double normDist = 0;
+            for (int comp = 0; comp < 3; comp++) {
+              const SaoOff *m = &sNb[mt].c[comp];
+              if (m->mode != SAO_OFF) normDist += ((double)sao_distortion(bd, m->type, m->aux, m->offset, sMrg[mt][comp][0], sMrg[mt][comp][1])) / sp->lambda[comp];
+            }
+            SaoBlk *t = mode;                                                                  // only mode / type of component 0 matter to the syntax
+            for (int comp = 0; comp < 3; comp++) { t->c[comp].mode = SAO_MERGE; t->c[comp].type = mt; }
+            cur = cabCur; sao_reset_bits(&cur);
+            sao_code_blk_param(&cur, t, sliceEnabled, hasL, hasA, 0, maxOffQ);
+            const double cost = normDist + (double)(int)sao_bits(&cur);
+            if (cost < best) { best = cost; bestType = mt; cabTemp = cur; }
+          }
+          cur = cabTemp;
+          if (best < minCost) {
+            minCost = best;
+            for (int comp = 0; comp < 3; comp++) { coded->c[comp] = sNb[bestType].c[comp]; coded->c[comp].mode = SAO_MERGE; coded->c[comp].type = bestType; }
+            cabNext = cur;
+          }
+        }
+        cur = cabNext;
+        // reconstructBlkSAOParam :248: new -> offsets as coded (zero bit shift), merge -> the neighbour's reconstructed parameters
+        for (int comp = 0; comp < 3; comp++) { if (coded->c[comp].mode == SAO_MERGE) recon->c[comp] = sNb[coded->c[comp].type].c[comp]; else recon->c[comp] = coded->c[comp]; }
       }
-      cur = cabTemp;
-      if (best < minCost) {
-        minCost = best;
-        for (int comp = 0; comp < 3; comp++) { coded->c[comp] = mrg[bestType]->c[comp]; coded->c[comp].mode = SAO_MERGE; coded->c[comp].type = bestType; }
-        cabNext = cur;
-      }
+      for (int c = 0; c < 3; c++) numOff[c] += recon->c[c].mode == SAO_OFF;                      // SAO_ENCODING_CHOICE :868
     }
-    cur = cabNext;
-    // reconstructBlkSAOParam :248: new -> offsets as coded (zero bit shift), merge -> the neighbour's reconstructed parameters
-    for (int comp = 0; comp < 3; comp++) { if (coded->c[comp].mode == SAO_MERGE) recon->c[comp] = mrg[coded->c[comp].type]->c[comp]; else recon->c[comp] = coded->c[comp]; }
+    __syncthreads();
+    { int32_t *gc = (int32_t *)(sp->coded + a), *gr = (int32_t *)(sp->recon + a);
+      for (int i = lane; i < nW; i += 64) { gc[i] = ((const int32_t *)&sCoded)[i]; gr[i] = ((const int32_t *)&sRecon)[i]; } }
+    __threadfence_block();
+    __syncthreads();
   }
-  for (int c = 0; c < 3; c++) { int n = 0; for (int a = 0; a < numCtus; a++) n += sp->recon[a].c[c].mode == SAO_OFF; sp->numOff[c] = n; }   // SAO_ENCODING_CHOICE :868
+  if (lane == 0) for (int c = 0; c < 3; c++) { sp->enabled[c] = sliceEnabled[c]; sp->numOff[c] = numOff[c]; }
 }
 
 // grid: x = ceil(plane width / 64), y = plane row, z = 3 * picture + component
