@@ -203,7 +203,13 @@ static inline int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; 
 /* ============================================================================================ */
 /* CABAC bit estimator (TEncBinCABACCounter, TEncBinCoderCABACCounter.cpp:56-131)                */
 /* ============================================================================================ */
-typedef struct { uint8_t s[NUM_CTX]; uint8_t pad[4]; uint64_t frac; } Cabac;
+/* The bitstream pass (hm_oracle_bits.inc) drives the same syntax functions with the arithmetic coder attached (be != NULL):
+   every bin then also goes through TEncBinCABAC (TEncBinCoderCABAC.cpp:69-437). */
+struct BinEnc;
+typedef struct { uint8_t s[NUM_CTX]; uint8_t pad[4]; uint64_t frac; struct BinEnc *be; } Cabac;
+static void be_bin(struct BinEnc *b, int ctx, int st, int bin);
+static void be_ep(struct BinEnc *b, uint32_t val, int n);
+static void be_trm(struct BinEnc *b, int bin);
 
 static int g_slice_type = I_SLICE;        /* selects the initialisation table (TEncSbac::resetEntropy uses the slice type) */
 static void cabac_init(Cabac *c, int qp)
@@ -217,16 +223,18 @@ static void cabac_init(Cabac *c, int qp)
     int mps = st >= 64;
     c->s[i] = (uint8_t)(((mps ? (st - 64) : (63 - st)) << 1) + mps);
   }
-  c->frac = 0;
+  c->frac = 0; c->be = NULL;
 }
 static inline void enc_bin(Cabac *c, int ctx, int bin)
 {
   uint8_t st = c->s[ctx];
+  if (c->be) be_bin(c->be, ctx, st, bin);
   c->frac += (uint64_t)ENTROPY_BITS[st ^ bin];
   c->s[ctx] = ((st & 1) == bin) ? NEXT_MPS[st] : NEXT_LPS[st];
 }
-static inline void enc_ep(Cabac *c, int n) { c->frac += (uint64_t)32768 * (uint64_t)n; }
-static inline void enc_trm(Cabac *c, int bin) { c->frac += (uint64_t)ENTROPY_BITS[126 ^ bin]; }
+static inline void enc_ep(Cabac *c, int n) { if (c->be) abort(); c->frac += (uint64_t)32768 * (uint64_t)n; }   /* estimator-only call sites */
+static inline void enc_epv(Cabac *c, uint32_t val, int n) { if (c->be) be_ep(c->be, val, n); c->frac += (uint64_t)32768 * (uint64_t)n; }  /* n bypass bins, first bin = MSB of val */
+static inline void enc_trm(Cabac *c, int bin) { if (c->be) be_trm(c->be, bin); c->frac += (uint64_t)ENTROPY_BITS[126 ^ bin]; }
 static inline void reset_bits(Cabac *c) { c->frac &= 32767; }          /* TEncBinCABAC::resetBits, TEncBinCoderCABAC.cpp:161 */
 static inline uint32_t num_bits(const Cabac *c) { return (uint32_t)(c->frac >> 15); }
 static inline int ebits(const Cabac *c, int ctx, int bin) { return ENTROPY_BITS[c->s[ctx] ^ bin]; }
@@ -957,8 +965,8 @@ static void code_coeff_nxn(Enc *e, Cabac *c, const TCoeff *coef, int n, int comp
     if (gx < GROUP_IDX[n - 1]) enc_bin(c, bxc + (k >> shift), 0);
     for (k = 0; k < gy; k++) enc_bin(c, byc + (k >> shift), 1);
     if (gy < GROUP_IDX[n - 1]) enc_bin(c, byc + (k >> shift), 0);
-    if (gx > 3) enc_ep(c, (gx - 2) >> 1);
-    if (gy > 3) enc_ep(c, (gy - 2) >> 1);
+    if (gx > 3) enc_epv(c, (uint32_t)(px - MIN_IN_GROUP[gx]), (gx - 2) >> 1);
+    if (gy > 3) enc_epv(c, (uint32_t)(py - MIN_IN_GROUP[gy]), (gy - 2) >> 1);
   }
   const int firstCtx = first_sig_ctx(n, scanType, chroma), sigOff = C_SIG + (chroma ? 28 : 0);
   const int lastScanSet = scanPosLast >> 4;
@@ -998,15 +1006,16 @@ static void code_coeff_nxn(Enc *e, Cabac *c, const TCoeff *coef, int n, int comp
       }
       if (c1 == 0 && firstC2 != -1) { const int sym = absCoeff[firstC2] > 2; enc_bin(c, C_ABS + ctxSet, sym); if (sym) escape = 1; }
       escape = escape || (numNonZero > 8);
-      if (signHidden) enc_ep(c, numNonZero - 1); else enc_ep(c, numNonZero);
+      if (signHidden) enc_epv(c, signs >> 1, numNonZero - 1); else enc_epv(c, signs, numNonZero);
       int firstCoeff2 = 1;
       if (escape)
         for (int idx = 0; idx < numNonZero; idx++) {
           const int baseLevel = (idx < 8) ? (2 + firstCoeff2) : 1;
           if (absCoeff[idx] >= baseLevel) {
             uint32_t sym = (uint32_t)(absCoeff[idx] - baseLevel);
-            if (sym < (3u << goRice)) enc_ep(c, (int)((sym >> goRice) + 1 + goRice));
-            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++)); enc_ep(c, (int)(3 + len + 1 - goRice + len)); }
+            if (sym < (3u << goRice)) { const uint32_t len = sym >> goRice; enc_epv(c, (1u << (len + 1)) - 2, (int)len + 1); enc_epv(c, sym & ((1u << goRice) - 1), (int)goRice); }
+            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++));
+                   enc_epv(c, (1u << (3 + len + 1 - goRice)) - 2, (int)(3 + len + 1 - goRice)); enc_epv(c, sym, (int)len); }
             if ((uint32_t)absCoeff[idx] > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
           }
           if (absCoeff[idx] >= 2) firstCoeff2 = 0;
@@ -1029,15 +1038,29 @@ static void code_intra_dir_luma(Enc *e, Cabac *c, int z, int multiple)
     enc_bin(c, C_INTRA_LUMA, predIdx[j] != -1);
   }
   for (int j = 0; j < partNum; j++) {
-    if (predIdx[j] != -1) enc_ep(c, predIdx[j] ? 2 : 1);
-    else enc_ep(c, 5);
+    if (predIdx[j] != -1) { if (predIdx[j]) enc_epv(c, 2u | (uint32_t)(predIdx[j] - 1), 2); else enc_epv(c, 0, 1); }
+    else {
+      int *p = preds[j], d = dir[j], t;
+      if (p[0] > p[1]) { t = p[0]; p[0] = p[1]; p[1] = t; }
+      if (p[0] > p[2]) { t = p[0]; p[0] = p[2]; p[2] = t; }
+      if (p[1] > p[2]) { t = p[1]; p[1] = p[2]; p[2] = t; }
+      for (int i = 2; i >= 0; i--) d = d > p[i] ? d - 1 : d;
+      enc_epv(c, (uint32_t)d, 5);
+    }
   }
 }
 /* TEncSbac::codeIntraDirChroma, TEncSbac.cpp:692-718 */
 static void code_intra_dir_chroma(Enc *e, Cabac *c, int z)
 {
   if (e->cm->dirC[z] == DM_CHROMA_IDX) enc_bin(c, C_CHROMA_PRED, 0);
-  else { enc_bin(c, C_CHROMA_PRED, 1); enc_ep(c, 2); }
+  else {
+    enc_bin(c, C_CHROMA_PRED, 1);
+    int list[4] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX}, idx = 0;       /* getAllowedChromaDir, TComDataCU.cpp:1486: the entry equal to the luma mode becomes 34 */
+    const int luma = e->cm->dirL[z];
+    for (int i = 0; i < 4; i++) if (list[i] == luma) list[i] = 34;
+    for (int i = 0; i < 4; i++) if (list[i] == e->cm->dirC[z]) { idx = i; break; }
+    enc_epv(c, (uint32_t)idx, 2);
+  }
 }
 /* TEncSbac::codeQtCbf, TEncSbac.cpp:911-960 (square TUs only) */
 static void code_qt_cbf(Enc *e, Cabac *c, const TU *t, int comp, int lowestLevel)
@@ -1814,6 +1837,7 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
 
 #include "hm_oracle_dbk.inc"
 #include "hm_oracle_sao.inc"
+#include "hm_oracle_bits.inc"
 
 int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus)
 { return compress_impl(cfg, org, rec, ctus, 0, NULL, NULL); }

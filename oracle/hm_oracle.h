@@ -10,6 +10,7 @@
  */
 #ifndef HM_ORACLE_H
 #define HM_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -91,6 +92,21 @@ int hmo_deblock(const hmo_cfg *cfg, int slice_type, const int32_t ref_poc[2][16]
  * sao_params (may be NULL) receives numCtus x 3 x 35 int32: modeIdc, typeIdc, typeAuxInfo, offset[32] as coded. ---- */
 int hmo_sao(const hmo_cfg *cfg, int cabac_init_type, int depth, double disabled_rate[3][8], const uint16_t *const org[3], uint16_t *const rec[3],
             int32_t *sao_params, int32_t enabled_out[3]);
+
+/* ---- bitstream pass (TEncSlice::encodeSlice, TEncSlice.cpp:910-1095): the CABAC-coded slice data of one picture from what
+ * compressSlice (ctus / ictus) and SAO (sao: numCtus x 3 x 35 int32 as hmo_sao writes them, or NULL) left.  cfg: width, height, bit_depth, wpp.
+ * out receives the substreams back to back (one per CTU row with wpp, else one), sub_sizes their byte counts; each substream ends with the
+ * terminating bin, the CABAC flush and the byte alignment, exactly the bytes TEncGOP concatenates behind the slice header (before emulation
+ * prevention).  next_cabac_init_type = what determineCabacInitIdx (TEncSbac.cpp:163) leaves in the PPS for the following pictures. ---- */
+typedef struct {
+  int slice_type;                    /* 2 = I, 1 = P, 0 = B */
+  int qp;
+  int cabac_init_type;               /* context table of a P / B slice (TEncSbac::resetEntropy :106-115) */
+  int num_ref_idx[2], mvd_l1_zero, max_merge_cand;
+  int sao_enabled[2];                /* slice_sao_luma_flag, slice_sao_chroma_flag */
+} hmo_bits_slice;
+int hmo_encode_slice(const hmo_cfg *cfg, const hmo_bits_slice *slice, const hmo_ctu *ctus, const hmo_ctu_inter *ictus, const int32_t *sao,
+                     uint8_t *out, size_t out_cap, uint32_t *sub_sizes, int *next_cabac_init_type, uint32_t *num_bins);
 
 /* ---- primitives, exported for the known-answer tests (TComRdCost.cpp / TComTrQuant.cpp) ---- */
 uint32_t hmo_sad(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int sub_shift, int bit_depth);

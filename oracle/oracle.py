@@ -179,3 +179,39 @@ def sao(org, rec, bit_depth, qp, lam, chroma_weight, cabac_init_type, depth, dis
     if rc != 0:
         raise RuntimeError(f"oracle sao failed rc={rc}")
     return out, params, en
+
+
+class BitsSlice(C.Structure):
+    _fields_ = [("slice_type", C.c_int), ("qp", C.c_int), ("cabac_init_type", C.c_int), ("num_ref_idx", C.c_int * 2),
+                ("mvd_l1_zero", C.c_int), ("max_merge_cand", C.c_int), ("sao_enabled", C.c_int * 2)]
+
+
+def encode_slice(width, height, bit_depth, wpp, slice_type, qp, ctus, ictus=None, cabac_init_type=None, num_ref_idx=(0, 0), mvd_l1_zero=0,
+                 max_merge_cand=5, sao=None, sao_enabled=(0, 0)):
+    """TEncSlice::encodeSlice: the CABAC-coded slice data of one picture.  ctus / ictus as compress*() return them; sao = int32 (numCtus, 3, 35)
+    as sao() returns it.  Returns (list of substream byte strings, next cabac_init_type, number of bins)."""
+    L = lib()
+    cfg = Cfg(width, height, bit_depth, int(qp), int(wpp), 0.0, 0.0)
+    s = BitsSlice()
+    s.slice_type, s.qp = int(slice_type), int(qp)
+    s.cabac_init_type = int(slice_type if cabac_init_type is None else cabac_init_type)
+    s.num_ref_idx[0], s.num_ref_idx[1] = int(num_ref_idx[0]), int(num_ref_idx[1])
+    s.mvd_l1_zero, s.max_merge_cand = int(mvd_l1_zero), int(max_merge_cand)
+    s.sao_enabled[0], s.sao_enabled[1] = int(sao_enabled[0]), int(sao_enabled[1])
+    c = np.ascontiguousarray(ctus)
+    assert c.dtype == CTU_DTYPE
+    ic = np.ascontiguousarray(ictus) if ictus is not None else None
+    sp = np.ascontiguousarray(sao, np.int32) if sao is not None else None
+    n_sub = (height + 63) // 64 if wpp else 1
+    cap = 4 * width * height + 4096
+    out = np.zeros(cap, np.uint8); sizes = np.zeros(n_sub, np.uint32)
+    nxt = C.c_int(-1); bins = C.c_uint32(0)
+    L.hmo_encode_slice.argtypes = [C.POINTER(Cfg), C.POINTER(BitsSlice), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+    rc = L.hmo_encode_slice(C.byref(cfg), C.byref(s), c.ctypes.data, ic.ctypes.data if ic is not None else None,
+                            sp.ctypes.data if sp is not None else None, out.ctypes.data, cap, sizes.ctypes.data, C.byref(nxt), C.byref(bins))
+    if rc != 0:
+        raise RuntimeError(f"oracle encode_slice failed rc={rc}")
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+    raw = out.tobytes()
+    return [raw[offs[k]:offs[k + 1]] for k in range(n_sub)], nxt.value, bins.value

@@ -221,6 +221,29 @@ extern "C" void __wrap__ZN9TEncSlice13compressSliceEP7TComPic(TEncSlice *self, T
   }
   putPlanes(f, pic->getPicYuvRec());
 }
+// 'B' : what TEncSlice::encodeSlice (TEncSlice.cpp:910) wrote for the slice, before the substreams are concatenated into the NAL unit
+//       (TEncGOP.cpp:1559-1583): i32 poc, u32 numSubstreams, per substream u32 numBytes + the bytes, then i32 encCABACTableIdx as
+//       determineCabacInitIdx left it for the following pictures (TEncSbac.cpp:163) and u32 numBinsCoded
+extern "C" void __real__ZN9TEncSlice11encodeSliceEP7TComPicP19TComOutputBitstreamRj(TEncSlice *self, TComPic *pic, TComOutputBitstream *subs, UInt &numBins);
+extern "C" void __wrap__ZN9TEncSlice11encodeSliceEP7TComPicP19TComOutputBitstreamRj(TEncSlice *self, TComPic *pic, TComOutputBitstream *subs, UInt &numBins)
+{
+  __real__ZN9TEncSlice11encodeSliceEP7TComPicP19TComOutputBitstreamRj(self, pic, subs, numBins);
+  if (!g_dump2) return;
+  FILE *f = g_dump2;
+  TComSlice *sl = pic->getSlice(self->getSliceIdx());
+  fputc('B', f);
+  int32_t poc = sl->getPOC(); fwrite(&poc, 4, 1, f);
+  const UInt n = (UInt)sl->getPPS()->getNumSubstreams();
+  put32(f, n);
+  for (UInt i = 0; i < n; i++)
+  {
+    const std::vector<uint8_t> &b = subs[i].getFIFO();
+    put32(f, (uint32_t)b.size());
+    if (!b.empty()) fwrite(&b[0], 1, b.size(), f);
+  }
+  int32_t idx = (int32_t)sl->getPPS()->getEncCABACTableIdx(); fwrite(&idx, 4, 1, f);
+  put32(f, numBins);
+}
 extern "C" void __real__ZN7TComPic14compressMotionEv(TComPic *self);
 extern "C" void __wrap__ZN7TComPic14compressMotionEv(TComPic *self)
 {

@@ -75,9 +75,9 @@ _S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "wei
            "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
 
 
-def load_ldp_case(name, records=None, sao=None):
+def load_ldp_case(name, records=None, sao=None, bits=None):
     """-> (cfg dict, list of 'S' records, {poc: 'F' record}) in the layout of tests/hmd2.py; `records` (a list) receives
-    every record in stream order, `sao` (a dict) the SAO decisions by POC"""
+    every record in stream order, `sao` (a dict) the SAO decisions by POC, `bits` (a dict) the encodeSlice output by POC"""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     cfg = {k: int(g[k]) for k in ("width", "height", "bit_depth", "frames", "seed")}
     cfg["wpp"] = int(g["wpp"]) if "wpp" in g else 0
@@ -87,6 +87,16 @@ def load_ldp_case(name, records=None, sao=None):
             r = {"tag": "A", "poc": int(g[f"r{i}_poc"]), "depth": int(g[f"r{i}_depth"]), "enabled": tuple(int(v) for v in g[f"r{i}_enabled"]), "sao": g[f"r{i}_sao"]}
             if sao is not None:
                 sao[r["poc"]] = r
+            if records is not None:
+                records.append(r)
+            continue
+        if chr(int(g[f"r{i}_tag"])) == "B":                      # slice data bytes of the picture (tests/hmd2.py 'B' record)
+            sizes, data = g[f"r{i}_sub_sizes"], g[f"r{i}_sub_bytes"].tobytes()
+            offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+            r = {"tag": "B", "poc": int(g[f"r{i}_poc"]), "substreams": [data[offs[k]:offs[k + 1]] for k in range(len(sizes))],
+                 "next_cabac_init_type": int(g[f"r{i}_next_cabac_init_type"]), "num_bins": int(g[f"r{i}_num_bins"])}
+            if bits is not None:
+                bits[r["poc"]] = r
             if records is not None:
                 records.append(r)
             continue

@@ -139,6 +139,11 @@ def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_ma
             out[f"r{i}_poc"] = np.array(r["poc"]); out[f"r{i}_depth"] = np.array(r["depth"])
             out[f"r{i}_enabled"] = np.array(r["enabled"]); out[f"r{i}_sao"] = r["sao"]
             continue
+        if r["tag"] == "B":
+            out[f"r{i}_poc"] = np.array(r["poc"]); out[f"r{i}_sub_sizes"] = np.array([len(b) for b in r["substreams"]], np.uint32)
+            out[f"r{i}_sub_bytes"] = np.frombuffer(b"".join(r["substreams"]), np.uint8).copy()
+            out[f"r{i}_next_cabac_init_type"] = np.array(r["next_cabac_init_type"]); out[f"r{i}_num_bins"] = np.array(r["num_bins"])
+            continue
         out[f"r{i}_num_ref_idx"] = np.array(r["num_ref_idx"]); out[f"r{i}_ref_poc"] = r["ref_poc"]; out[f"r{i}_ref_long_term"] = r["ref_long_term"]
         for c in range(3):
             out[f"r{i}_rec{c}"] = r["rec"][c]

@@ -1,6 +1,7 @@
 """Reader of the HMD2 record stream written by `oracle/_ref/hm_dump enc2` (oracle/ref_harness.cpp):
 'S' records = one slice as TEncSlice::compressSlice saw and left it, 'F' records = the finished picture
-as later pictures reference it (final reconstruction + compressed motion field)."""
+as later pictures reference it (final reconstruction + compressed motion field), 'A' records = the SAO decisions of the picture,
+'B' records = the substream bytes TEncSlice::encodeSlice wrote for the slice."""
 import struct
 
 import numpy as np
@@ -62,6 +63,14 @@ def parse(path, width, height):
             r["poc"], r["depth"], en0, en1, n = struct.unpack_from("<4iI", buf, off); off += 20
             r["enabled"] = (en0, en1)
             r["sao"] = np.frombuffer(buf, "<i4", n * 3 * 35, off).reshape(n, 3, 35).copy(); off += n * 3 * 35 * 4
+        elif tag == b"B":
+            r = {"tag": "B"}
+            r["poc"], n = struct.unpack_from("<iI", buf, off); off += 8
+            r["substreams"] = []
+            for _ in range(n):
+                nb, = struct.unpack_from("<I", buf, off); off += 4
+                r["substreams"].append(bytes(buf[off:off + nb])); off += nb
+            r["next_cabac_init_type"], r["num_bins"] = struct.unpack_from("<iI", buf, off); off += 8
         else:
             raise ValueError(f"bad record tag {tag!r} at {off - 1}")
         recs.append(r)
@@ -76,8 +85,8 @@ def write(path, recs):
     with open(path, "wb") as f:
         f.write(b"HMD2")
         for r in recs:
-            if r["tag"] == "A":
-                continue                                  # SAO decisions: not part of what the search replays
+            if r["tag"] in ("A", "B"):
+                continue                                  # SAO decisions, slice data bytes: not part of what the search replays
             f.write(r["tag"].encode())
             rec = b"".join(np.ascontiguousarray(p, "<u2").tobytes() for p in r["rec"])
             if r["tag"] == "S":

@@ -111,3 +111,33 @@ def test_oracle_sao_matches_reference(built, name):
             assert np.array_equal(out[c], finals[poc]["rec"][c]), f"{name} POC {poc}: finished picture plane {c}"
         n_new += int((a["sao"][:, :, 0] == 1).sum())
     assert n_new > 0, "the fixture never chose new offsets"
+
+
+def fixture_bits_args(cfg, r, sao_rec, with_sao):
+    """keyword arguments of oracle.encode_slice / Encoder.encode_slices for one 'S' record of an inter fixture"""
+    return dict(cabac_init_type=int(r["cabac_init_type"]), num_ref_idx=tuple(int(v) for v in r["num_ref_idx"]), mvd_l1_zero=int(r["mvd_l1_zero"]),
+                max_merge_cand=int(r["max_merge_cand"]), sao=sao_rec["sao"] if with_sao else None, sao_enabled=tuple(sao_rec["enabled"]) if with_sao else (0, 0))
+
+
+@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES + common.DBK_CASES)
+def test_oracle_bitstream_pass_matches_reference(built, name):
+    """TEncSlice::encodeSlice: from the reference's own CTU decisions and SAO parameters the oracle's arithmetic coder must write the same
+    substream bytes as the reference (I, P and B slices, 8 and 10 bit, one substream or one per CTU row, SAO syntax on and off), code the
+    same number of bins and leave the same context table choice for the next picture (determineCabacInitIdx)."""
+    import oracle
+    sd, bd = {}, {}
+    cfg, slices, _ = common.load_ldp_case(name, sao=sd, bits=bd)
+    with_sao = not name.startswith("dbk_")
+    total = 0
+    for r in slices:
+        poc, st = int(r["poc"]), int(r["slice_type"])
+        ctus, ictus = common.split_fixture_ctus(r["ctus"])
+        subs, nxt, bins = oracle.encode_slice(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], st, int(r["qp"]), ctus, ictus if st != 2 else None,
+                                              **fixture_bits_args(cfg, r, sd.get(poc), with_sao))
+        want = bd[poc]
+        assert len(subs) == len(want["substreams"])
+        for k, (g, w) in enumerate(zip(subs, want["substreams"])):
+            assert g == w, f"{name} POC {poc}: substream {k} differs ({len(g)} vs {len(w)} bytes)"
+        assert bins == want["num_bins"] and nxt == want["next_cabac_init_type"], f"{name} POC {poc}: bins {bins}/{want['num_bins']}, next table {nxt}/{want['next_cabac_init_type']}"
+        total += sum(len(s) for s in subs)
+    assert total > 500
