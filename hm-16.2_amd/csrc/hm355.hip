@@ -15,6 +15,7 @@
 #include "hm355_core.h"
 #include "hm355_dbk.h"
 #include "hm355_sao.h"
+#include "hm355_bits_kernel.h"
 #include "hm355_host_common.h"
 #include "../../include/hm355.h"
 
@@ -125,7 +126,9 @@ struct Slot {           // one picture resident in HBM
   FrameBuf fb;          // device pointers + slice parameters (host copy)
   InterMeta *imeta;     // motion arrays of the slot (allocated on first inter use; kept for the deblocking pass)
   Pel *saoSrc[3]; SaoStat *saoStat; SaoCand *saoCand; SaoBlk *saoCoded, *saoRecon;   // SAO working buffers (allocated on first use)
+  uint8_t *bitsRaw, *bitsPacked; uint32_t *bitsSizes; CabacW *bitsSync; uint32_t *bitsFlag; InterPic *bitsIp;   // bitstream pass (allocated on first use)
 };
+#define HM_BITS_CAP_PER_CTU 16384u   /* bytes reserved per CTU in the raw substream buffers: above the raw size of a 10-bit 4:2:0 CTU (7.7 KB) */
 struct hm355_ctx {
   hm355_seq_cfg cfg;
   Params hp;            // host copy of the kernel parameters
@@ -144,6 +147,7 @@ struct hm355_ctx {
   void *staging; size_t stagingBytes;
   DbkParams *dDbk;      // [max_batch] deblocking parameters of the pictures in the slots
   SaoParams *dSao;      // [max_batch] SAO parameters / results of the pictures in the slots
+  BitsParams *dBits;    // [max_batch] bitstream pass parameters / results
 };
 
 #define HM_CHECK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HM355_ERR_DEVICE; } } while (0)
@@ -171,7 +175,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
-  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL;
+  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL;
   c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
@@ -196,6 +200,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   for (int s = 0; s < cfg->max_batch; s++) {
     FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
     c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCand = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
+    c->slots[s].bitsRaw = c->slots[s].bitsPacked = NULL; c->slots[s].bitsSizes = NULL; c->slots[s].bitsSync = NULL; c->slots[s].bitsFlag = NULL; c->slots[s].bitsIp = NULL;
     for (int k = 0; k < 3; k++) {
       const size_t bytes = (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel);
       HM_CHECK(c, hipMalloc((void **)&fb.org[k], bytes)); HM_CHECK(c, hipMemset(fb.org[k], 0, bytes));
@@ -225,6 +230,8 @@ extern "C" void hm355_destroy(hm355_ctx *c)
     for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
     if (c->slots[s].imeta) hipFree(c->slots[s].imeta);
     for (int k = 0; k < 3; k++) if (c->slots[s].saoSrc[k]) hipFree(c->slots[s].saoSrc[k]);
+    { Slot &sl = c->slots[s]; if (sl.bitsRaw) hipFree(sl.bitsRaw); if (sl.bitsPacked) hipFree(sl.bitsPacked); if (sl.bitsSizes) hipFree(sl.bitsSizes);
+      if (sl.bitsSync) hipFree(sl.bitsSync); if (sl.bitsFlag) hipFree(sl.bitsFlag); if (sl.bitsIp) hipFree(sl.bitsIp); }
     if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCand) hipFree(c->slots[s].saoCand); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
     if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState); if (fb.done) hipFree(fb.done);
   }
@@ -232,6 +239,7 @@ extern "C" void hm355_destroy(hm355_ctx *c)
   if (c->staging) hipHostFree(c->staging);
   if (c->dDbk) hipFree(c->dDbk);
   if (c->dSao) hipFree(c->dSao);
+  if (c->dBits) hipFree(c->dBits);
   if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -662,6 +670,109 @@ extern "C" int hm355_deblock(hm355_ctx *c, const hm355_dbk_desc *desc, const hm3
     HM_CHECK(c, hipMemcpy2D(rec->plane[k], (size_t)w * 2, fb.rec[k], (size_t)P.stride[k] * sizeof(Pel), (size_t)w * 2, h, hipMemcpyDeviceToHost));
   }
   return HM355_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bitstream pass (TEncSlice::encodeSlice) on the pictures of the slots
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm355_num_substreams(const hm355_ctx *c) { return c ? (c->hp.wpp ? c->hp.hCtu : 1) : HM355_ERR_ARG; }
+
+extern "C" int hm355_encode_slices_run(hm355_ctx *c, int n, hm355_bits_desc *descs)
+{
+  if (!c || !descs || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp;
+  const int numSub = P.wpp ? P.hCtu : 1;
+  const size_t rawBytes = (size_t)c->numCtus * HM_BITS_CAP_PER_CTU;
+  std::vector<FrameBuf> fbs(n); std::vector<BitsParams> bps(n);
+  c->epoch++;
+  for (int f = 0; f < n; f++) {
+    hm355_bits_desc &d = descs[f];
+    if (d.slice_type < 0 || d.slice_type > 2 || d.qp < 0 || d.qp > 51 || !d.out || !d.sub_sizes) return fail(c, HM355_ERR_ARG, "bad bitstream pass parameters");
+    Slot &sl = c->slots[f];
+    if (d.slice_type != 2) {
+      if (!sl.imeta) return fail(c, HM355_ERR_ARG, "hm355_encode_slices_run: the slot holds no motion data (run hm355_compress_slices_inter first)");
+      if (d.cabac_init_type < 0 || d.cabac_init_type > 1 || d.num_ref_idx[0] < 1 || d.num_ref_idx[0] > 16 || d.num_ref_idx[1] < 0 || d.num_ref_idx[1] > 16 ||
+          d.max_merge_cand < 1 || d.max_merge_cand > 5) return fail(c, HM355_ERR_ARG, "bad inter slice header values");
+    }
+    if ((d.sao_enabled[0] || d.sao_enabled[1]) && !sl.saoCoded) return fail(c, HM355_ERR_ARG, "hm355_encode_slices_run: the slot holds no SAO parameters (run hm355_sao_run first)");
+    if (!sl.bitsRaw) HM_CHECK(c, hipMalloc((void **)&sl.bitsRaw, rawBytes));
+    if (!sl.bitsPacked) HM_CHECK(c, hipMalloc((void **)&sl.bitsPacked, rawBytes));
+    if (!sl.bitsSizes) HM_CHECK(c, hipMalloc((void **)&sl.bitsSizes, sizeof(uint32_t) * P.hCtu));
+    if (!sl.bitsSync) HM_CHECK(c, hipMalloc((void **)&sl.bitsSync, sizeof(CabacW) * P.hCtu));
+    if (!sl.bitsFlag) { HM_CHECK(c, hipMalloc((void **)&sl.bitsFlag, sizeof(uint32_t) * (P.hCtu + 1))); HM_CHECK(c, hipMemset(sl.bitsFlag, 0, sizeof(uint32_t) * (P.hCtu + 1))); }
+    fbs[f] = sl.fb; fbs[f].imeta = NULL; fbs[f].ip = NULL;
+    if (d.slice_type != 2) {
+      if (!sl.bitsIp) HM_CHECK(c, hipMalloc((void **)&sl.bitsIp, sizeof(InterPic)));
+      std::vector<InterPic> ipv(1); InterPic &ip = ipv[0];   // only the slice header values the PU syntax reads
+      memset(&ip, 0, sizeof(ip));
+      ip.sliceType = d.slice_type; ip.numRefIdx[0] = d.num_ref_idx[0]; ip.numRefIdx[1] = d.slice_type == 0 ? d.num_ref_idx[1] : 0;
+      ip.mvdL1Zero = d.mvd_l1_zero; ip.maxMergeCand = d.max_merge_cand; ip.cabacInitType = d.cabac_init_type;
+      HM_CHECK(c, hipMemcpy(sl.bitsIp, &ip, sizeof(InterPic), hipMemcpyHostToDevice));
+      fbs[f].imeta = sl.imeta; fbs[f].ip = sl.bitsIp;
+    }
+    BitsParams &bp = bps[f]; memset(&bp, 0, sizeof(bp));
+    bp.sliceType = d.slice_type; bp.qp = d.qp; bp.cabacInitType = d.cabac_init_type;
+    bp.saoEnabled[0] = d.sao_enabled[0]; bp.saoEnabled[1] = bp.saoEnabled[2] = d.sao_enabled[1];
+    bp.sao = (d.sao_enabled[0] || d.sao_enabled[1]) ? (const int32_t *)sl.saoCoded : NULL;
+    bp.raw = sl.bitsRaw; bp.capPerCtu = HM_BITS_CAP_PER_CTU; bp.packed = sl.bitsPacked; bp.subSizes = sl.bitsSizes;
+    bp.sync = sl.bitsSync; bp.syncFlag = sl.bitsFlag; bp.epoch = c->epoch; bp.nextInitType = d.slice_type;
+  }
+  if (!c->dBits) HM_CHECK(c, hipMalloc((void **)&c->dBits, sizeof(BitsParams) * c->slots.size()));
+  HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipMemcpyAsync(c->dBits, bps.data(), sizeof(BitsParams) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
+  const int total = numSub * n, grid = total < (int)c->wsCount ? total : (int)c->wsCount;
+  hipLaunchKernelGGL(hm355_bits_kernel, dim3(grid), dim3(64), 0, c->stream, c->dP, c->dBits, n);
+  hipLaunchKernelGGL(hm355_bits_pack_kernel, dim3(numSub, n), dim3(64), 0, c->stream, c->dP, c->dBits);
+  HM_CHECK(c, hipGetLastError());
+  HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->lastKernelMs = ms; c->lastLaunches = 2;
+  HM_CHECK(c, hipMemcpy(bps.data(), c->dBits, sizeof(BitsParams) * n, hipMemcpyDeviceToHost));
+  for (int f = 0; f < n; f++) {
+    hm355_bits_desc &d = descs[f]; Slot &sl = c->slots[f];
+    uint32_t abortWord = 0;
+    HM_CHECK(c, hipMemcpy(&abortWord, sl.bitsFlag + P.hCtu, 4, hipMemcpyDeviceToHost));
+    if (abortWord) { hipMemset(sl.bitsFlag + P.hCtu, 0, 4); return fail(c, HM355_ERR_DEVICE, "bitstream pass: a WPP hand-off wait was abandoned"); }
+    if (bps[f].overflow) return fail(c, HM355_ERR_DEVICE, "bitstream pass: a substream outgrew its buffer");
+    HM_CHECK(c, hipMemcpy(d.sub_sizes, sl.bitsSizes, sizeof(uint32_t) * numSub, hipMemcpyDeviceToHost));
+    size_t tot = 0; for (int k = 0; k < numSub; k++) tot += d.sub_sizes[k];
+    if (tot > d.out_cap) return fail(c, HM355_ERR_ARG, "hm355_encode_slices_run: out_cap too small");
+    if (tot) HM_CHECK(c, hipMemcpy(d.out, sl.bitsPacked, tot, hipMemcpyDeviceToHost));
+    d.next_cabac_init_type = bps[f].nextInitType; d.num_bins = bps[f].bins;
+  }
+  return HM355_OK;
+}
+
+// host buffers in: the CTU data of one slice goes to slot 0 first
+extern "C" int hm355_encode_slice(hm355_ctx *c, hm355_bits_desc *desc, const hm355_ctu_out *ctus, const hm355_ctu_inter_out *ictus, const int32_t *sao)
+{
+  if (!c || !desc || !ctus) return HM355_ERR_ARG;
+  if (desc->slice_type != 2 && !ictus) return fail(c, HM355_ERR_ARG, "hm355_encode_slice: inter slices need the motion data");
+  if ((desc->sao_enabled[0] || desc->sao_enabled[1]) && !sao) return fail(c, HM355_ERR_ARG, "hm355_encode_slice: SAO enabled without parameters");
+  Slot &sl = c->slots[0]; FrameBuf &fb = sl.fb;
+  std::vector<CtuMeta> meta(c->numCtus); std::vector<TCoeff> coef((size_t)c->numCtus * HM_COEF_CTU);
+  for (int a = 0; a < c->numCtus; a++) {
+    const hm355_ctu_out *o = ctus + a; CtuMeta *m = &meta[a];
+    memcpy(m->depth, o->depth, 256); memcpy(m->part, o->part_size, 256); memcpy(m->pred, o->pred_mode, 256);
+    memcpy(m->dirL, o->intra_dir_luma, 256); memcpy(m->dirC, o->intra_dir_chroma, 256); memcpy(m->tr, o->tr_idx, 256);
+    memcpy(m->cbf, o->cbf, 768); memcpy(m->ts, o->tskip, 768);
+    memcpy(&coef[(size_t)a * HM_COEF_CTU], o->coeff_y, 4096 * 4); memcpy(&coef[(size_t)a * HM_COEF_CTU + 4096], o->coeff_cb, 1024 * 4);
+    memcpy(&coef[(size_t)a * HM_COEF_CTU + 5120], o->coeff_cr, 1024 * 4);
+  }
+  HM_CHECK(c, hipMemcpy(fb.meta, meta.data(), sizeof(CtuMeta) * c->numCtus, hipMemcpyHostToDevice));
+  HM_CHECK(c, hipMemcpy(fb.coef, coef.data(), sizeof(TCoeff) * coef.size(), hipMemcpyHostToDevice));
+  if (desc->slice_type != 2) {
+    if (!sl.imeta) HM_CHECK(c, hipMalloc((void **)&sl.imeta, sizeof(InterMeta) * c->numCtus));
+    HM_CHECK(c, hipMemcpy(sl.imeta, ictus, sizeof(InterMeta) * c->numCtus, hipMemcpyHostToDevice));
+  }
+  if (sao) {
+    if (!sl.saoCoded) HM_CHECK(c, hipMalloc((void **)&sl.saoCoded, sizeof(SaoBlk) * c->numCtus));
+    HM_CHECK(c, hipMemcpy(sl.saoCoded, sao, sizeof(SaoBlk) * c->numCtus, hipMemcpyHostToDevice));
+  }
+  return hm355_encode_slices_run(c, 1, desc);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1418,17 +1418,23 @@ HM_DEV inline void enc_bin(const Shared *e, CabacR *r, int ctx, int bin)
   HM_LV_SET(r->st, ctx >> 2, (w & ~(0xff << sh)) | (ns << sh));
 }
 HM_DEV inline void enc_ep(CabacR *r, int n) { r->frac += (uint64_t)32768 * (uint64_t)n; }
+// n bypass bins carrying a value (first bin = MSB of val): the estimators only count them
+HM_DEV inline void enc_epv(Cabac *c, uint32_t val, int n) { (void)val; enc_ep(c, n); }
+HM_DEV inline void enc_epv(CabacR *r, uint32_t val, int n) { (void)val; enc_ep(r, n); }
+#include "hm355_bits.h"
+HM_DEV inline int hm_min_in_group(int g) { return g < 4 ? g : ((2 + (g & 1)) << ((g >> 1) - 1)); }    // g_uiMinInGroup, TComRom.cpp
 
 // TEncSbac::codeCoeffNxN, TEncSbac.cpp:1172-1525 (+codeLastSignificantXY :1106, xWriteCoefRemainExGolomb :337)
 // Wavefront form: the coefficients are staged into LDS in scan order lane-parallel (last significant position by
 // wave-max, coefficient-group flags by ballot); per coefficient group the 16 levels, their significance contexts
 // and the >0 / >1 / >2 masks are produced lane-parallel, and the bins are coded by the serial context chain on
 // register-resident data (CabacR).
-HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
+template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
 {
   HM_ENTRY(e); n = HM_UNI(n); comp = HM_UNI(comp); scanType = HM_UNI(scanType); tskipFlag = HM_UNI(tskipFlag); c = hm_uni_ptr(c); HM_ASSUME_LDS(c); coef = hm_uni_ptr(coef);
   const int chroma = comp != 0, log2n = hm_log2(n), wg = n >> 2;
-  CabacR r; cabr_load(r, c);
+  const bool real = EngOf<C>::REAL != 0;          // the arithmetic coder also needs the values of the bypass bins
+  typename EngOf<C>::R r; cabr_load(r, c);
   if (n == 4) enc_bin(e, &r, C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
   int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->u.rq.cgFlag;
@@ -1458,8 +1464,8 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
     if (gx < gmax) enc_bin(e, &r, bxc + (k >> shift), 0);
     for (k = 0; k < gy; k++) enc_bin(e, &r, byc + (k >> shift), 1);
     if (gy < gmax) enc_bin(e, &r, byc + (k >> shift), 0);
-    if (gx > 3) enc_ep(&r, (gx - 2) >> 1);
-    if (gy > 3) enc_ep(&r, (gy - 2) >> 1);
+    if (gx > 3) enc_epv(&r, (uint32_t)(px - hm_min_in_group(gx)), (gx - 2) >> 1);
+    if (gy > 3) enc_epv(&r, (uint32_t)(py - hm_min_in_group(gy)), (gy - 2) >> 1);
   }
   const int firstCtx = first_sig_ctx(n, scanType, chroma), sigOff = C_SIG + (chroma ? 28 : 0);
   const int lastScanSet = scanPosLast >> 4;
@@ -1475,10 +1481,11 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
     const int pattern = wg <= 1 ? 0 : sigRight + (sigLower << 1);
     const int top = isLastSet ? (scanPosLast & 15) : 15;            // highest coded position of this group
     HM_LV(int32_t, vCtx); HM_LV(int32_t, vAbs);
-    uint64_t nz = 0, g1 = 0, g2 = 0;
+    uint64_t nz = 0, g1 = 0, g2 = 0, ng = 0;
     HM_WAVE_FOR(k) {
       const int kk = k & 15, sp = subPos + kk;
       const int a = (kk <= top) ? hm_abs((int)lv[sp]) : 0;
+      if (real) HM_BALLOT(ng, k, kk <= top && lv[sp] < 0 && k < 16);
       HM_LVK(vAbs, k) = a;
       HM_LVK(vCtx, k) = sig_ctx_inc(pattern, firstCtx, sposArr[sp], log2n, chroma);
       HM_BALLOT(nz, k, a != 0 && k < 16); HM_BALLOT(g1, k, a > 1 && k < 16); HM_BALLOT(g2, k, a > 2 && k < 16);
@@ -1507,7 +1514,9 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
       }
       if (c1 == 0 && firstC2 != -1) { const int sym = (int)((g2 >> firstC2) & 1); enc_bin(e, &r, C_ABS + ctxSet, sym); if (sym) escape = 1; }
       escape = escape || (numNonZero > 8);
-      enc_ep(&r, signHidden ? numNonZero - 1 : numNonZero);
+      uint32_t signs = 0;                 // coeff_sign_flag of the non-zero levels, highest scan position first; the hidden one is the last
+      if (real) { for (uint64_t m = nz; m;) { const int p = 63 - __builtin_clzll(m); m &= ~(1ull << p); signs = (signs << 1) | (uint32_t)((ng >> p) & 1); } if (signHidden) signs >>= 1; }
+      enc_epv(&r, signs, signHidden ? numNonZero - 1 : numNonZero);
       if (escape) {
         int firstCoeff2 = 1; uint32_t goRice = 0; idx = 0;
         for (uint64_t m = nz; m; idx++) {
@@ -1516,8 +1525,11 @@ HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, Cabac *c, const TCoeff *coef, 
           const int baseLevel = (idx < 8) ? (2 + firstCoeff2) : 1;
           if (a >= baseLevel) {
             uint32_t sym = (uint32_t)(a - baseLevel);
-            if (sym < (3u << goRice)) enc_ep(&r, (int)((sym >> goRice) + 1 + goRice));
-            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++)); enc_ep(&r, (int)(3 + len + 1 - goRice + len)); }
+            // xWriteCoefRemainExGolomb :337: unary prefix + rice suffix, or the escape (prefix of 4+ ones, exp-golomb suffix)
+            if (sym < (3u << goRice)) { const uint32_t len = sym >> goRice; enc_epv(&r, (((1u << (len + 1)) - 2) << goRice) | (sym & ((1u << goRice) - 1)), (int)(len + 1 + goRice)); }
+            else { uint32_t len = goRice; sym -= (3u << goRice); while (sym >= (1u << len)) sym -= (1u << (len++));
+                   if (real) { enc_epv(&r, (1u << (3 + len + 1 - goRice)) - 2, (int)(3 + len + 1 - goRice)); enc_epv(&r, sym, (int)len); }
+                   else enc_epv(&r, 0, (int)(3 + len + 1 - goRice + len)); }
             if ((uint32_t)a > (3u << goRice)) goRice = goRice + 1 < 4 ? goRice + 1 : 4;
           }
           if (a >= 2) firstCoeff2 = 0;
@@ -1545,15 +1557,32 @@ template <class C> HM_DEV inline void code_intra_dir_luma(Shared *e, C *c, int z
     enc_bin(e, c, C_INTRA_LUMA, predIdx[j] != -1);
   }
   for (int j = 0; j < partNum; j++) {
-    if (predIdx[j] != -1) enc_ep(c, predIdx[j] ? 2 : 1);
-    else enc_ep(c, 5);
+    if (predIdx[j] != -1) { if (predIdx[j]) enc_epv(c, 2u | (uint32_t)(predIdx[j] - 1), 2); else enc_epv(c, 0, 1); }
+    else {
+      uint32_t rem = 0;                   // rem_intra_luma_pred_mode: the mode minus the number of smaller candidates
+      if (EngOf<C>::REAL) {
+        int p[3]; intra_dir_predictor(e, z + partOffset * j, p);
+        int d = m->dirL[z + partOffset * j];
+        rem = (uint32_t)(d - (d > p[0]) - (d > p[1]) - (d > p[2]));
+      }
+      enc_epv(c, rem, 5);
+    }
   }
 }
 // TEncSbac::codeIntraDirChroma, TEncSbac.cpp:692-718
 template <class C> HM_DEV inline void code_intra_dir_chroma(Shared *e, C *c, int z)
 {
   if ((&e->meta)->dirC[z] == DM_CHROMA_IDX) enc_bin(e, c, C_CHROMA_PRED, 0);
-  else { enc_bin(e, c, C_CHROMA_PRED, 1); enc_ep(c, 2); }
+  else {
+    enc_bin(e, c, C_CHROMA_PRED, 1);
+    uint32_t idx = 0;
+    if (EngOf<C>::REAL) { // position in getAllowedChromaDir's list (TComDataCU.cpp:1486): planar, vertical, horizontal, DC, the one equal to the luma mode replaced by 34
+      const int luma = (&e->meta)->dirL[z], dc = (&e->meta)->dirC[z];
+      const int list[4] = { PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX };
+      for (int i = 3; i >= 0; i--) if ((list[i] == luma ? 34 : list[i]) == dc) idx = (uint32_t)i;
+    }
+    enc_epv(c, idx, 2);
+  }
 }
 // TEncSbac::codeQtCbf, TEncSbac.cpp:911-960 (square TUs)
 template <class C> HM_DEV inline void code_qt_cbf(Shared *e, C *c, const TU *t, int comp, int lowestLevel)
@@ -2094,7 +2123,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
 // ------------------------------------------------------------------------------------------------
 // final syntax of a CU (TEncEntropy::xEncodeTransform, TEncEntropy.cpp:222-412)
 // ------------------------------------------------------------------------------------------------
-HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, Cabac *c, int cuZ, int cuDepth)
+template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, C *c, int cuZ, int cuDepth)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); c = hm_uni_ptr(c); HM_ASSUME_LDS(c); // CU-level syntax shared by xCheckRDCostIntra (TEncCu.cpp:1601-1626) and xEncodeCU (:1246-1288), I slice
   const CtuMeta *m = (&e->meta);
@@ -2304,7 +2333,7 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
 }
 
 // TEncCu::xEncodeCU, TEncCu.cpp:1185-1295: re-encode the decided CTU to advance the contexts
-HM_DEV HM_NOINLINE void encode_ctu(Shared *e, Cabac *c, int lastCtuOfSlice)
+template <class C> HM_DEV HM_NOINLINE void encode_ctu(Shared *e, C *c, int lastCtuOfSlice)
 {
   HM_ENTRY(e); lastCtuOfSlice = HM_UNI(lastCtuOfSlice); c = hm_uni_ptr(c); HM_ASSUME_LDS(c);
   const CtuMeta *m = (&e->meta);

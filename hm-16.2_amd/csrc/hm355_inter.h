@@ -969,46 +969,47 @@ template <class C> HM_DEV inline void code_skip_flag(Shared *e, C *c, int z)
   ca = nb_at(e, x4, y4, NB_ABOVE, z, &zz); ctx += ca >= 0 ? imeta_of(e, ca)->skip[zz] : 0;
   enc_bin(e, c, C_SKIP + ctx, e->im->skip[z] ? 1 : 0);
 }
-HM_DEV inline void code_merge_index(Shared *e, Cabac *c, int z)
+template <class C> HM_DEV inline void code_merge_index(Shared *e, C *c, int z)
 { // codeMergeIndex :555
   const int idx = e->im->mrgIdx[z], num = e->fb.ip->maxMergeCand;
   if (num > 1)
     for (int ui = 0; ui < num - 1; ui++) {
       const int sym = ui == idx ? 0 : 1;
-      if (ui == 0) enc_bin(e, c, C_MRG_IDX, sym); else enc_ep(c, 1);
+      if (ui == 0) enc_bin(e, c, C_MRG_IDX, sym); else enc_epv(c, (uint32_t)sym, 1);
       if (sym == 0) break;
     }
 }
-HM_DEV inline void code_part_size_inter(Shared *e, Cabac *c, int z, int depth)
+template <class C> HM_DEV inline void code_part_size_inter(Shared *e, C *c, int z, int depth)
 { // codePartSize :431-520, inter branch; AMP below the maximum depth
   const int size = e->meta.part[z], amp = depth < 3;
   switch (size) {
     case SIZE_2Nx2N: enc_bin(e, c, C_PART, 1); break;
     case SIZE_2NxN: case SIZE_2NxnU: case SIZE_2NxnD:
       enc_bin(e, c, C_PART, 0); enc_bin(e, c, C_PART + 1, 1);
-      if (amp) { if (size == SIZE_2NxN) enc_bin(e, c, C_PART + 3, 1); else { enc_bin(e, c, C_PART + 3, 0); enc_ep(c, 1); } }
+      if (amp) { if (size == SIZE_2NxN) enc_bin(e, c, C_PART + 3, 1); else { enc_bin(e, c, C_PART + 3, 0); enc_epv(c, size == SIZE_2NxnU ? 0 : 1, 1); } }
       break;
     case SIZE_Nx2N: case SIZE_nLx2N: case SIZE_nRx2N:
       enc_bin(e, c, C_PART, 0); enc_bin(e, c, C_PART + 1, 0);
-      if (amp) { if (size == SIZE_Nx2N) enc_bin(e, c, C_PART + 3, 1); else { enc_bin(e, c, C_PART + 3, 0); enc_ep(c, 1); } }
+      if (amp) { if (size == SIZE_Nx2N) enc_bin(e, c, C_PART + 3, 1); else { enc_bin(e, c, C_PART + 3, 0); enc_epv(c, size == SIZE_nLx2N ? 0 : 1, 1); } }
       break;
     default: break;
   }
 }
-HM_DEV inline void write_ep_ex_golomb(Cabac *c, uint32_t symbol, uint32_t count)
-{ // xWriteEpExGolomb :270-290: only the number of bypass bins matters to the estimator
-  uint32_t numBins = 0;
-  while (symbol >= (1u << count)) { numBins++; symbol -= 1u << count; count++; }
-  numBins++; numBins += count;
-  enc_ep(c, (int)numBins);
+template <class C> HM_DEV inline void write_ep_ex_golomb(C *c, uint32_t symbol, uint32_t count)
+{ // xWriteEpExGolomb :309-330: unary prefix, a zero, then the remainder in `count` bits
+  uint32_t numBins = 0, bins = 0;
+  while (symbol >= (1u << count)) { bins = 2 * bins + 1; numBins++; symbol -= 1u << count; count++; }
+  bins = 2 * bins; numBins++;
+  bins = (bins << count) | symbol; numBins += count;
+  enc_epv(c, bins, (int)numBins);
 }
-HM_DEV inline void code_inter_dir(Shared *e, Cabac *c, int z, int cuDepth)
+template <class C> HM_DEV inline void code_inter_dir(Shared *e, C *c, int z, int cuDepth)
 { // codeInterDir :723-740; getCtxInterDir = depth (TComDataCU.cpp:1662)
   const int dir = e->im->interDir[z] - 1;
   if (e->meta.part[z] == SIZE_2Nx2N || (64 >> cuDepth) != 8) enc_bin(e, c, C_INTER_DIR + cuDepth, dir == 2 ? 1 : 0);
   if (dir < 2) enc_bin(e, c, C_INTER_DIR + 4, dir);
 }
-HM_DEV inline void code_mvd(Shared *e, Cabac *c, int z, int list)
+template <class C> HM_DEV inline void code_mvd(Shared *e, C *c, int z, int list)
 { // codeMvd :757
   if (e->fb.ip->mvdL1Zero && list == 1 && e->im->interDir[z] == 3) return;
   const int hor = e->im->mvd[list][z].x, ver = e->im->mvd[list][z].y;
@@ -1016,10 +1017,10 @@ HM_DEV inline void code_mvd(Shared *e, Cabac *c, int z, int list)
   const uint32_t ha = (uint32_t)hm_abs(hor), va = (uint32_t)hm_abs(ver);
   if (hor != 0) enc_bin(e, c, C_MVD + 1, ha > 1);
   if (ver != 0) enc_bin(e, c, C_MVD + 1, va > 1);
-  if (hor != 0) { if (ha > 1) write_ep_ex_golomb(c, ha - 2, 1); enc_ep(c, 1); }
-  if (ver != 0) { if (va > 1) write_ep_ex_golomb(c, va - 2, 1); enc_ep(c, 1); }
+  if (hor != 0) { if (ha > 1) write_ep_ex_golomb(c, ha - 2, 1); enc_epv(c, hor < 0, 1); }
+  if (ver != 0) { if (va > 1) write_ep_ex_golomb(c, va - 2, 1); enc_epv(c, ver < 0, 1); }
 }
-HM_DEV inline void code_ref_idx(Shared *e, Cabac *c, int z, int list)
+template <class C> HM_DEV inline void code_ref_idx(Shared *e, C *c, int z, int list)
 { // codeRefFrmIdx :737
   int ref = e->im->refIdx[list][z];
   enc_bin(e, c, C_REF, ref == 0 ? 0 : 1);
@@ -1028,12 +1029,12 @@ HM_DEV inline void code_ref_idx(Shared *e, Cabac *c, int z, int list)
     ref--;
     for (int ui = 0; ui < num; ui++) {
       const int sym = ui == ref ? 0 : 1;
-      if (ui == 0) enc_bin(e, c, C_REF + 1, sym); else enc_ep(c, 1);
+      if (ui == 0) enc_bin(e, c, C_REF + 1, sym); else enc_epv(c, (uint32_t)sym, 1);
       if (sym == 0) break;
     }
   }
 }
-HM_DEV inline void code_pu_wise(Shared *e, Cabac *c, int cuZ, int cuDepth)
+template <class C> HM_DEV inline void code_pu_wise(Shared *e, C *c, int cuZ, int cuDepth)
 { // TEncEntropy::encodePUWise :477
   const InterMeta *m = e->im; const int partSize = e->meta.part[cuZ], np = num_parts_of(partSize);
   for (int p = 0; p < np; p++) {
@@ -1054,7 +1055,7 @@ HM_DEV inline void code_pu_wise(Shared *e, Cabac *c, int cuZ, int cuDepth)
 HM_DEV inline int qt_root_cbf(const CtuMeta *m, int z) { return (m->cbf[0][z] & 1) || (m->cbf[1][z] & 1) || (m->cbf[2][z] & 1); }
 
 // TEncEntropy::xEncodeTransform :222-412 for an inter CU (coefficients from the CTU arrays)
-HM_DEV inline void encode_transform_inter(Shared *e, Cabac *c, const TU *root)
+template <class C> HM_DEV inline void encode_transform_inter(Shared *e, C *c, const TU *root)
 {
   const CtuMeta *m = &e->meta;
   TuWalk &w = e->walkOuter; walk_begin(&w, root);
@@ -1091,7 +1092,7 @@ HM_DEV inline void encode_transform_inter(Shared *e, Cabac *c, const TU *root)
   }
 }
 // the whole inter CU: xAddSymbolBitsInter :5517 and xEncodeCU :1246-1290
-HM_DEV HM_NOINLINE void encode_cu_syntax_inter(Shared *e, Cabac *c, int cuZ, int cuDepth)
+template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax_inter(Shared *e, C *c, int cuZ, int cuDepth)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); c = hm_uni_ptr(c); HM_ASSUME_LDS(c);
   const CtuMeta *m = &e->meta; const InterMeta *im = e->im;

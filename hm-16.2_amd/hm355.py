@@ -70,8 +70,15 @@ class SaoDesc(C.Structure):
                 ("disabled_rate", (C.c_double * 8) * 3), ("enabled", C.c_int32 * 3), ("params", C.c_void_p)]
 
 
+class BitsDesc(C.Structure):
+    _fields_ = [("slice_type", C.c_int32), ("qp", C.c_int32), ("cabac_init_type", C.c_int32), ("num_ref_idx", C.c_int32 * 2), ("mvd_l1_zero", C.c_int32),
+                ("max_merge_cand", C.c_int32), ("sao_enabled", C.c_int32 * 2), ("out", C.c_void_p), ("out_cap", C.c_size_t), ("sub_sizes", C.c_void_p),
+                ("next_cabac_init_type", C.c_int32), ("num_bins", C.c_uint32)]
+
+
 EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
            "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_sao_run",
+           "hm355_num_substreams", "hm355_encode_slices_run", "hm355_encode_slice",
            "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
@@ -103,6 +110,9 @@ def load_library(path=LIB_PATH):
     lib.hm355_ref_release.argtypes = [C.c_void_p, C.c_void_p]
     lib.hm355_ref_release.restype = None
     lib.hm355_sao_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SaoDesc)]
+    lib.hm355_num_substreams.argtypes = [C.c_void_p]
+    lib.hm355_encode_slices_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(BitsDesc)]
+    lib.hm355_encode_slice.argtypes = [C.c_void_p, C.POINTER(BitsDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hm355_dist_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hm355_transform_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
@@ -306,6 +316,51 @@ class Encoder:
                     d["disabled_rate"][c][t] = arr[k].disabled_rate[c][t]
             out.append((tuple(int(v) for v in arr[k].enabled), params[k]))
         return out
+
+    def _bits_descs(self, descs):
+        n = len(descs)
+        nsub = self.lib.hm355_num_substreams(self.h_)
+        arr = (BitsDesc * n)()
+        cap = 4 * self.w * self.h + 4096
+        outs = [np.zeros(cap, np.uint8) for _ in range(n)]; sizes = [np.zeros(nsub, np.uint32) for _ in range(n)]
+        for k, d in enumerate(descs):
+            a = arr[k]
+            a.slice_type, a.qp = int(d["slice_type"]), int(d["qp"])
+            a.cabac_init_type = int(d.get("cabac_init_type", d["slice_type"]) if d.get("cabac_init_type") is not None else d["slice_type"])
+            nri = d.get("num_ref_idx", (0, 0))
+            a.num_ref_idx[0], a.num_ref_idx[1] = int(nri[0]), int(nri[1])
+            a.mvd_l1_zero, a.max_merge_cand = int(d.get("mvd_l1_zero", 0)), int(d.get("max_merge_cand", 5))
+            en = d.get("sao_enabled", (0, 0))
+            a.sao_enabled[0], a.sao_enabled[1] = int(en[0]), int(en[1])
+            a.out, a.out_cap, a.sub_sizes = outs[k].ctypes.data, cap, sizes[k].ctypes.data
+        return arr, outs, sizes
+
+    @staticmethod
+    def _bits_results(arr, outs, sizes):
+        res = []
+        for k in range(len(outs)):
+            offs = np.concatenate([[0], np.cumsum(sizes[k])]).astype(int)
+            raw = outs[k][:offs[-1]].tobytes()
+            res.append(([raw[offs[i]:offs[i + 1]] for i in range(len(sizes[k]))], int(arr[k].next_cabac_init_type), int(arr[k].num_bins)))
+        return res
+
+    def encode_slices_run(self, descs):
+        """hm355_encode_slices_run on slots 0..n-1 (search results, and SAO parameters when sao_enabled is set, resident).  descs: dicts with
+        slice_type, qp and, for P / B slices, cabac_init_type, num_ref_idx, mvd_l1_zero, max_merge_cand; sao_enabled (luma, chroma).
+        Returns [(substream byte strings, next cabac_init_type, number of bins)]."""
+        arr, outs, sizes = self._bits_descs(descs)
+        self._check(self.lib.hm355_encode_slices_run(self.h_, len(descs), arr), "hm355_encode_slices_run")
+        return self._bits_results(arr, outs, sizes)
+
+    def encode_slice(self, desc, ctus, ictus=None, sao=None):
+        """hm355_encode_slice: host buffers in (CTU data of one slice, optional motion data and SAO parameters (numCtus, 3, 35) int32)"""
+        arr, outs, sizes = self._bits_descs([desc])
+        c = np.ascontiguousarray(ctus); assert c.dtype == CTU_DTYPE and len(c) == self.num_ctus
+        ic = np.ascontiguousarray(ictus) if ictus is not None else None
+        sp = np.ascontiguousarray(sao, np.int32) if sao is not None else None
+        self._check(self.lib.hm355_encode_slice(self.h_, arr, c.ctypes.data, ic.ctypes.data if ic is not None else None,
+                                                sp.ctypes.data if sp is not None else None), "hm355_encode_slice")
+        return self._bits_results(arr, outs, sizes)[0]
 
     def deblock_run(self, descs):
         """hm355_deblock_run on slots 0..n-1 (device-resident); descs: list of (slice_type, qp, ref_poc).  Returns kernel ms."""

@@ -12,6 +12,7 @@
  */
 #ifndef HM355_H
 #define HM355_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -163,6 +164,28 @@ typedef struct {
   int32_t *params;                     /* out, may be NULL: numCtus x 3 x 35 int32 (modeIdc, typeIdc, typeAuxInfo, offset[32]) as coded */
 } hm355_sao_desc;
 int hm355_sao_run(hm355_ctx *ctx, int n, hm355_sao_desc *descs);
+
+/* ---- bitstream pass: TEncSlice::encodeSlice (TEncSlice.cpp:910-1095, called from TEncGOP.cpp:1559) on the pictures of slots 0..n-1 as
+ * the search (hm355_run / hm355_compress_slices_inter) and, when sao_enabled is set, hm355_sao_run left them: the CABAC-coded slice data,
+ * one substream per CTU row with WPP, else one.  Each substream ends with the terminating bin, the CABAC flush (TEncBinCABAC::finish)
+ * and the byte alignment -- exactly the bytes TEncGOP.cpp:1572-1583 concatenates behind the slice header, before emulation prevention;
+ * sub_sizes are the entry point sizes of the slice header (TEncSlice.cpp:1067-1071 adds the emulation count).  Slice header, parameter
+ * sets and NAL packing stay with the caller. ---- */
+typedef struct {
+  int32_t slice_type, qp;              /* 2 = I, 1 = P, 0 = B; slice QP */
+  int32_t cabac_init_type;             /* context table of a P / B slice (TEncSbac::resetEntropy :106-115); ignored for I */
+  int32_t num_ref_idx[2], mvd_l1_zero, max_merge_cand;   /* slice header values the PU syntax depends on (P / B) */
+  int32_t sao_enabled[2];              /* slice_sao_luma_flag, slice_sao_chroma_flag: both 0 = no SAO syntax (SPS SAO off, or switched off for the slice) */
+  uint8_t *out; size_t out_cap;        /* out: the substreams back to back */
+  uint32_t *sub_sizes;                 /* out: [hm355_num_substreams()] bytes of each substream */
+  int32_t next_cabac_init_type;        /* out: TEncSbac::determineCabacInitIdx (:163-222): the table the PPS carries for the following pictures */
+  uint32_t num_bins;                   /* out: bins coded (TEncBinCABAC::getBinsCoded) */
+} hm355_bits_desc;
+int hm355_num_substreams(const hm355_ctx *ctx);
+int hm355_encode_slices_run(hm355_ctx *ctx, int n, hm355_bits_desc *descs);
+/* host buffers in: the CTU data of one slice in the layout the search returns it (ictus NULL for an I slice), sao = numCtus x 3 x 35 int32 as
+ * hm355_sao_run returns them (NULL with sao_enabled 0).  Uses slot 0. */
+int hm355_encode_slice(hm355_ctx *ctx, hm355_bits_desc *desc, const hm355_ctu_out *ctus, const hm355_ctu_inter_out *ictus, const int32_t *sao);
 
 /* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
  * Upload / run / download are separate so that a caller can keep pictures resident. */

@@ -77,16 +77,28 @@ def parse(path, width, height):
     return recs
 
 
-def write(path, recs):
-    """the inverse of parse(): records (dicts as parse() returns them; missing S fields are written as 0) -> HMD2 stream"""
+def write(path, recs, bits=False):
+    """the inverse of parse(): records (dicts as parse() returns them; missing S fields are written as 0) -> HMD2 stream.
+    Without `bits` only the 'S' and 'F' records the search replays are written; with it also every 'B' record, preceded by the 'A'
+    record of the same picture (the SAO syntax is part of the slice data)."""
     def ref_lists(r):
         return struct.pack("<2i", *[int(v) for v in r["num_ref_idx"]]) + np.ascontiguousarray(r["ref_poc"], "<i4").tobytes() + \
             np.ascontiguousarray(r["ref_long_term"], "<i4").tobytes()
     with open(path, "wb") as f:
         f.write(b"HMD2")
         for r in recs:
-            if r["tag"] in ("A", "B"):
+            if r["tag"] == "A" or (r["tag"] == "B" and not bits):
                 continue                                  # SAO decisions, slice data bytes: not part of what the search replays
+            if r["tag"] == "B":
+                for a in recs:
+                    if a["tag"] == "A" and a["poc"] == r["poc"]:
+                        f.write(b"A" + struct.pack("<4iI", int(a["poc"]), int(a["depth"]), int(a["enabled"][0]), int(a["enabled"][1]), len(a["sao"])))
+                        f.write(np.ascontiguousarray(a["sao"], "<i4").tobytes())
+                f.write(b"B" + struct.pack("<iI", int(r["poc"]), len(r["substreams"])))
+                for sub in r["substreams"]:
+                    f.write(struct.pack("<I", len(sub)) + sub)
+                f.write(struct.pack("<iI", int(r["next_cabac_init_type"]), int(r["num_bins"])))
+                continue
             f.write(r["tag"].encode())
             rec = b"".join(np.ascontiguousarray(p, "<u2").tobytes() for p in r["rec"])
             if r["tag"] == "S":

@@ -2,8 +2,11 @@
 // (see hostsim.cpp), driven by an HMD2 record stream of the real reference (oracle/ref_harness.cpp, `hm_dump enc2`):
 // every P or B slice is re-run with the slice parameters and reference pictures of its record and compared in place.
 //   hostsim_inter <in.yuv> <dump2.bin> <w> <h> <bitdepth> [wpp]   exit code 0 = every inter slice bit-exact
+// 'B' records (with the 'A' record of the same picture in front, tests/hmd2.py write(bits=True)) also replay the bitstream pass
+// (hm355_bits_kernel.h) on the CTU data of the preceding 'S' record, I slices included, and compare the substream bytes.
 #define HM355_HOSTSIM 1
 #include "../../hm-16.2_amd/csrc/hm355_core.h"
+#include "../../hm-16.2_amd/csrc/hm355_bits_kernel.h"
 #include "../../hm-16.2_amd/csrc/hm355_host_common.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,8 +35,12 @@ int main(int argc, char **argv)
   P.ws = (WorkSpace *)calloc(1, sizeof(WorkSpace));
   std::map<int, FinalPic> finals;
   const size_t frameBytes = (size_t)w * h * 3 / 2 * (bd == 8 ? 1 : 2);
-  int bad = 0, nP = 0;
+  int bad = 0, nP = 0, nB = 0;
   static Shared sh;
+  // the last 'S' record (the reference's own CTU data) and 'A' record, for the bitstream pass
+  std::vector<CtuMeta> lastMeta; std::vector<InterMeta> lastIm; std::vector<TCoeff> lastCoef; InterPic lastIp; int lastPoc = -1, lastQp = 0;
+  std::vector<int32_t> lastSao; int saoPoc = -1, saoEn[2] = {0, 0};
+  memset(&lastIp, 0, sizeof(lastIp));
 #ifdef HM355_TRACE
   if (argc > 7) g_hm_trace = fopen(argv[7], "w");
 #endif
@@ -61,7 +68,43 @@ int main(int argc, char **argv)
       finals[f.poc] = f;
       continue;
     }
-    if (tag == 'A') { g_off += 16; const uint32_t n = rd<uint32_t>(); g_off += (size_t)n * 3 * 35 * 4; continue; }   // SAO decisions: not replayed here
+    if (tag == 'A') { // SAO decisions of a picture: part of its slice data
+      saoPoc = rd<int32_t>(); rd<int32_t>(); saoEn[0] = rd<int32_t>(); saoEn[1] = rd<int32_t>();
+      const uint32_t n = rd<uint32_t>(); lastSao.resize((size_t)n * 105); rdbuf(lastSao.data(), lastSao.size() * 4);
+      continue;
+    }
+    if (tag == 'B') { // TEncSlice::encodeSlice of the picture of the last 'S' record
+      const int poc = rd<int32_t>(); const uint32_t ns = rd<uint32_t>();
+      std::vector<std::vector<uint8_t> > want(ns);
+      for (uint32_t k = 0; k < ns; k++) { const uint32_t nb = rd<uint32_t>(); want[k].resize(nb); rdbuf(want[k].data(), nb); }
+      const int wantNext = rd<int32_t>(); const uint32_t wantBins = rd<uint32_t>();
+      if (poc != lastPoc) { fprintf(stderr, "B record of POC %d without its S record\n", poc); return 1; }
+      nB++;
+      FrameBuf fb; memset(&fb, 0, sizeof(fb));
+      fb.meta = lastMeta.data(); fb.coef = lastCoef.data();
+      if (lastIp.sliceType != 2) { fb.imeta = lastIm.data(); fb.ip = &lastIp; }
+      P.frames = &fb;
+      const uint32_t cap = 16384;
+      std::vector<uint8_t> raw((size_t)nctu * cap); std::vector<uint32_t> sizes(P.hCtu); std::vector<CabacW> sync(P.hCtu); std::vector<uint32_t> flags(P.hCtu + 1);
+      BitsParams bp; memset(&bp, 0, sizeof(bp));
+      bp.sliceType = lastIp.sliceType; bp.qp = lastQp; bp.cabacInitType = lastIp.cabacInitType;
+      const int en = saoPoc == poc;
+      bp.saoEnabled[0] = en ? saoEn[0] : 0; bp.saoEnabled[1] = bp.saoEnabled[2] = en ? saoEn[1] : 0;
+      bp.sao = (bp.saoEnabled[0] || bp.saoEnabled[1]) ? lastSao.data() : NULL;
+      bp.raw = raw.data(); bp.capPerCtu = cap; bp.subSizes = sizes.data(); bp.sync = sync.data(); bp.syncFlag = flags.data(); bp.epoch = 1;
+      static CabacW cw;
+      const int numSub = P.wpp ? P.hCtu : 1;
+      int bbad = (uint32_t)numSub != ns;
+      for (int k = 0; k < numSub && !bbad; k++) {
+        bits_encode_substream(&sh, &cw, &P, 0, &bp, k, 0);
+        const uint8_t *got = raw.data() + (size_t)(P.wpp ? k * P.wCtu : 0) * cap;
+        if (sizes[k] != want[k].size() || memcmp(got, want[k].data(), sizes[k])) { bbad = 1; printf("POC %d substream %d: %u bytes, want %zu\n", poc, k, sizes[k], want[k].size()); }
+      }
+      if (!bbad && (bp.bins != wantBins || bp.nextInitType != wantNext)) { bbad = 1; printf("POC %d: bins %u/%u next table %d/%d\n", poc, bp.bins, wantBins, bp.nextInitType, wantNext); }
+      printf("POC %d bitstream: %s\n", poc, bbad ? "MISMATCH" : "ok");
+      bad += bbad;
+      continue;
+    }
     if (tag != 'S') { fprintf(stderr, "bad tag at %zu\n", g_off - 1); return 1; }
     const int poc = rd<int32_t>(), sliceType = rd<int32_t>(), qp = rd<int32_t>(); rd<int32_t>(); rd<int32_t>();
     const double lambda = rd<double>(); rd<double>(); const double wcb = rd<double>(); rd<double>();
@@ -81,6 +124,9 @@ int main(int argc, char **argv)
     }
     std::vector<uint16_t> wantRec[3];
     for (int c = 0; c < 3; c++) { wantRec[c].resize((size_t)(w >> (c ? 1 : 0)) * (h >> (c ? 1 : 0))); rdbuf(wantRec[c].data(), wantRec[c].size() * 2); }
+    lastMeta = wantMeta; lastIm = wantIm; lastCoef = wantCoef; lastPoc = poc; lastQp = qp;
+    memset(&lastIp, 0, sizeof(lastIp));
+    lastIp.sliceType = sliceType; lastIp.numRefIdx[0] = numRef[0]; lastIp.numRefIdx[1] = numRef[1]; lastIp.mvdL1Zero = misc[3]; lastIp.maxMergeCand = misc[4]; lastIp.cabacInitType = misc[6];
     if (sliceType != HM_P_SLICE && sliceType != HM_B_SLICE) continue;
     nP++;
     FrameBuf fb; memset(&fb, 0, sizeof(fb));
@@ -128,6 +174,6 @@ int main(int argc, char **argv)
     printf("POC %d: %s\n", poc, slcBad ? "MISMATCH" : "ok");
     bad += slcBad;
   }
-  printf("%d P slices, %s\n", nP, bad ? "MISMATCH" : "all bit-exact");
+  printf("%d P slices, %d bitstream passes, %s\n", nP, nB, bad ? "MISMATCH" : "all bit-exact");
   return bad ? 1 : 0;
 }

@@ -39,6 +39,11 @@ def test_hip_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, qp, wpp, seed):
     common.assert_ctus_equal(got_ctus, want_ctus, f"{w}x{h}")
     for k in range(3):
         assert np.array_equal(got_rec[k], want_rec[k])
+    # bitstream pass on the slot the search just filled, against the oracle's arithmetic coder on the same CTU data
+    (subs, nxt, bins), = enc.encode_slices_run([dict(slice_type=2, qp=qp)])
+    want_subs, want_nxt, want_bins = oracle.encode_slice(w, h, bd, wpp, 2, qp, want_ctus)
+    assert subs == want_subs and nxt == want_nxt and bins == want_bins
+    assert len(subs) == ((h + 63) // 64 if wpp else 1) and all(len(x) > 0 for x in subs)
     enc.close()
 
 
@@ -193,8 +198,8 @@ def test_hip_closed_loop_on_device_matches_reference(hm, name):
     reference (border extension + compressMotion on the device) -> next picture's search.  Clips the reference ran with SAO off compare
     the deblocked picture; clips with the default loop filters also run hm355_sao_run and compare the finished picture, so the whole
     per-picture pipeline of the reference's default configuration runs on the device."""
-    saod = {}
-    cfg, slices, finals = common.load_ldp_case(name, sao=saod)
+    saod, bitd = {}, {}
+    cfg, slices, finals = common.load_ldp_case(name, sao=saod, bits=bitd)
     with_sao = not name.startswith("dbk_")
     rate = np.zeros((3, 8), np.float64)
     enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=1)
@@ -216,15 +221,56 @@ def test_hip_closed_loop_on_device_matches_reference(hm, name):
         for c in range(3):
             assert np.array_equal(rec[c], r["rec"][c]), f"{name} POC {poc}: pre-deblocking reconstruction plane {c}"
         enc.deblock_run([(st, int(r["qp"]), r["ref_poc"])])
+        en = (0, 0)
         if with_sao:
-            enc.sao_run([dict(qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), depth=saod[poc]["depth"], disabled_rate=rate,
-                              chroma_weight=float(r["weight_cb"]), **{"lambda": float(r["lambda"])})])
+            (en3, _), = enc.sao_run([dict(qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), depth=saod[poc]["depth"], disabled_rate=rate,
+                                          chroma_weight=float(r["weight_cb"]), **{"lambda": float(r["lambda"])})])
+            en = (en3[0], en3[1])
+        # the slice data of the picture from what the search and SAO left on the device (TEncGOP.cpp:1559 runs encodeSlice at this point)
+        (subs, nxt, bins), = enc.encode_slices_run([dict(slice_type=st, qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), num_ref_idx=r["num_ref_idx"],
+                                                         mvd_l1_zero=int(r["mvd_l1_zero"]), max_merge_cand=int(r["max_merge_cand"]), sao_enabled=en)])
+        assert subs == bitd[poc]["substreams"], f"{name} POC {poc}: slice data bytes differ"
+        assert (nxt, bins) == (bitd[poc]["next_cabac_init_type"], bitd[poc]["num_bins"]), f"{name} POC {poc}: next context table / bin count"
         dbk, _, _ = enc.download(0, want_ctus=False)
         for c in range(3):
             assert np.array_equal(dbk[c], finals[poc]["rec"][c]), f"{name} POC {poc}: finished picture plane {c}"
         dev_refs[poc] = enc.ref_from_slot(0, poc, st != 2, r["num_ref_idx"], r["ref_poc"], r["ref_long_term"])
     for ref in dev_refs.values():
         enc.ref_release(ref)
+    enc.close()
+
+
+@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES + common.DBK_CASES)
+def test_hip_bitstream_pass_matches_reference(hm, name):
+    """hm355_encode_slice (host buffers in) on the reference's own CTU decisions and SAO parameters: the substream bytes, the bin count and
+    the context table choice for the next picture must equal what the reference's TEncSlice::encodeSlice produced (I, P and B slices,
+    8 and 10 bit, one substream or one per CTU row, with and without SAO syntax)."""
+    sd, bd = {}, {}
+    cfg, slices, _ = common.load_ldp_case(name, sao=sd, bits=bd)
+    with_sao = not name.startswith("dbk_")
+    enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=1)
+    for r in slices:
+        poc, st = int(r["poc"]), int(r["slice_type"])
+        ctus, ictus = common.split_fixture_ctus(r["ctus"])
+        a = sd.get(poc)
+        desc = dict(slice_type=st, qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), num_ref_idx=r["num_ref_idx"], mvd_l1_zero=int(r["mvd_l1_zero"]),
+                    max_merge_cand=int(r["max_merge_cand"]), sao_enabled=tuple(a["enabled"]) if with_sao else (0, 0))
+        subs, nxt, bins = enc.encode_slice(desc, ctus, ictus if st != 2 else None, a["sao"] if with_sao else None)
+        want = bd[poc]
+        for k, (g, w) in enumerate(zip(subs, want["substreams"])):
+            assert g == w, f"{name} POC {poc}: substream {k} differs ({len(g)} vs {len(w)} bytes)"
+        assert len(subs) == len(want["substreams"]) and (nxt, bins) == (want["next_cabac_init_type"], want["num_bins"]), f"{name} POC {poc}"
+    enc.close()
+
+
+def test_hip_bitstream_pass_rejects_bad_parameters(hm):
+    enc = hm.Encoder(128, 64, 8, 0, max_batch=1)
+    with pytest.raises(RuntimeError):
+        enc.encode_slices_run([dict(slice_type=1, qp=30, cabac_init_type=1, num_ref_idx=(1, 0))])       # no motion data in the slot
+    with pytest.raises(RuntimeError):
+        enc.encode_slices_run([dict(slice_type=2, qp=30, sao_enabled=(1, 1))])                           # no SAO parameters in the slot
+    with pytest.raises(RuntimeError):
+        enc.encode_slices_run([dict(slice_type=2, qp=77)])
     enc.close()
 
 
@@ -284,7 +330,13 @@ def test_full_size_4k_wpp_properties(built, hm):
     planes = synth.frame(w, h, bd, 0, 1234)
     enc = hm.Encoder(w, h, bd, 1, max_batch=2)
     (rec0, ctus0, st0), (rec1, ctus1, st1) = enc.compress([planes, planes], qp)
+    # (4) the bitstream pass of the full-size picture (34 substreams per picture, both slots in one launch) equals the oracle's
+    # arithmetic coder on the same CTU data byte for byte
+    (subs0, nxt0, bins0), (subs1, nxt1, bins1) = enc.encode_slices_run([dict(slice_type=2, qp=qp), dict(slice_type=2, qp=qp)])
     enc.close()
+    want_subs, want_nxt, want_bins = oracle.encode_slice(w, h, bd, 1, 2, qp, ctus0)
+    assert subs0 == want_subs and subs1 == want_subs and (nxt0, bins0) == (want_nxt, want_bins) and (nxt1, bins1) == (want_nxt, want_bins)
+    assert len(subs0) == 34
     common.assert_ctus_equal(ctus0, ctus1, "slot 0 vs slot 1")
     for k in range(3):
         assert np.array_equal(rec0[k], rec1[k])

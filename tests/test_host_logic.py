@@ -103,14 +103,15 @@ def test_hostsim_of_kernel_source_matches_reference_fixture(tmp_path):
 @pytest.mark.parametrize("name", common.LDP_CASES[1:] + common.B_CASES)
 def test_hostsim_of_kernel_source_matches_reference_p_slices(tmp_path, name):
     """The P-slice part of the kernel source (hm355_inter.h / hm355_inter_cu.h) compiled for the host with one lane, forwards and
-    with every lane-parallel loop reversed: self-checking replay of the reference's HMD2 record stream (rebuilt from the fixture)."""
+    with every lane-parallel loop reversed: self-checking replay of the reference's HMD2 record stream (rebuilt from the fixture),
+    the search of every inter slice and the bitstream pass of every picture."""
     import synth
     import hmd2
     recs = []
     cfg, _, _ = common.load_ldp_case(name, recs)
     yuv, dump = tmp_path / "in.yuv", tmp_path / "dump2.bin"
     synth.write_yuv(str(yuv), cfg["width"], cfg["height"], cfg["bit_depth"], cfg["frames"], cfg["seed"])
-    hmd2.write(str(dump), recs)
+    hmd2.write(str(dump), recs, bits=True)
     for flag, exe in (("", "hostsim_inter"), ("-DHM355_HOSTSIM_REVERSE", "hostsim_inter_rev")):
         out = tmp_path / exe
         cmd = ["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-w"] + ([flag] if flag else []) + ["-o", str(out), os.path.join(ROOT, "tests", "hostsim", "hostsim_inter.cpp")]
@@ -118,3 +119,4 @@ def test_hostsim_of_kernel_source_matches_reference_p_slices(tmp_path, name):
         r = subprocess.run([str(out), str(yuv), str(dump), str(cfg["width"]), str(cfg["height"]), str(cfg["bit_depth"]), str(cfg["wpp"])],
                            capture_output=True, text=True)
         assert r.returncode == 0 and "all bit-exact" in r.stdout, r.stdout[-2000:]
+        assert r.stdout.count("bitstream: ok") == cfg["frames"], r.stdout[-2000:]     # the bitstream pass (hm355_bits_kernel.h) of every picture, I slice included
