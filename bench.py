@@ -298,9 +298,67 @@ def run_dbk(args, torch):
     enc.close()
 
 
+def run_bits(args, torch):
+    """Secondary workload: the bitstream pass (hm355_encode_slices_run) over `--frames` 3840x2160 10-bit I pictures whose search
+    results and SAO parameters are resident in their slots (search, deblocking and SAO run once, untimed).  A step = the CABAC-coded slice
+    data of every picture of the batch: 34 substreams per picture (WPP), one wavefront per substream, plus the packing launch.
+    The arithmetic coder is a serial dependency chain per substream, so the step is bounded by the longest CTU row, not by HBM."""
+    import hm355
+    import synth
+    w, h, bd, qp, F = args.width, args.height, 10, args.qp, args.frames
+    enc = hm355.Encoder(w, h, bd, 1, F)
+    distinct = [synth.frame(w, h, bd, f, 1234) for f in range(min(4, F))]
+    for i in range(F):
+        enc.upload(i, distinct[i % len(distinct)])
+    lam, cw = hm355.intra_lambda(qp)
+    enc.run(F, qp)
+    enc.deblock_run([(2, qp, None)] * F)
+    sao = enc.sao_run([dict(qp=qp, cabac_init_type=2, depth=0, disabled_rate=np.zeros((3, 8)), chroma_weight=cw, **{"lambda": lam}) for _ in range(F)])
+    descs = [dict(slice_type=2, qp=qp, sao_enabled=(sao[i][0][0], sao[i][0][1])) for i in range(F)]
+    ms_total, wall_total, out_bytes, bins = 0.0, 0.0, 0, 0
+    k, l = hm355.C.c_double(), hm355.C.c_int()
+    for it in range(args.warmup + args.steps):
+        t0 = time.time()
+        res = enc.encode_slices_run(descs)
+        dt = time.time() - t0
+        enc.lib.hm355_last_run_info(enc.h_, hm355.C.byref(k), hm355.C.byref(l))
+        if it >= args.warmup:
+            ms_total += k.value; wall_total += dt
+            out_bytes = sum(sum(len(x) for x in r[0]) for r in res); bins = sum(r[2] for r in res)
+    n = enc.num_ctus * F * args.steps
+    per_ctu = 3072 + 6144 * 4                            # decision arrays + coefficients of a CTU, read once
+    alg = (per_ctu * enc.num_ctus * F + 2 * out_bytes) * args.steps      # + the slice data written raw and once more packed
+    ach = alg / (ms_total * 1e-3) / 1e9
+    line = {"metric": "CTUs/sec (bitstream pass, encodeSlice) at 4K main10; byte-exact slice data vs HM", "value": n / (ms_total * 1e-3), "unit": "CTU/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_total / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"TEncSlice::encodeSlice on {F} I pictures {w}x{h} 10-bit (QP {qp}, WPP, SAO syntax) resident in HBM with their CU / TU data, coefficients and SAO parameters",
+                       "frames_per_gpu": F, "pictures_per_s": F * args.steps / (ms_total * 1e-3), "slice_data_bytes_per_step": out_bytes, "bins_per_step": bins,
+                       "mbins_per_s": bins * args.steps / (ms_total * 1e-3) / 1e6, "ms_per_step_with_readback": 1e3 * wall_total / args.steps},
+            "roofline": {"bound": "hbm", "kernel": "hm355_bits_kernel + hm355_bits_pack_kernel (2 launches per step)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "note": (f"algorithmic bytes = {per_ctu} B per CTU read (decision arrays + coefficients) + the slice data written twice; the coder is a serial "
+                                  "chain per substream (one wavefront, wave-uniform), so the step time is the longest CTU row of the batch, far from the HBM bound")}}
+    if not args.no_cpu_baseline:
+        import oracle
+        _, ctus1, _ = enc.download(0)
+        oc = np.zeros(len(ctus1), oracle.CTU_DTYPE)
+        for f in oc.dtype.names:
+            oc[f] = ctus1[f]
+        t0 = time.time()
+        want = oracle.encode_slice(w, h, bd, 1, 2, qp, oc, sao=sao[0][1], sao_enabled=descs[0]["sao_enabled"])
+        dt = time.time() - t0
+        line["parity_checked_in_run"] = bool(want[0] == res[0][0] and want[2] == res[0][2])
+        line["cpu_baseline"] = {"value": enc.num_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
+                                "sample": f"one {w}x{h} picture ({enc.num_ctus} CTUs, {sum(len(x) for x in want[0])} bytes) through oracle/hm_oracle_bits.inc"}
+        line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+    enc.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao"], help="intra4k = the BASELINE.json metric (default)")
+    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao", "bits"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
@@ -321,6 +379,8 @@ def main():
     if args.workload != "intra4k":
         if world > 1:
             raise SystemExit("--workload ldp_p / ra_b / dbk are single-GPU measurements")
+        if args.workload == "bits":
+            return run_bits(args, torch)
         return run_dbk(args, torch) if args.workload in ("dbk", "sao") else run_inter(args, torch)
     dist = None
     if world > 1:

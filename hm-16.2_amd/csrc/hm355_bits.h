@@ -14,11 +14,12 @@ struct CabacW {
   uint32_t held; int32_t numHeld;     // TComOutputBitstream::m_held_bits
   uint8_t *out; uint32_t len, cap;    // byte FIFO of the substream (HBM)
   uint32_t bins;                      // TEncBinCABAC::m_uiBinsCoded
+  int32_t tabLps[64], tabNlps[32];    // LDS copies of the LPS range table (4 bytes per state) and of the LPS transitions (4 states per word)
 };
 enum { C_SAO_MERGE = HM_NUM_CTX, C_SAO_TYPE = HM_NUM_CTX + 1 };
 static_assert(HM_NUM_CTX + 2 <= 184, "SAO contexts live in the padding of the context array");
 
-HM_CONST uint8_t HM_LPS_TABLE[64][4] = {   // TComCABACTables::sm_aucLPSTable (H.265 table 9-46)
+HM_CONST uint8_t HM_LPS_TABLE[64][4] __attribute__((aligned(4))) = {   // TComCABACTables::sm_aucLPSTable (H.265 table 9-46)
   {128,176,208,240},{128,167,197,227},{128,158,187,216},{123,150,178,205},{116,142,169,195},{111,135,160,185},{105,128,152,175},{100,122,144,166},
   { 95,116,137,158},{ 90,110,130,150},{ 85,104,123,142},{ 81, 99,117,135},{ 77, 94,111,128},{ 73, 89,105,122},{ 69, 85,100,116},{ 66, 80, 95,110},
   { 62, 76, 90,104},{ 59, 72, 86, 99},{ 56, 69, 81, 94},{ 53, 65, 77, 89},{ 51, 62, 73, 85},{ 48, 59, 69, 80},{ 46, 56, 66, 76},{ 43, 53, 63, 72},
@@ -45,6 +46,8 @@ HM_DEV inline void cabw_put_bits(CabacW *w, uint32_t bits, int n)
   w->held = held; w->numHeld = nh;
 }
 // ---- arithmetic coder ----
+HM_DEV inline void cabw_load_tables(CabacW *w)
+{ HM_PAR_FOR(i, 64) { w->tabLps[i] = ((const int32_t *)HM_LPS_TABLE)[i]; if (i < 32) w->tabNlps[i] = ((const int32_t *)HM_NEXT_LPS)[i]; } }
 HM_DEV inline void cabw_start(CabacW *w)
 { w->low = 0; w->range = 510; w->bitsLeft = 23; w->numBufferedBytes = 0; w->bufferedByte = 0xff; }       // TEncBinCABAC::start :69
 HM_DEV inline void cabw_write_out(CabacW *w)
@@ -112,12 +115,70 @@ HM_DEV inline void cabw_finish(CabacW *w)
   cabw_put_bits(w, w->low >> 8, 24 - w->bitsLeft);
 }
 
+// Register-resident form for code_coeff_nxn (the bulk of the bins): context states, their "coded" flags, the LPS range table and the
+// LPS transitions live in lane registers as in CabacR (4 bytes per lane, read with v_readlane), low / range / bitsLeft / the bin count
+// in scalars; only the byte output (once per 8 bits) goes through the LDS copy.
+struct CabacWR { CabacW *w; HM_LV(int32_t, st); HM_LV(int32_t, us); HM_LV(int32_t, lpsRow); HM_LV(int32_t, nlps); uint32_t low, range; int32_t bitsLeft; uint32_t bins; };
+HM_DEV inline void cabr_load(CabacWR &r, CabacW *c)
+{
+  r.w = c;
+  HM_WAVE_FOR(k) {
+    HM_LVK(r.st, k) = k < 46 ? ((const int32_t *)c->s)[k] : 0; HM_LVK(r.us, k) = k < 46 ? ((const int32_t *)c->used)[k] : 0;
+    HM_LVK(r.lpsRow, k) = c->tabLps[k];
+    HM_LVK(r.nlps, k) = c->tabNlps[k & 31];
+  }
+  r.low = c->low; r.range = c->range; r.bitsLeft = c->bitsLeft; r.bins = c->bins;
+}
+HM_DEV inline void cabr_store(const CabacWR &r, CabacW *c)
+{
+  HM_WAVE_FOR(k) { if (k < 46) { ((int32_t *)c->s)[k] = HM_LVK(r.st, k); ((int32_t *)c->used)[k] = HM_LVK(r.us, k); } }
+  c->low = r.low; c->range = r.range; c->bitsLeft = r.bitsLeft; c->bins = r.bins;
+  HM_SYNC();
+}
+HM_DEV inline void cabwr_write_out(CabacWR *r)
+{ // cabw_write_out with low / bitsLeft in registers
+  CabacW *w = r->w;
+  const uint32_t leadByte = r->low >> (24 - r->bitsLeft);
+  r->bitsLeft += 8; r->low &= 0xffffffffu >> r->bitsLeft;
+  if (leadByte == 0xff) w->numBufferedBytes++;
+  else if (w->numBufferedBytes > 0) {
+    const uint32_t carry = leadByte >> 8;
+    cabw_put_byte(w, (w->bufferedByte + carry) & 0xff);
+    w->bufferedByte = leadByte & 0xff;
+    const uint32_t fill = (0xff + carry) & 0xff;
+    while (w->numBufferedBytes > 1) { cabw_put_byte(w, fill); w->numBufferedBytes--; }
+  } else { w->numBufferedBytes = 1; w->bufferedByte = leadByte; }
+}
+HM_DEV inline void enc_bin(const Shared *e, CabacWR *r, int ctx, int bin)
+{
+  (void)e;
+  const int wd = HM_LV_GET(r->st, ctx >> 2), sh = (ctx & 3) * 8, s = (wd >> sh) & 0xff;
+  const uint32_t lps = ((uint32_t)HM_LV_GET(r->lpsRow, s >> 1) >> (((r->range >> 6) & 3) * 8)) & 0xff;
+  uint32_t range = r->range - lps;
+  if (bin != (s & 1)) {
+    const int numBits = __builtin_clz(lps) - 23;
+    r->low = (r->low + range) << numBits; range = lps << numBits; r->bitsLeft -= numBits;
+  } else if (range < 256) { r->low <<= 1; range <<= 1; r->bitsLeft--; }
+  r->range = range; r->bins++;
+  const int lw = HM_LV_GET(r->nlps, s >> 2);
+  const int ns = (bin == (s & 1)) ? (s < 124 ? s + 2 : s) : ((lw >> ((s & 3) * 8)) & 0xff);
+  HM_LV_SET(r->st, ctx >> 2, (wd & ~(0xff << sh)) | (ns << sh));
+  HM_LV_SET(r->us, ctx >> 2, HM_LV_GET(r->us, ctx >> 2) | (1 << sh));
+  if (r->bitsLeft < 12) cabwr_write_out(r);
+}
+HM_DEV inline void enc_epv(CabacWR *r, uint32_t val, int n)
+{
+  if (n <= 0) return;
+  r->bins += (uint32_t)n;
+  while (n > 8) {
+    n -= 8;
+    const uint32_t pattern = val >> n;
+    r->low = (r->low << 8) + r->range * pattern; val -= pattern << n; r->bitsLeft -= 8;
+    if (r->bitsLeft < 12) cabwr_write_out(r);
+  }
+  r->low = (r->low << n) + r->range * val; r->bitsLeft -= n;
+  if (r->bitsLeft < 12) cabwr_write_out(r);
+}
 // engine traits: the register-resident form code_coeff_nxn codes on, and whether the values of bypass bins matter
-struct CabacWR { CabacW *w; };
-HM_DEV inline void cabr_load(CabacWR &r, CabacW *c) { r.w = c; }
-HM_DEV inline void cabr_store(const CabacWR &r, CabacW *c) { (void)r; (void)c; }
-HM_DEV inline void enc_bin(const Shared *e, CabacWR *r, int ctx, int bin) { enc_bin(e, r->w, ctx, bin); }
-HM_DEV inline void enc_epv(CabacWR *r, uint32_t val, int n) { enc_epv(r->w, val, n); }
 template <class C> struct EngOf { typedef CabacR R; enum { REAL = 0 }; };
 template <> struct EngOf<CabacW> { typedef CabacWR R; enum { REAL = 1 }; };
-template <> struct EngOf<CabacWR> { typedef CabacWR R; enum { REAL = 1 }; };

@@ -91,6 +91,7 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
   // start of the substream: resetEntropy (context init + TEncBinCABAC::start); a WPP row then takes the contexts stored after the
   // second CTU of the row above (TEncSlice.cpp:975-994)
   HM_PAR_FOR(i, 184) { w->s[i] = (uint8_t)(i < HM_NUM_CTX + 2 ? bits_ctx_init_state(bits_ctx_init_value(i, initType), qp) : 0); w->used[i] = 0; }
+  cabw_load_tables(w);
   cabw_start(w);
   w->held = 0; w->numHeld = 0; w->len = 0; w->bins = 0;
   w->out = bp->raw + (size_t)first * bp->capPerCtu; w->cap = (uint32_t)(last - first) * bp->capPerCtu;
