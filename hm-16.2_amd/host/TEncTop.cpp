@@ -56,7 +56,19 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
     // loop filters (TEncGOP.cpp:1184, :1475-1497), then the finished picture back into getPicYuvRec()
     const Bool bLF = !m_pcEncTop->getLoopFilterDisable(), bSAO = m_pcEncTop->getUseSAO();
     if (bLF) m_pcLoopFilter->loopFilterPic(pcPic);
-    if (bSAO) { Bool sliceEnabled[3]; m_pcSAO->SAOProcess(pcPic, sliceEnabled, m_pcSliceEncoder->getLambdas()); }
+    pcSlice->setSaoEnabledFlag(0, false); pcSlice->setSaoEnabledFlag(1, false);
+    if (bSAO) {
+      Bool sliceEnabled[3]; m_pcSAO->SAOProcess(pcPic, sliceEnabled, m_pcSliceEncoder->getLambdas());
+      pcSlice->setSaoEnabledFlag(0, sliceEnabled[0]); pcSlice->setSaoEnabledFlag(1, sliceEnabled[1]);      // TEncGOP.cpp:1486-1490
+    }
+    { // the slice data (TEncGOP.cpp:1127, :1556-1561): one substream per CTU row with WPP, else one
+      const Int numSubstreams = hm355_num_substreams(m_pcEncTop->getDeviceContext());
+      std::vector<TComOutputBitstream> &substreamsOut = pcPic->getSubstreams();
+      substreamsOut.assign(numSubstreams, TComOutputBitstream());
+      pcSlice->clearSubstreamSizes();
+      UInt numBinsCoded = 0;
+      m_pcSliceEncoder->encodeSlice(pcPic, &substreamsOut[0], numBinsCoded);
+    }
     if (bLF || bSAO) {
       hm355_planes rec; for (Int c = 0; c < 3; c++) rec.plane[c] = pcPic->getPicYuvRec()->getAddr(ComponentID(c));
       if (hm355_download(m_pcEncTop->getDeviceContext(), 0, &rec, NULL, NULL) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: download failed: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
@@ -104,6 +116,24 @@ Void TEncSlice::initEncSlice(TComPic *pcPic, Int, Int, Int, Int, TComSlice *&rpc
   const Int iQP = (Int)floor(dQP + 0.5);
   setUpLambda(rpcSlice, dLambda, iQP);
   rpcSlice->setSliceQp(iQP);
+}
+Void TEncSlice::encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, UInt &numBinsCoded)
+{ // the picture (CU / TU data, coefficients, SAO parameters) is still resident in device slot 0
+  TComSlice *pcSlice = pcPic->getSlice(0);
+  hm355_ctx *ctx = m_pcEncTop->getDeviceContext();
+  const Int numSubstreams = hm355_num_substreams(ctx);
+  hm355_bits_desc bd; memset(&bd, 0, sizeof(bd));
+  bd.slice_type = (int32_t)pcSlice->getSliceType(); bd.qp = pcSlice->getSliceQp(); bd.cabac_init_type = bd.slice_type; bd.max_merge_cand = 5;
+  bd.sao_enabled[0] = pcSlice->getSaoEnabledFlag(0); bd.sao_enabled[1] = pcSlice->getSaoEnabledFlag(1);
+  std::vector<uint8_t> bytes((size_t)m_pcEncTop->getSourceWidth() * m_pcEncTop->getSourceHeight() * 4 + 4096); std::vector<uint32_t> sizes(numSubstreams);
+  bd.out = bytes.data(); bd.out_cap = bytes.size(); bd.sub_sizes = sizes.data();
+  if (hm355_encode_slices_run(ctx, 1, &bd) != HM355_OK) { fprintf(stderr, "TEncSlice::encodeSlice: device path failed: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
+  const uint8_t *p = bytes.data();
+  for (Int k = 0; k < numSubstreams; p += sizes[k], k++) {
+    pcSubstreams[k].getFIFO().assign(p, p + sizes[k]);
+    if (k + 1 < numSubstreams) pcSlice->addSubstreamSize(sizes[k]);      // TEncSlice.cpp:1067-1071 (+ the start code emulation count, a NAL-level matter)
+  }
+  numBinsCoded = bd.num_bins;
 }
 Void TEncSlice::compressSlice(TComPic *pcPic)
 {

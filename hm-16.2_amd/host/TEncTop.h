@@ -39,8 +39,23 @@ public:
   Void setSliceQp(Int qp) { m_qp = qp; } Int getSliceQp() const { return m_qp; }
   Void setPOC(Int p) { m_poc = p; } Int getPOC() const { return m_poc; }
   Void setSliceBits(UInt b) { m_bits = b; } UInt getSliceBits() const { return m_bits; }
+  Void setSaoEnabledFlag(Int chType, Bool b) { m_sao[chType] = b; } Bool getSaoEnabledFlag(Int chType) const { return m_sao[chType]; }
+  Void clearSubstreamSizes() { m_substreamSizes.clear(); } Void addSubstreamSize(UInt s) { m_substreamSizes.push_back(s); }
+  UInt getNumberOfSubstreamSizes() const { return (UInt)m_substreamSizes.size(); } UInt getSubstreamSize(Int i) const { return m_substreamSizes[i]; }
 private:
-  SliceType m_type = I_SLICE; Int m_qp = 32, m_poc = 0; UInt m_bits = 0;
+  SliceType m_type = I_SLICE; Int m_qp = 32, m_poc = 0; UInt m_bits = 0; Bool m_sao[2] = {false, false}; std::vector<UInt> m_substreamSizes;
+};
+
+// byte FIFO of one substream (TComBitStream.h:89-160): only what encodeSlice's callers read
+class TComOutputBitstream {
+public:
+  std::vector<uint8_t> &getFIFO() { return m_fifo; }
+  const std::vector<uint8_t> &getFIFO() const { return m_fifo; }
+  UInt getByteStreamLength() const { return (UInt)m_fifo.size(); }
+  UInt getNumberOfWrittenBits() const { return (UInt)m_fifo.size() * 8; }
+  Void clear() { m_fifo.clear(); }
+private:
+  std::vector<uint8_t> m_fifo;
 };
 
 // picture = original + reconstruction + per-CTU decision data (TComPic.h / TComPicSym.h / TComDataCU.h)
@@ -53,8 +68,9 @@ public:
   hm355_ctu_out *getCtu(UInt ctuRsAddr) { return &m_ctus[ctuRsAddr]; }     // the arrays of TComDataCU
   UInt getNumberOfCtusInFrame() const { return (UInt)m_ctus.size(); }
   Int getPOC() { return m_slice.getPOC(); }
+  std::vector<TComOutputBitstream> &getSubstreams() { return m_substreams; }   // the slice data of the picture (kept where TEncGOP would hand it to the NAL writer)
 private:
-  TComPicYuv m_org, m_rec; TComSlice m_slice; std::vector<hm355_ctu_out> m_ctus;
+  TComPicYuv m_org, m_rec; TComSlice m_slice; std::vector<hm355_ctu_out> m_ctus; std::vector<TComOutputBitstream> m_substreams;
 };
 
 // configuration holder (TEncCfg.h): the subset the hot path reads; unsupported values are rejected by create()
@@ -85,6 +101,7 @@ public:
   const Double *getLambdas() const { return m_dLambdas; }                            // TComSlice::getLambdas of the current slice
   Void precompressSlice(TComPic *) {}                                                // DeltaQpRD = 0 in every config: no-op
   Void compressSlice(TComPic *pcPic);                                                // TEncSlice.cpp:640 -> hm355_compress_slice
+  Void encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, UInt &numBinsCoded);   // TEncSlice.cpp:910 -> hm355_encode_slices_run
   uint64_t getTotalBits() const { return m_uiPicTotalBits; }
   Double getPicRdCost() const { return m_dPicRdCost; }
   uint64_t getPicDist() const { return m_uiPicDist; }

@@ -2,10 +2,12 @@
 // 4:2:0 file, feeds TEncTop::encode picture by picture and dumps what compressSlice left behind in the
 // same "HMD1" format the reference harness writes (oracle/ref_harness.cpp), for the parity tests.
 //   hm355_encmain <in.yuv> <w> <h> <bitdepth> <frames> <qp> <wpp> <dump.bin> [lf]     lf: run deblocking + SAO, the dump then holds the finished pictures
+// The slice data of every picture (TEncSlice::encodeSlice) goes to <dump.bin>.bits: per picture u32 numSubstreams, then per substream u32 size + bytes.
 #include "TEncTop.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 
 int main(int argc, char **argv)
 {
@@ -18,6 +20,8 @@ int main(int argc, char **argv)
   enc.setWaveFrontSynchro(wpp); enc.setFramesToBeEncoded(frames);
   if (argc > 9 && !strcmp(argv[9], "lf")) { enc.setLoopFilterDisable(false); enc.setUseSAO(true); }
   enc.create(); enc.init();
+  FILE *fb = fopen((std::string(argv[8]) + ".bits").c_str(), "wb");
+  if (!fb) { perror("open"); return 1; }
   fwrite("HMD1", 1, 4, fo);
   uint32_t hdr[5] = { (uint32_t)w, (uint32_t)h, (uint32_t)bd, 64, (uint32_t)frames }; fwrite(hdr, 4, 5, fo);
   TComPicYuv org; org.create(w, h);
@@ -39,8 +43,10 @@ int main(int argc, char **argv)
       fwrite(c->coeff_y, 4, 6144, fo);
     }
     for (int c = 0; c < 3; c++) fwrite(pic->getPicYuvRec()->getAddr(ComponentID(c)), 2, (size_t)org.getWidth(ComponentID(c)) * org.getHeight(ComponentID(c)), fo);
+    const uint32_t ns = (uint32_t)pic->getSubstreams().size(); fwrite(&ns, 4, 1, fb);
+    for (uint32_t k = 0; k < ns; k++) { const std::vector<uint8_t> &b = pic->getSubstreams()[k].getFIFO(); const uint32_t nb = (uint32_t)b.size(); fwrite(&nb, 4, 1, fb); if (nb) fwrite(b.data(), 1, nb, fb); }
   }
   enc.destroy();
-  fclose(fo); fclose(fi);
+  fclose(fo); fclose(fi); fclose(fb);
   return 0;
 }

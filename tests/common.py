@@ -170,3 +170,19 @@ def normalise_sao(params):
     p[off, 1:] = 0
     p[mrg, 2:] = 0
     return p
+
+
+def read_mirror_bits(path, frames):
+    """the .bits side file of hm355_encmain: per picture u32 numSubstreams, then per substream u32 size + bytes -> [[bytes]]"""
+    import struct
+    buf = open(path, "rb").read()
+    off, out = 0, []
+    for _ in range(frames):
+        n, = struct.unpack_from("<I", buf, off); off += 4
+        subs = []
+        for _ in range(n):
+            nb, = struct.unpack_from("<I", buf, off); off += 4
+            subs.append(buf[off:off + nb]); off += nb
+        out.append(subs)
+    assert off == len(buf)
+    return out

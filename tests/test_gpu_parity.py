@@ -411,6 +411,8 @@ def test_cpp_host_mirror_drop_in(tmp_path):
     for i, (ctus, rec) in enumerate(frames):
         common.assert_ctus_equal(got[i][0], ctus, f"frame {i}", (cfg["width"], cfg["height"]))
         assert np.array_equal(got[i][1], rec)
+    bits = common.read_mirror_bits(str(dump) + ".bits", len(frames))          # loop filters off: one substream per picture, no SAO syntax
+    assert all(len(b) == ((cfg["height"] + 63) // 64 if cfg["wpp"] else 1) and all(len(x) > 0 for x in b) for b in bits)
 
 
 def test_cpp_host_mirror_with_loop_filters(built, tmp_path):
@@ -428,12 +430,16 @@ def test_cpp_host_mirror_with_loop_filters(built, tmp_path):
     import hm355
     lam, cw = hm355.intra_lambda(qp)
     rate = np.zeros((3, 8), np.float64)
+    bits = common.read_mirror_bits(str(dump) + ".bits", nf)
     for i in range(nf):
         planes = synth.frame(w, h, bd, i, seed)
         rec, ctus = oracle.compress(planes, bd, qp, wpp)
         common.assert_ctus_equal(got[i][0], ctus, f"frame {i}")
         dbk = oracle.deblock(rec, bd, qp, 2, np.zeros((2, 16), np.int32), ctus, None)
-        fin, _, _ = oracle.sao(planes, dbk, bd, qp, lam, cw, 2, 0, rate)
+        fin, params, en = oracle.sao(planes, dbk, bd, qp, lam, cw, 2, 0, rate)
         want = np.concatenate([p.ravel() for p in fin])
         assert np.array_equal(got[i][1], want), f"frame {i}: finished picture differs at {int((got[i][1] != want).sum())} samples"
+        # TEncSlice::encodeSlice of the mirror: the slice data (SAO syntax included) equals the oracle's arithmetic coder on the same decisions
+        want_subs, _, _ = oracle.encode_slice(w, h, bd, wpp, 2, qp, ctus, sao=params, sao_enabled=(int(en[0]), int(en[1])))
+        assert bits[i] == want_subs, f"frame {i}: slice data of the C++ mirror differs"
 
