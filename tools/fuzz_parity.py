@@ -87,6 +87,14 @@ for k in range(cases):
         for c in range(3):
             assert np.array_equal(got_sao[c], want_sao[c]), f"SAO output plane {c}"
         what += f" sao(depth {depth}, en {tuple(en)}, new {int((par[:, :, 0] == 1).sum())}, merge {int((par[:, :, 0] == 2).sum())})"
+        # bitstream pass on the same slot (CU data, coefficients, SAO parameters resident) against the oracle's arithmetic coder
+        hdr = {} if kind == "I" else dict(cabac_init_type=int(srec["cabac_init_type"]), num_ref_idx=srec["num_ref_idx"], mvd_l1_zero=int(srec["mvd_l1_zero"]),
+                                          max_merge_cand=int(srec["max_merge_cand"]))
+        (subs, nxt, bins), = enc.encode_slices_run([dict(slice_type=st, qp=sqp, sao_enabled=(en[0], en[1]), **hdr)])
+        want_subs, want_nxt, want_bins = oracle.encode_slice(w, h, bd, wpp, st, sqp, oc, oi, sao=want_par, sao_enabled=(int(want_en[0]), int(want_en[1])), **hdr)
+        assert subs == want_subs, "slice data bytes"
+        assert (nxt, bins) == (want_nxt, want_bins), "next context table / bin count"
+        what += f" bits({sum(len(x) for x in subs)} B, {len(subs)} substreams, next table {nxt})"
         print(f"case {k}: {kind} {w}x{h} {bd}b qp{qp} wpp{wpp} seed{seed} {what} ok ({time.time() - t0:.1f}s)", flush=True)
     except AssertionError as ex:
         bad += 1
