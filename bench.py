@@ -298,6 +298,55 @@ def run_dbk(args, torch):
     enc.close()
 
 
+def run_ingest(args, torch):
+    """Secondary workload: picture ingest and output (hm355_upload_file_frames / hm355_download_file_frames): `--frames` 3840x2160
+    file frames (10-bit samples in 16-bit words, as main10 sequences are stored) -> the slots' original planes, and the slots' planes -> file
+    frames.  A step = one ingest launch + one output launch over the batch, raw frames resident in HBM when the timed region starts (the
+    HIP events bracket the kernels only).  Pure HBM streaming: algorithmic bytes = every sample read once and written once per direction."""
+    import hm355
+    import synth
+    w, h, bd, F, fbd = args.width, args.height, 10, args.frames, 10
+    enc = hm355.Encoder(w, h, bd, 1, F)
+    distinct = [synth.frame(w, h, fbd, f, 1234) for f in range(min(4, F))]
+    raws = [b"".join(np.ascontiguousarray(p, "<u2").tobytes() for p in d) for d in distinct]
+    frames = [raws[i % len(raws)] for i in range(F)]
+    ms_in = ms_out = wall_in = wall_out = 0.0
+    for it in range(args.warmup + args.steps):
+        t0 = time.time(); a = enc.upload_file_frames(frames, w, h, fbd); t1 = time.time()
+        out, b = enc.download_file_frames(F, fbd, 0, 0, source=1); t2 = time.time()
+        if it >= args.warmup:
+            ms_in += a; ms_out += b; wall_in += t1 - t0; wall_out += t2 - t1
+    ok = out[0] == frames[0] and out[F - 1] == frames[F - 1]
+    got = enc.download_org(1 % F)
+    ok = ok and all(np.array_equal(got[k], distinct[1 % len(distinct)][k]) for k in range(3))
+    n = enc.num_ctus * F * args.steps
+    per_pic = w * h * 3 // 2 * 2 * 2                    # 16-bit samples read once + written once
+    ms_total = ms_in + ms_out
+    alg = 2 * per_pic * F * args.steps                  # ingest + output
+    ach = alg / (ms_total * 1e-3) / 1e9
+    line = {"metric": "CTUs/sec (picture ingest + output, TVideoIOYuv read / write) at 4K main10; byte-exact vs HM", "value": n / (ms_total * 1e-3), "unit": "CTU/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_total / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": f"TVideoIOYuv::read + ::write of {F} 4:2:0 frames {w}x{h}, 10-bit samples in 16-bit words, raw frames resident in HBM",
+                       "frames_per_gpu": F, "pictures_per_s": F * args.steps / (ms_total * 1e-3), "ingest_ms_per_step": ms_in / args.steps,
+                       "output_ms_per_step": ms_out / args.steps, "ingest_ms_per_step_with_pcie": 1e3 * wall_in / args.steps,
+                       "output_ms_per_step_with_pcie": 1e3 * wall_out / args.steps, "roundtrip_identical": bool(ok)},
+            "roofline": {"bound": "hbm", "kernel": "hm355_ingest_kernel + hm355_output_kernel (1 launch each per step)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "note": f"algorithmic bytes = {per_pic} B per picture and direction (every 16-bit sample read once + written once)"}}
+    if not args.no_cpu_baseline:
+        import oracle
+        t0 = time.time()
+        pl = oracle.yuv_read(frames[0], w, h, fbd, bd, 0, 0)
+        oracle.yuv_write(pl, bd, fbd, 0, 0)
+        dt = time.time() - t0
+        line["cpu_baseline"] = {"value": enc.num_ctus / dt, "unit": "CTU/s", "cores": 1, "kind": "port",
+                                "sample": f"one {w}x{h} frame read + written through oracle/hm_oracle_yuv.inc"}
+        line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+    enc.close()
+
+
 def run_bits(args, torch):
     """Secondary workload: the bitstream pass (hm355_encode_slices_run) over `--frames` 3840x2160 10-bit I pictures whose search
     results and SAO parameters are resident in their slots (search, deblocking and SAO run once, untimed).  A step = the CABAC-coded slice
@@ -358,7 +407,7 @@ def run_bits(args, torch):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao", "bits"], help="intra4k = the BASELINE.json metric (default)")
+    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao", "bits", "ingest"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
@@ -381,6 +430,8 @@ def main():
             raise SystemExit("--workload ldp_p / ra_b / dbk are single-GPU measurements")
         if args.workload == "bits":
             return run_bits(args, torch)
+        if args.workload == "ingest":
+            return run_ingest(args, torch)
         return run_dbk(args, torch) if args.workload in ("dbk", "sao") else run_inter(args, torch)
     dist = None
     if world > 1:

@@ -16,6 +16,7 @@
 #include "hm355_dbk.h"
 #include "hm355_sao.h"
 #include "hm355_bits_kernel.h"
+#include "hm355_ingest.h"
 #include "hm355_host_common.h"
 #include "../../include/hm355.h"
 
@@ -126,6 +127,7 @@ struct Slot {           // one picture resident in HBM
   FrameBuf fb;          // device pointers + slice parameters (host copy)
   InterMeta *imeta;     // motion arrays of the slot (allocated on first inter use; kept for the deblocking pass)
   Pel *saoSrc[3]; SaoStat *saoStat; SaoCand *saoCand; SaoBlk *saoCoded, *saoRecon;   // SAO working buffers (allocated on first use)
+  uint8_t *rawIn, *rawOut;   // file frames as they are on disk (ingest / output, allocated on first use)
   uint8_t *bitsRaw, *bitsPacked; uint32_t *bitsSizes; CabacW *bitsSync; uint32_t *bitsFlag; InterPic *bitsIp;   // bitstream pass (allocated on first use)
 };
 #define HM_BITS_CAP_PER_CTU 16384u   /* bytes reserved per CTU in the raw substream buffers: above the raw size of a 10-bit 4:2:0 CTU (7.7 KB) */
@@ -148,6 +150,7 @@ struct hm355_ctx {
   DbkParams *dDbk;      // [max_batch] deblocking parameters of the pictures in the slots
   SaoParams *dSao;      // [max_batch] SAO parameters / results of the pictures in the slots
   BitsParams *dBits;    // [max_batch] bitstream pass parameters / results
+  IngestParams *dIngest; // [max_batch] ingest / output parameters
 };
 
 #define HM_CHECK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_); return HM355_ERR_DEVICE; } } while (0)
@@ -175,7 +178,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
-  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL;
+  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
   c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
@@ -200,6 +203,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   for (int s = 0; s < cfg->max_batch; s++) {
     FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
     c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCand = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
+    c->slots[s].rawIn = c->slots[s].rawOut = NULL;
     c->slots[s].bitsRaw = c->slots[s].bitsPacked = NULL; c->slots[s].bitsSizes = NULL; c->slots[s].bitsSync = NULL; c->slots[s].bitsFlag = NULL; c->slots[s].bitsIp = NULL;
     for (int k = 0; k < 3; k++) {
       const size_t bytes = (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel);
@@ -230,7 +234,7 @@ extern "C" void hm355_destroy(hm355_ctx *c)
     for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
     if (c->slots[s].imeta) hipFree(c->slots[s].imeta);
     for (int k = 0; k < 3; k++) if (c->slots[s].saoSrc[k]) hipFree(c->slots[s].saoSrc[k]);
-    { Slot &sl = c->slots[s]; if (sl.bitsRaw) hipFree(sl.bitsRaw); if (sl.bitsPacked) hipFree(sl.bitsPacked); if (sl.bitsSizes) hipFree(sl.bitsSizes);
+    { Slot &sl = c->slots[s]; if (sl.rawIn) hipFree(sl.rawIn); if (sl.rawOut) hipFree(sl.rawOut); if (sl.bitsRaw) hipFree(sl.bitsRaw); if (sl.bitsPacked) hipFree(sl.bitsPacked); if (sl.bitsSizes) hipFree(sl.bitsSizes);
       if (sl.bitsSync) hipFree(sl.bitsSync); if (sl.bitsFlag) hipFree(sl.bitsFlag); if (sl.bitsIp) hipFree(sl.bitsIp); }
     if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCand) hipFree(c->slots[s].saoCand); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
     if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState); if (fb.done) hipFree(fb.done);
@@ -240,6 +244,7 @@ extern "C" void hm355_destroy(hm355_ctx *c)
   if (c->dDbk) hipFree(c->dDbk);
   if (c->dSao) hipFree(c->dSao);
   if (c->dBits) hipFree(c->dBits);
+  if (c->dIngest) hipFree(c->dIngest);
   if (c->ev0) hipEventDestroy(c->ev0); if (c->ev1) hipEventDestroy(c->ev1); if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -669,6 +674,79 @@ extern "C" int hm355_deblock(hm355_ctx *c, const hm355_dbk_desc *desc, const hm3
     const int w = P.width >> (k ? 1 : 0), h = P.height >> (k ? 1 : 0);
     HM_CHECK(c, hipMemcpy2D(rec->plane[k], (size_t)w * 2, fb.rec[k], (size_t)P.stride[k] * sizeof(Pel), (size_t)w * 2, h, hipMemcpyDeviceToHost));
   }
+  return HM355_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// picture ingest / output (TVideoIOYuv::read / ::write) between file frames and the slots
+// ------------------------------------------------------------------------------------------------
+static int ingest_launch(hm355_ctx *c, int n, const std::vector<IngestParams> &ips, int output, int gridW, int gridH)
+{
+  if (!c->dIngest) HM_CHECK(c, hipMalloc((void **)&c->dIngest, sizeof(IngestParams) * c->slots.size()));
+  std::vector<FrameBuf> fbs(n); for (int f = 0; f < n; f++) fbs[f] = c->slots[f].fb;
+  HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipMemcpyAsync(c->dIngest, ips.data(), sizeof(IngestParams) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
+  const dim3 grid(((unsigned)((gridW + 7) / 8) * (unsigned)gridH + HM_INGEST_BLOCK - 1) / HM_INGEST_BLOCK, 1, 3 * n);   // sized for the luma plane
+  if (output) hipLaunchKernelGGL(hm355_output_kernel, grid, dim3(HM_INGEST_BLOCK), 0, c->stream, c->dP, c->dIngest);
+  else hipLaunchKernelGGL(hm355_ingest_kernel, grid, dim3(HM_INGEST_BLOCK), 0, c->stream, c->dP, c->dIngest);
+  HM_CHECK(c, hipGetLastError());
+  HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->lastKernelMs = ms; c->lastLaunches = 1;
+  return HM355_OK;
+}
+
+extern "C" int hm355_upload_file_frames(hm355_ctx *c, int n, const void *const *frames, int file_width, int file_height, int file_bit_depth)
+{
+  if (!c || !frames || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp;
+  if (file_width < 2 || file_height < 2 || (file_width & 1) || (file_height & 1) || file_width > P.width || file_height > P.height ||
+      file_bit_depth < 8 || file_bit_depth > 14) return fail(c, HM355_ERR_ARG, "hm355_upload_file_frames: bad file frame geometry / bit depth");
+  const size_t maxBytes = (size_t)P.width * P.height * 3, bytes = (size_t)file_width * file_height * 3 / 2 * (file_bit_depth > 8 ? 2 : 1);
+  std::vector<IngestParams> ips(n);
+  for (int f = 0; f < n; f++) {
+    if (!frames[f]) return fail(c, HM355_ERR_ARG, "null frame");
+    Slot &sl = c->slots[f];
+    if (!sl.rawIn) HM_CHECK(c, hipMalloc((void **)&sl.rawIn, maxBytes));
+    HM_CHECK(c, hipMemcpyAsync(sl.rawIn, frames[f], bytes, hipMemcpyHostToDevice, c->stream));
+    ips[f].src = sl.rawIn; ips[f].dst = NULL; ips[f].fileW = file_width; ips[f].fileH = file_height; ips[f].fileBitDepth = file_bit_depth; ips[f].fromOrg = 0;
+  }
+  return ingest_launch(c, n, ips, 0, P.width, P.height);
+}
+
+extern "C" int hm355_download_org(hm355_ctx *c, int slot, hm355_planes *org)
+{
+  if (!c || !org || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
+  const Params &P = c->hp; FrameBuf &fb = c->slots[slot].fb;
+  for (int k = 0; k < 3; k++) {
+    if (!org->plane[k]) return fail(c, HM355_ERR_ARG, "null plane");
+    const int w = P.width >> (k ? 1 : 0), h = P.height >> (k ? 1 : 0);
+    HM_CHECK(c, hipMemcpy2D(org->plane[k], (size_t)w * 2, fb.org[k], (size_t)P.stride[k] * sizeof(Pel), (size_t)w * 2, h, hipMemcpyDeviceToHost));
+  }
+  return HM355_OK;
+}
+
+extern "C" int hm355_download_file_frames(hm355_ctx *c, int n, void *const *frames, int file_bit_depth, int conf_right, int conf_bottom, int source)
+{
+  if (!c || !frames || n < 1 || n > (int)c->slots.size() || source < 0 || source > 1) return HM355_ERR_ARG;
+  const Params &P = c->hp;
+  if (conf_right < 0 || conf_bottom < 0 || (conf_right & 1) || (conf_bottom & 1) || conf_right >= P.width || conf_bottom >= P.height ||
+      file_bit_depth < 8 || file_bit_depth > 14) return fail(c, HM355_ERR_ARG, "hm355_download_file_frames: bad conformance window / bit depth");
+  const int fw = P.width - conf_right, fh = P.height - conf_bottom;
+  const size_t maxBytes = (size_t)P.width * P.height * 3, bytes = (size_t)fw * fh * 3 / 2 * (file_bit_depth > 8 ? 2 : 1);
+  std::vector<IngestParams> ips(n);
+  for (int f = 0; f < n; f++) {
+    if (!frames[f]) return fail(c, HM355_ERR_ARG, "null frame");
+    Slot &sl = c->slots[f];
+    if (!sl.rawOut) HM_CHECK(c, hipMalloc((void **)&sl.rawOut, maxBytes));
+    ips[f].src = NULL; ips[f].dst = sl.rawOut; ips[f].fileW = fw; ips[f].fileH = fh; ips[f].fileBitDepth = file_bit_depth; ips[f].fromOrg = source;
+  }
+  int rc = ingest_launch(c, n, ips, 1, fw, fh);
+  if (rc != HM355_OK) return rc;
+  for (int f = 0; f < n; f++) HM_CHECK(c, hipMemcpy(frames[f], c->slots[f].rawOut, bytes, hipMemcpyDeviceToHost));
   return HM355_OK;
 }
 

@@ -79,6 +79,7 @@ class BitsDesc(C.Structure):
 EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
            "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_sao_run",
            "hm355_num_substreams", "hm355_encode_slices_run", "hm355_encode_slice",
+           "hm355_upload_file_frames", "hm355_download_file_frames", "hm355_download_org",
            "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
@@ -110,6 +111,9 @@ def load_library(path=LIB_PATH):
     lib.hm355_ref_release.argtypes = [C.c_void_p, C.c_void_p]
     lib.hm355_ref_release.restype = None
     lib.hm355_sao_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SaoDesc)]
+    lib.hm355_upload_file_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
+    lib.hm355_download_file_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.hm355_download_org.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes)]
     lib.hm355_num_substreams.argtypes = [C.c_void_p]
     lib.hm355_encode_slices_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(BitsDesc)]
     lib.hm355_encode_slice.argtypes = [C.c_void_p, C.POINTER(BitsDesc), C.c_void_p, C.c_void_p, C.c_void_p]
@@ -316,6 +320,37 @@ class Encoder:
                     d["disabled_rate"][c][t] = arr[k].disabled_rate[c][t]
             out.append((tuple(int(v) for v in arr[k].enabled), params[k]))
         return out
+
+    def upload_file_frames(self, frames, file_w, file_h, file_bd):
+        """hm355_upload_file_frames: raw 4:2:0 frames (bytes, as on disk) -> original planes of slots 0..n-1 (TVideoIOYuv::read on the device).
+        Returns the kernel time in ms."""
+        n = len(frames)
+        bufs = [np.frombuffer(f, np.uint8) for f in frames]
+        need = file_w * file_h * 3 // 2 * (2 if file_bd > 8 else 1)
+        assert all(len(b) == need for b in bufs)
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        self._check(self.lib.hm355_upload_file_frames(self.h_, n, ptrs, file_w, file_h, file_bd), "hm355_upload_file_frames")
+        ms, launches = C.c_double(), C.c_int()
+        self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
+        return ms.value
+
+    def download_file_frames(self, n, file_bd, conf_right=0, conf_bottom=0, source=0):
+        """hm355_download_file_frames: the reconstruction (source 0) or the original planes (source 1) of slots 0..n-1 as raw 4:2:0 frames
+        (TVideoIOYuv::write on the device).  Returns (list of bytes, kernel ms)."""
+        size = (self.w - conf_right) * (self.h - conf_bottom) * 3 // 2 * (2 if file_bd > 8 else 1)
+        bufs = [np.zeros(size, np.uint8) for _ in range(n)]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        self._check(self.lib.hm355_download_file_frames(self.h_, n, ptrs, file_bd, conf_right, conf_bottom, source), "hm355_download_file_frames")
+        ms, launches = C.c_double(), C.c_int()
+        self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
+        return [b.tobytes() for b in bufs], ms.value
+
+    def download_org(self, slot):
+        """the original planes of a slot as the encoder sees them"""
+        planes = [np.zeros((self.h, self.w), np.uint16), np.zeros((self.h // 2, self.w // 2), np.uint16), np.zeros((self.h // 2, self.w // 2), np.uint16)]
+        p = _planes(planes)
+        self._check(self.lib.hm355_download_org(self.h_, slot, C.byref(p)), "hm355_download_org")
+        return planes
 
     def _bits_descs(self, descs):
         n = len(descs)

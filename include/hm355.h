@@ -187,6 +187,17 @@ int hm355_encode_slices_run(hm355_ctx *ctx, int n, hm355_bits_desc *descs);
  * hm355_sao_run returns them (NULL with sao_enabled 0).  Uses slot 0. */
 int hm355_encode_slice(hm355_ctx *ctx, hm355_bits_desc *desc, const hm355_ctu_out *ctus, const hm355_ctu_inter_out *ictus, const int32_t *sao);
 
+/* ---- picture ingest and output: TVideoIOYuv::read / ::write (TVideoIOYuv.cpp:633-792) for planar 4:2:0 files, as TAppEncTop::encode drives them
+ * (:431 read into the padded source picture, :603 write of the reconstruction with the conformance window).  The frames travel as they are on
+ * disk (8-bit samples, or 16-bit little endian when file_bit_depth > 8); bit-depth scaling, padding by repetition up to the configured
+ * (padded) width x height, cropping, rounding and clipping happen on the device.
+ * hm355_upload_file_frames: frames[i] -> original planes of slot i.  hm355_download_file_frames: the reconstruction (source 0) or the original
+ * planes (source 1) of slot i -> frames[i] of (width - conf_right) x (height - conf_bottom) samples at file_bit_depth.
+ * hm355_download_org: the original planes of a slot as the encoder sees them (the TComPicYuv view of the padded source picture). ---- */
+int hm355_upload_file_frames(hm355_ctx *ctx, int n, const void *const *frames, int file_width, int file_height, int file_bit_depth);
+int hm355_download_file_frames(hm355_ctx *ctx, int n, void *const *frames, int file_bit_depth, int conf_right, int conf_bottom, int source);
+int hm355_download_org(hm355_ctx *ctx, int slot, hm355_planes *org);
+
 /* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
  * Upload / run / download are separate so that a caller can keep pictures resident. */
 int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */

@@ -1838,6 +1838,7 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
 #include "hm_oracle_dbk.inc"
 #include "hm_oracle_sao.inc"
 #include "hm_oracle_bits.inc"
+#include "hm_oracle_yuv.inc"
 
 int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus)
 { return compress_impl(cfg, org, rec, ctus, 0, NULL, NULL); }

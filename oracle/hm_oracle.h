@@ -108,6 +108,13 @@ typedef struct {
 int hmo_encode_slice(const hmo_cfg *cfg, const hmo_bits_slice *slice, const hmo_ctu *ctus, const hmo_ctu_inter *ictus, const int32_t *sao,
                      uint8_t *out, size_t out_cap, uint32_t *sub_sizes, int *next_cabac_init_type, uint32_t *num_bins);
 
+/* ---- picture ingest and output (TVideoIOYuv::read / ::write, TVideoIOYuv.cpp:633-792) for planar 4:2:0 files.
+ * read: one frame of a file_w x file_h file (8-bit samples, or 16-bit little endian when file_bit_depth > 8) into tightly packed planes of
+ * (file_w + pad_x) x (file_h + pad_y), padded by repetition and scaled to internal_bit_depth.  write: the planes minus the conformance window
+ * at the right / bottom, scaled to file_bit_depth (rounded and clipped when that is lower). ---- */
+int hmo_yuv_read(const uint8_t *file, int file_w, int file_h, int file_bit_depth, int internal_bit_depth, int pad_x, int pad_y, uint16_t *const planes[3]);
+int hmo_yuv_write(const uint16_t *const planes[3], int width, int height, int internal_bit_depth, int file_bit_depth, int crop_right, int crop_bottom, uint8_t *file);
+
 /* ---- primitives, exported for the known-answer tests (TComRdCost.cpp / TComTrQuant.cpp) ---- */
 uint32_t hmo_sad(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int sub_shift, int bit_depth);
 uint32_t hmo_sse(const int16_t *org, int so, const int16_t *cur, int sc, int w, int h, int bit_depth);

@@ -215,3 +215,32 @@ def encode_slice(width, height, bit_depth, wpp, slice_type, qp, ctus, ictus=None
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
     raw = out.tobytes()
     return [raw[offs[k]:offs[k + 1]] for k in range(n_sub)], nxt.value, bins.value
+
+
+def yuv_read(raw, file_w, file_h, file_bd, internal_bd, pad_x=0, pad_y=0):
+    """TVideoIOYuv::read of one frame: raw bytes -> 3 planes (uint16) of (file_w + pad_x) x (file_h + pad_y)"""
+    L = lib()
+    w, h = file_w + pad_x, file_h + pad_y
+    planes = [np.zeros((h, w), np.uint16), np.zeros((h // 2, w // 2), np.uint16), np.zeros((h // 2, w // 2), np.uint16)]
+    buf = np.frombuffer(raw, np.uint8)
+    pp = (C.c_void_p * 3)(*[p.ctypes.data for p in planes])
+    L.hmo_yuv_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.hmo_yuv_read(buf.ctypes.data, file_w, file_h, file_bd, internal_bd, pad_x, pad_y, pp)
+    if rc != 0:
+        raise RuntimeError(f"oracle yuv_read failed rc={rc}")
+    return planes
+
+
+def yuv_write(planes, internal_bd, file_bd, crop_right=0, crop_bottom=0):
+    """TVideoIOYuv::write of one frame: 3 planes (uint16) -> raw bytes of the cropped picture at file_bd"""
+    L = lib()
+    h, w = planes[0].shape
+    pl = [np.ascontiguousarray(p, np.uint16) for p in planes]
+    n = (w - crop_right) * (h - crop_bottom) * 3 // 2 * (2 if file_bd > 8 else 1)
+    out = np.zeros(n, np.uint8)
+    pp = (C.c_void_p * 3)(*[p.ctypes.data for p in pl])
+    L.hmo_yuv_write.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.hmo_yuv_write(pp, w, h, internal_bd, file_bd, crop_right, crop_bottom, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle yuv_write failed rc={rc}")
+    return out.tobytes()

@@ -443,8 +443,37 @@ static int runKat(const char *name, uint32_t seed)
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// yuvio: the reference's own file reader / writer (TVideoIOYuv::read :633, ::write :706) as a known-answer generator for the ingest row
+// (SURVEY 8f n3).  hm_dump yuvio <in.yuv> <fileW> <fileH> <fileBitDepth> <internalBitDepth> <padX> <padY> <frames> <outBitDepth> <out.yuv> <dump.bin>
+// reads every frame into a (fileW + padX) x (fileH + padY) 4:2:0 picture exactly as TAppEncTop::encode does (:407-455), dumps its planes
+// (u16, tightly packed) and writes it back through TVideoIOYuv::write with the padding as conformance window (:603) into out.yuv.
+// ---------------------------------------------------------------------------------------------
+static int runYuvIo(char **a)
+{
+  const int fw = atoi(a[1]), fh = atoi(a[2]), fbd = atoi(a[3]), ibd = atoi(a[4]), px = atoi(a[5]), py = atoi(a[6]), nf = atoi(a[7]), obd = atoi(a[8]);
+  Int fileBD[2] = { fbd, fbd }, intBD[2] = { ibd, ibd }, outBD[2] = { obd, obd }, pad[2] = { px, py };
+  TVideoIOYuv in, out;
+  in.open(a[0], false, fileBD, fileBD, intBD);
+  out.open(a[9], true, outBD, outBD, intBD);
+  TComPicYuv org, trueOrg;
+  org.create(fw + px, fh + py, CHROMA_420, 64, 64, 4); trueOrg.create(fw + px, fh + py, CHROMA_420, 64, 64, 4);
+  FILE *f = fopen(a[10], "wb");
+  if (!f) { perror(a[10]); return 1; }
+  for (int i = 0; i < nf; i++)
+  {
+    if (!in.read(&org, &trueOrg, IPCOLOURSPACE_UNCHANGED, pad, CHROMA_420)) { fprintf(stderr, "yuvio: short read\n"); return 1; }
+    putPlanes(f, &org);
+    if (!out.write(&org, IPCOLOURSPACE_UNCHANGED, 0, px, 0, py)) { fprintf(stderr, "yuvio: write failed\n"); return 1; }
+  }
+  fclose(f); in.close(); out.close();
+  org.destroy(); trueOrg.destroy();
+  return 0;
+}
+
 int main(int argc, char **argv)
 {
+  if (argc >= 13 && !strcmp(argv[1], "yuvio")) return runYuvIo(argv + 2);
   if (getenv("HM_TRACE")) g_trace = fopen(getenv("HM_TRACE"), "w");
   if (argc >= 4 && !strcmp(argv[1], "kat")) return runKat(argv[2], (uint32_t)atoi(argv[3]));
   if (argc >= 4 && !strcmp(argv[1], "enc2"))

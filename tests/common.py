@@ -186,3 +186,26 @@ def read_mirror_bits(path, frames):
         out.append(subs)
     assert off == len(buf)
     return out
+
+
+YUVIO_CASES = ["yuvio_100x60_8to10_pad4x4_out8", "yuvio_72x40_10to10_out10", "yuvio_90x50_10to8_pad6x6_out10", "yuvio_64x64_8to8_out8",
+               "yuvio_130x70_8to10_pad6x2_out10"]
+
+
+def load_yuvio_case(name):
+    """-> dict: geometry / bit depths, per-frame raw input bytes, per-frame planes as TVideoIOYuv::read left them, per-frame bytes TVideoIOYuv::write produced"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    c = {k: int(g[k]) for k in ("file_w", "file_h", "file_bd", "internal_bd", "pad_x", "pad_y", "out_bd", "frames")}
+    w, h = c["file_w"] + c["pad_x"], c["file_h"] + c["pad_y"]
+    fb = c["file_w"] * c["file_h"] * 3 // 2 * (2 if c["file_bd"] > 8 else 1)
+    ob = c["file_w"] * c["file_h"] * 3 // 2 * (2 if c["out_bd"] > 8 else 1)
+    pn = w * h * 3 // 2
+    raw, out = g["raw"].tobytes(), g["out"].tobytes()
+    c["raw"] = [raw[i * fb:(i + 1) * fb] for i in range(c["frames"])]
+    c["out"] = [out[i * ob:(i + 1) * ob] for i in range(c["frames"])]
+    c["planes"] = []
+    for i in range(c["frames"]):
+        p = g["planes"][i * pn:(i + 1) * pn]
+        c["planes"].append([p[:w * h].reshape(h, w), p[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), p[w * h * 5 // 4:].reshape(h // 2, w // 2)])
+    c["width"], c["height"] = w, h
+    return c

@@ -157,11 +157,42 @@ def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_ma
     print(name, "ok", len(recs), "records")
 
 
+# picture ingest / output cases: name, file width, height, file bit depth, internal bit depth, pad x, pad y, output bit depth, seed.
+# Random samples over the whole range of the file bit depth, so that down-conversions round and clip.
+YUVIO_CASES = [
+    ("yuvio_100x60_8to10_pad4x4_out8", 100, 60, 8, 10, 4, 4, 8, 1),
+    ("yuvio_72x40_10to10_out10", 72, 40, 10, 10, 0, 0, 10, 2),
+    ("yuvio_90x50_10to8_pad6x6_out10", 90, 50, 10, 8, 6, 6, 10, 3),
+    ("yuvio_64x64_8to8_out8", 64, 64, 8, 8, 0, 0, 8, 4),
+    ("yuvio_130x70_8to10_pad6x2_out10", 130, 70, 8, 10, 6, 2, 10, 5),
+]
+
+
+def gen_yuvio():
+    nf = 2
+    for name, fw, fh, fbd, ibd, px, py, obd, seed in YUVIO_CASES:
+        rng = np.random.default_rng(seed)
+        n = fw * fh * 3 // 2 * nf
+        raw = (rng.integers(0, 1 << fbd, n).astype(np.uint16).astype("<u2").tobytes() if fbd > 8 else rng.integers(0, 256, n).astype(np.uint8).tobytes())
+        with tempfile.TemporaryDirectory() as td:
+            fi, fo, fd = os.path.join(td, "in.yuv"), os.path.join(td, "out.yuv"), os.path.join(td, "dump.bin")
+            open(fi, "wb").write(raw)
+            subprocess.run([HM_DUMP, "yuvio", fi, str(fw), str(fh), str(fbd), str(ibd), str(px), str(py), str(nf), str(obd), fo, fd], check=True)
+            planes = np.frombuffer(open(fd, "rb").read(), "<u2").copy()
+            out = np.frombuffer(open(fo, "rb").read(), np.uint8).copy()
+        assert len(planes) == (fw + px) * (fh + py) * 3 // 2 * nf
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), file_w=fw, file_h=fh, file_bd=fbd, internal_bd=ibd, pad_x=px, pad_y=py, out_bd=obd, frames=nf,
+                            raw=np.frombuffer(raw, np.uint8), planes=planes, out=out)
+        print(name, "ok")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if "--yuvio-only" in sys.argv:
+        gen_yuvio(); sys.exit(0)
     if "--ldp-only" not in sys.argv:
-        gen_kat()
+        gen_kat(); gen_yuvio()
     if "--kat-only" not in sys.argv:
         if "--ldp-only" not in sys.argv:
             for c in CASES:

@@ -263,6 +263,45 @@ def test_hip_bitstream_pass_matches_reference(hm, name):
     enc.close()
 
 
+@pytest.mark.parametrize("name", common.YUVIO_CASES)
+def test_hip_picture_ingest_and_output_match_reference(hm, name):
+    """hm355_upload_file_frames / hm355_download_file_frames (TVideoIOYuv::read / ::write on the device) against the reference's own reader and
+    writer: raw file frames -> the slot's original planes (bit-depth scaling, padding by repetition), and those planes -> file bytes
+    (conformance crop, rounding and clipping); both frames of a fixture go through one batched launch."""
+    c = common.load_yuvio_case(name)
+    enc = hm.Encoder(c["width"], c["height"], c["internal_bd"], 0, max_batch=c["frames"])
+    enc.upload_file_frames(c["raw"], c["file_w"], c["file_h"], c["file_bd"])
+    for i in range(c["frames"]):
+        got = enc.download_org(i)
+        for k in range(3):
+            assert np.array_equal(got[k], c["planes"][i][k]), f"{name} frame {i}: plane {k} differs at {int((got[k] != c['planes'][i][k]).sum())} samples"
+    out, _ = enc.download_file_frames(c["frames"], c["out_bd"], c["pad_x"], c["pad_y"], source=1)
+    for i in range(c["frames"]):
+        assert out[i] == c["out"][i], f"{name} frame {i}: written bytes differ"
+    enc.close()
+
+
+def test_hip_ingest_search_output_chain_matches_oracle(built, hm):
+    """file frame -> ingest -> search -> reconstruction as a file frame, all on the device, against the oracle chain (8-bit file, 10-bit
+    internal, picture padded from 180x100 to 184x104, reconstruction written back at 8 bit through the conformance window)"""
+    import oracle
+    fw, fh, px, py, qp = 180, 100, 4, 4, 30
+    base = synth.frame(fw + px, fh + py, 8, 0, 77)
+    raw = b"".join(p[:fh >> (1 if k else 0), :fw >> (1 if k else 0)].astype(np.uint8).tobytes() for k, p in enumerate(base))
+    planes = oracle.yuv_read(raw, fw, fh, 8, 10, px, py)
+    want_rec, want_ctus = oracle.compress(planes, 10, qp, 0)
+    enc = hm.Encoder(fw + px, fh + py, 10, 0, max_batch=1)
+    enc.upload_file_frames([raw], fw, fh, 8)
+    enc.run(1, qp)
+    rec, ctus, _ = enc.download(0)
+    common.assert_ctus_equal(ctus, want_ctus, "ingested picture")
+    (out,), _ = enc.download_file_frames(1, 8, px, py)
+    assert out == oracle.yuv_write(want_rec, 10, 8, px, py)
+    with pytest.raises(RuntimeError):
+        enc.upload_file_frames([raw + raw], fw * 2, fh, 8)            # wider than the configured picture
+    enc.close()
+
+
 def test_hip_bitstream_pass_rejects_bad_parameters(hm):
     enc = hm.Encoder(128, 64, 8, 0, max_batch=1)
     with pytest.raises(RuntimeError):

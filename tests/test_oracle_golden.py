@@ -141,3 +141,17 @@ def test_oracle_bitstream_pass_matches_reference(built, name):
         assert bins == want["num_bins"] and nxt == want["next_cabac_init_type"], f"{name} POC {poc}: bins {bins}/{want['num_bins']}, next table {nxt}/{want['next_cabac_init_type']}"
         total += sum(len(s) for s in subs)
     assert total > 500
+
+
+@pytest.mark.parametrize("name", common.YUVIO_CASES)
+def test_oracle_yuv_io_matches_reference(built, name):
+    """TVideoIOYuv::read / ::write (picture ingest and output): the planes the reference's reader produced from raw file frames (8 -> 10 bit,
+    10 -> 8 bit with rounding and clipping, padding by repetition) and the bytes its writer produced from them (conformance crop, down / up
+    conversion) must equal the oracle's."""
+    import oracle
+    c = common.load_yuvio_case(name)
+    for i in range(c["frames"]):
+        planes = oracle.yuv_read(c["raw"][i], c["file_w"], c["file_h"], c["file_bd"], c["internal_bd"], c["pad_x"], c["pad_y"])
+        for k in range(3):
+            assert np.array_equal(planes[k], c["planes"][i][k]), f"{name} frame {i}: plane {k}"
+        assert oracle.yuv_write(planes, c["internal_bd"], c["out_bd"], c["pad_x"], c["pad_y"]) == c["out"][i], f"{name} frame {i}: written bytes"
