@@ -6,7 +6,12 @@
 
 static const unsigned char kChromaScale420[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,29,30,31,32,33,33,34,34,35,35,36,36,37,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51 };
 
-Void TComPic::create(Int w, Int h) { m_org.create(w, h); m_rec.create(w, h); m_ctus.assign((size_t)((w + 63) / 64) * ((h + 63) / 64), hm355_ctu_out()); }
+Void TComPic::create(Int w, Int h)
+{
+  m_org.create(w, h); m_rec.create(w, h);
+  const size_t n = (size_t)((w + 63) / 64) * ((h + 63) / 64);
+  m_ctus.assign(n, hm355_ctu_out()); m_ictus.assign(n, hm355_ctu_inter_out());
+}
 
 // ---- TEncTop ----
 Void TEncTop::create()
@@ -22,7 +27,7 @@ Void TEncTop::create()
     exit(EXIT_FAILURE);
   }
 }
-Void TEncTop::destroy() { for (auto p : m_cListPic) delete p; m_cListPic.clear(); if (m_ctx) hm355_destroy(m_ctx); m_ctx = nullptr; }
+Void TEncTop::destroy() { for (auto p : m_cListPic) { if (p->getDeviceRef()) hm355_ref_release(m_ctx, p->getDeviceRef()); delete p; } m_cListPic.clear(); if (m_ctx) hm355_destroy(m_ctx); m_ctx = nullptr; }
 Void TEncTop::init() { m_cGOPEncoder.init(this); m_cSliceEncoder.init(this); m_cLoopFilter.init(this); m_cEncSAO.init(this); }
 Void TEncTop::encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &rcListPicOut, Int &iNumEncoded)
 {
@@ -36,7 +41,7 @@ Void TEncTop::encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &
     pic->getSlice(0)->setPOC(m_iPOCLast);
     m_cListPic.push_back(pic);
   }
-  if (!m_iNumPicRcvd || (!flush && m_iNumPicRcvd != m_iGOPSize)) return;   // TEncTop.cpp:277
+  if (!m_iNumPicRcvd || (!flush && m_iPOCLast != 0 && m_iNumPicRcvd != m_iGOPSize && m_iGOPSize)) return;   // TEncTop.cpp:277: POC 0 goes alone
   m_cGOPEncoder.compressGOP(m_iPOCLast, m_iNumPicRcvd, m_cListPic);
   iNumEncoded = m_iNumPicRcvd; m_iNumPicRcvd = 0;
   rcListPicOut = m_cListPic;
@@ -46,10 +51,27 @@ Void TEncTop::encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &
 Void TEncGOP::init(TEncTop *t) { m_pcEncTop = t; m_pcSliceEncoder = t->getSliceEncoder(); m_pcLoopFilter = t->getLoopFilter(); m_pcSAO = t->getSAO(); }
 Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &rcListPic)
 {
-  Int iGOPid = 0;
-  for (auto it = rcListPic.rbegin(); it != rcListPic.rend() && iGOPid < iNumPicRcvd; ++it, ++iGOPid) {
-    TComPic *pcPic = *it; TComSlice *pcSlice = nullptr;
-    m_pcSliceEncoder->initEncSlice(pcPic, iPOCLast, pcPic->getPOC(), iNumPicRcvd, iGOPid, pcSlice);   // TEncGOP.cpp:760
+  hm355_ctx *ctx = m_pcEncTop->getDeviceContext();
+  const Int gopSize = iPOCLast == 0 ? 1 : m_pcEncTop->getGOPSize();                                    // xInitGOP, TEncGOP.cpp:1794
+  for (Int iGOPid = 0; iGOPid < gopSize; iGOPid++) {
+    const Int pocCurr = iPOCLast == 0 ? 0 : iPOCLast - iNumPicRcvd + m_pcEncTop->getGOPEntry(iGOPid).m_POC;   // :757-771
+    if (pocCurr >= m_pcEncTop->getFramesToBeEncoded()) continue;
+    TComPic *pcPic = nullptr;
+    for (auto p : rcListPic) if (p->getPOC() == pocCurr && !p->getReconMark()) pcPic = p;
+    if (!pcPic) continue;
+    TComSlice *pcSlice = nullptr;
+    m_pcSliceEncoder->initEncSlice(pcPic, iPOCLast, pocCurr, iNumPicRcvd, iGOPid, pcSlice);            // :783
+    if (pcSlice->getSliceType() == B_SLICE && m_pcEncTop->getGOPEntry(iGOPid).m_sliceType == 'P') pcSlice->setSliceType(P_SLICE);   // :800
+    if (pcSlice->getSliceType() == B_SLICE) { fprintf(stderr, "TEncGOP::compressGOP: B slices are not mirrored on the host side yet\n"); exit(EXIT_FAILURE); }
+    if (!pcSlice->isIntra()) xSetReferences(pcSlice, pocCurr, iGOPid, rcListPic);                      // :851-959
+    pcSlice->setColFromL0Flag(1); pcSlice->setColRefIdx(0); pcSlice->setCheckLDC(true);                // P slices: :961-999
+    pcSlice->setEnableTMVPFlag(m_pcEncTop->getTMVPModeId() == 1);                                     // :1017-1025
+    pcSlice->setMvdL1ZeroFlag(false);                                                                  // :1042-1058 (B slices only)
+    pcSlice->setMaxNumMergeCand(m_pcEncTop->getMaxNumMergeCand());
+    { // context table of the slice: TEncSbac::resetEntropy :106-115 with cabac_init_present_flag (TEncTop::xInitPPS)
+      const Int idx = m_pcEncTop->getEncCABACTableIdx();
+      pcSlice->setCabacInitType((!pcSlice->isIntra() && (idx == B_SLICE || idx == P_SLICE)) ? idx : (Int)pcSlice->getSliceType());
+    }
     m_pcSliceEncoder->precompressSlice(pcPic);                                                        // :1137
     m_pcSliceEncoder->compressSlice(pcPic);                                                           // :1138
     pcSlice->setSliceBits((UInt)m_pcSliceEncoder->getTotalBits());
@@ -62,7 +84,7 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
       pcSlice->setSaoEnabledFlag(0, sliceEnabled[0]); pcSlice->setSaoEnabledFlag(1, sliceEnabled[1]);      // TEncGOP.cpp:1486-1490
     }
     { // the slice data (TEncGOP.cpp:1127, :1556-1561): one substream per CTU row with WPP, else one
-      const Int numSubstreams = hm355_num_substreams(m_pcEncTop->getDeviceContext());
+      const Int numSubstreams = hm355_num_substreams(ctx);
       std::vector<TComOutputBitstream> &substreamsOut = pcPic->getSubstreams();
       substreamsOut.assign(numSubstreams, TComOutputBitstream());
       pcSlice->clearSubstreamSizes();
@@ -71,9 +93,40 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
     }
     if (bLF || bSAO) {
       hm355_planes rec; for (Int c = 0; c < 3; c++) rec.plane[c] = pcPic->getPicYuvRec()->getAddr(ComponentID(c));
-      if (hm355_download(m_pcEncTop->getDeviceContext(), 0, &rec, NULL, NULL) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: download failed: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
+      if (hm355_download(ctx, 0, &rec, NULL, NULL) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: download failed: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
+    }
+    pcPic->setReconMark(true);
+    if (m_pcEncTop->getGOPSize() > 1) {
+      // the finished picture becomes a reference on the device: border extension + TComPic::compressMotion (:1660), no host round trip
+      int32_t numRef[2] = { pcSlice->getNumRefIdx(REF_PIC_LIST_0), 0 }, refPoc[2][16], refLT[2][16];
+      memset(refPoc, 0, sizeof(refPoc)); memset(refLT, 0, sizeof(refLT));
+      for (Int i = 0; i < numRef[0]; i++) refPoc[0][i] = pcSlice->getRefPOC(REF_PIC_LIST_0, i);
+      hm355_ref *ref = nullptr;
+      if (hm355_ref_from_slot(ctx, 0, pocCurr, pcSlice->isIntra() ? 0 : 1, numRef, refPoc, refLT, &ref) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
+      pcPic->setDeviceRef(ref);
+      for (auto p : rcListPic) if (p->getDeviceRef() && p->getPOC() < pocCurr - 16) { hm355_ref_release(ctx, p->getDeviceRef()); p->setDeviceRef(nullptr); }   // out of every reference picture set
     }
   }
+}
+
+Void TEncGOP::xSetReferences(TComSlice *pcSlice, Int pocCurr, Int iGOPid, std::list<TComPic *> &rcListPic)
+{
+  const GOPEntry &ge = m_pcEncTop->getGOPEntry(iGOPid);
+  auto find = [&](Int poc) -> TComPic * { for (auto p : rcListPic) if (p->getPOC() == poc && p->getReconMark() && p->getDeviceRef()) return p; return nullptr; };
+  std::vector<Int> refs; Bool missing = false;
+  for (Int i = 0; i < ge.m_numRefPics; i++) { const Int poc = pocCurr + ge.m_referencePics[i]; if (poc >= 0 && find(poc)) refs.push_back(poc); else missing = true; }
+  // start of the sequence (TAppEncCfg.cpp xCheckParameter, the extra reference picture sets): pictures before POC 0 are replaced by the most
+  // recently coded ones, stepping backwards in coding order (= POC order in a low-delay GOP), up to the number of active references
+  if (missing)
+    for (Int poc = pocCurr - 1; poc >= 0 && (Int)refs.size() < ge.m_numRefPicsActive; poc--) {
+      Bool have = false; for (Int r : refs) have = have || r == poc;
+      if (!have && find(poc)) refs.push_back(poc);
+    }
+  // TComSlice::setRefPicList: list 0 = pictures before the current one, closest first (no list modification; nothing follows in a low-delay GOP)
+  for (size_t i = 0; i < refs.size(); i++) for (size_t j = i + 1; j < refs.size(); j++) if (refs[j] > refs[i]) { const Int t = refs[i]; refs[i] = refs[j]; refs[j] = t; }
+  const Int n = (Int)refs.size() < ge.m_numRefPicsActive ? (Int)refs.size() : ge.m_numRefPicsActive;     // TEncGOP.cpp:951
+  pcSlice->setNumRefIdx(REF_PIC_LIST_0, n); pcSlice->setNumRefIdx(REF_PIC_LIST_1, 0);
+  for (Int i = 0; i < n; i++) { pcSlice->setRefPic(find(refs[i]), REF_PIC_LIST_0, i); pcSlice->setRefPOC(refs[i], REF_PIC_LIST_0, i); }
 }
 
 // ---- loop filters: the picture is still resident in device slot 0 after TEncSlice::compressSlice ----
@@ -81,12 +134,13 @@ Void TComLoopFilter::loopFilterPic(TComPic *pcPic)
 {
   hm355_dbk_desc dd; memset(&dd, 0, sizeof(dd));
   dd.slice_type = (int32_t)pcPic->getSlice(0)->getSliceType(); dd.qp = pcPic->getSlice(0)->getSliceQp();
+  for (Int i = 0; i < pcPic->getSlice(0)->getNumRefIdx(REF_PIC_LIST_0); i++) dd.ref_poc[0][i] = pcPic->getSlice(0)->getRefPOC(REF_PIC_LIST_0, i);
   if (hm355_deblock_run(m_pcEncTop->getDeviceContext(), 1, &dd) != HM355_OK) { fprintf(stderr, "TComLoopFilter::loopFilterPic: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
 }
 Void TEncSampleAdaptiveOffset::SAOProcess(TComPic *pPic, Bool *sliceEnabled, const Double *lambdas)
 {
   hm355_sao_desc sd; memset(&sd, 0, sizeof(sd));
-  sd.qp = pPic->getSlice(0)->getSliceQp(); sd.cabac_init_type = (int32_t)pPic->getSlice(0)->getSliceType(); sd.depth = 0;   // all-intra GOP: temporal depth 0
+  sd.qp = pPic->getSlice(0)->getSliceQp(); sd.cabac_init_type = pPic->getSlice(0)->getCabacInitType(); sd.depth = pPic->getSlice(0)->getDepth();
   sd.lambda = lambdas[0]; sd.chroma_weight = lambdas[0] / lambdas[1];
   memcpy(sd.disabled_rate, m_saoDisabledRate, sizeof(m_saoDisabledRate));
   if (hm355_sao_run(m_pcEncTop->getDeviceContext(), 1, &sd) != HM355_OK) { fprintf(stderr, "TEncSampleAdaptiveOffset::SAOProcess: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
@@ -104,18 +158,41 @@ Void TEncSlice::setUpLambda(TComSlice *, const Double dLambda, Int iQP)
   m_dChromaWeight = pow(2.0, (iQP - qpc) / 3.0);
   m_dLambdas[0] = dLambda; m_dLambdas[1] = m_dLambdas[2] = dLambda / m_dChromaWeight;   // :150-155
 }
-Void TEncSlice::initEncSlice(TComPic *pcPic, Int, Int, Int, Int, TComSlice *&rpcSlice)
+Void TEncSlice::initEncSlice(TComPic *pcPic, Int pocLast, Int pocCurr, Int, Int iGOPid, TComSlice *&rpcSlice)
 {
   rpcSlice = pcPic->getSlice(0);
-  rpcSlice->setSliceType(I_SLICE);                          // IntraPeriod 1: every picture is an I slice
-  const Double dQP = m_pcEncTop->getQP();
-  const Int NumberBFrames = m_pcEncTop->getGOPSize() - 1;
-  Double s = 0.05 * (Double)NumberBFrames; s = s < 0.0 ? 0.0 : (s > 0.5 ? 0.5 : s);
-  const Double dLambda_scale = 1.0 - s;
-  const Double dLambda = 0.57 * dLambda_scale * pow(2.0, (dQP - 12) / 3.0);   // TEncSlice.cpp:323-352
-  const Int iQP = (Int)floor(dQP + 0.5);
+  const Int gopSize = m_pcEncTop->getGOPSize();
+  const GOPEntry &ge = m_pcEncTop->getGOPEntry(iGOPid);
+  // depth of the picture in the GOP hierarchy (TEncSlice.cpp:196-231)
+  Int depth = 0;
+  { Int poc = rpcSlice->getPOC() % gopSize;
+    if (poc != 0) {
+      Int step = gopSize;
+      for (Int i = step >> 1; i >= 1; i >>= 1) {
+        for (Int j = i; j < gopSize; j += step) if (j == poc) { i = 0; break; }
+        step >>= 1; depth++;
+      }
+    } }
+  // slice type (:245-262): POC 0 and every IntraPeriod-th picture are I slices (the period is unsigned: -1 never matches)
+  SliceType eSliceType = (pocLast == 0 || (UInt)pocCurr % (UInt)m_pcEncTop->getIntraPeriod() == 0 || gopSize == 0) ? I_SLICE : B_SLICE;
+  rpcSlice->setSliceType(eSliceType);
+  // QP and lambda (:287-352): no delta QP, no lossless mode, lambda modifiers 1
+  Double dQP = m_pcEncTop->getQP();
+  if (eSliceType != I_SLICE) dQP += ge.m_QPOffset;
+  const Int NumberBFrames = gopSize - 1;
+  Double sc = 0.05 * (Double)NumberBFrames; sc = sc < 0.0 ? 0.0 : (sc > 0.5 ? 0.5 : sc);
+  const Double dLambda_scale = 1.0 - sc;
+  const Double qp_temp = dQP - 12;                                          // bitdepth_luma_qp_scale = 0 (TEncSlice.cpp:322)
+  Double dQPFactor = ge.m_QPFactor;
+  if (eSliceType == I_SLICE) dQPFactor = 0.57 * dLambda_scale;
+  Double dLambda = dQPFactor * pow(2.0, qp_temp / 3.0);
+  if (depth > 0) { Double c = qp_temp / 6.0; c = c < 2.0 ? 2.0 : (c > 4.0 ? 4.0 : c); dLambda *= c; }
+  if (!m_pcEncTop->getUseHADME() && eSliceType != I_SLICE) dLambda *= 0.95;
+  Int iQP = (Int)floor(dQP + 0.5); iQP = iQP > 51 ? 51 : (iQP < 0 ? 0 : iQP);
   setUpLambda(rpcSlice, dLambda, iQP);
-  rpcSlice->setSliceQp(iQP);
+  rpcSlice->setSliceQp(iQP); rpcSlice->setLambda(dLambda);
+  rpcSlice->setNumRefIdx(REF_PIC_LIST_0, 0); rpcSlice->setNumRefIdx(REF_PIC_LIST_1, 0);
+  rpcSlice->setDepth(depth);
 }
 Void TEncSlice::encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, UInt &numBinsCoded)
 { // the picture (CU / TU data, coefficients, SAO parameters) is still resident in device slot 0
@@ -123,7 +200,9 @@ Void TEncSlice::encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, U
   hm355_ctx *ctx = m_pcEncTop->getDeviceContext();
   const Int numSubstreams = hm355_num_substreams(ctx);
   hm355_bits_desc bd; memset(&bd, 0, sizeof(bd));
-  bd.slice_type = (int32_t)pcSlice->getSliceType(); bd.qp = pcSlice->getSliceQp(); bd.cabac_init_type = bd.slice_type; bd.max_merge_cand = 5;
+  bd.slice_type = (int32_t)pcSlice->getSliceType(); bd.qp = pcSlice->getSliceQp(); bd.cabac_init_type = pcSlice->getCabacInitType();
+  bd.max_merge_cand = (int32_t)pcSlice->getMaxNumMergeCand(); bd.mvd_l1_zero = pcSlice->getMvdL1ZeroFlag();
+  bd.num_ref_idx[0] = pcSlice->getNumRefIdx(REF_PIC_LIST_0); bd.num_ref_idx[1] = pcSlice->getNumRefIdx(REF_PIC_LIST_1);
   bd.sao_enabled[0] = pcSlice->getSaoEnabledFlag(0); bd.sao_enabled[1] = pcSlice->getSaoEnabledFlag(1);
   std::vector<uint8_t> bytes((size_t)m_pcEncTop->getSourceWidth() * m_pcEncTop->getSourceHeight() * 4 + 4096); std::vector<uint32_t> sizes(numSubstreams);
   bd.out = bytes.data(); bd.out_cap = bytes.size(); bd.sub_sizes = sizes.data();
@@ -134,10 +213,28 @@ Void TEncSlice::encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, U
     if (k + 1 < numSubstreams) pcSlice->addSubstreamSize(sizes[k]);      // TEncSlice.cpp:1067-1071 (+ the start code emulation count, a NAL-level matter)
   }
   numBinsCoded = bd.num_bins;
+  m_pcEncTop->setEncCABACTableIdx(bd.next_cabac_init_type);               // determineCabacInitIdx, TEncSlice.cpp:1083-1093 (cabac_init_present_flag)
 }
 Void TEncSlice::compressSlice(TComPic *pcPic)
 {
   TComSlice *pcSlice = pcPic->getSlice(0);
+  if (!pcSlice->isIntra()) { // P slice: the reference pictures are device-resident (hm355_ref_from_slot)
+    hm355_inter_slice_desc d; memset(&d, 0, sizeof(d));
+    d.base.slice_type = (int32_t)pcSlice->getSliceType(); d.base.qp = pcSlice->getSliceQp(); d.base.lambda = m_dLambda; d.base.chroma_weight = m_dChromaWeight;
+    d.poc = pcSlice->getPOC(); d.cabac_init_type = pcSlice->getCabacInitType();
+    d.num_ref_idx[0] = pcSlice->getNumRefIdx(REF_PIC_LIST_0); d.num_ref_idx[1] = 0;
+    for (Int i = 0; i < d.num_ref_idx[0]; i++) d.dev_ref[0][i] = pcSlice->getRefPic(REF_PIC_LIST_0, i)->getDeviceRef();
+    d.col_from_l0 = (int32_t)pcSlice->getColFromL0Flag(); d.col_ref_idx = (int32_t)pcSlice->getColRefIdx(); d.tmvp = pcSlice->getEnableTMVPFlag();
+    d.mvd_l1_zero = pcSlice->getMvdL1ZeroFlag(); d.max_merge_cand = (int32_t)pcSlice->getMaxNumMergeCand(); d.check_ldc = pcSlice->getCheckLDC();
+    d.lambda_motion_sad = (uint32_t)floor(65536.0 * sqrt(m_dLambda)); d.lambda_motion_sse = (uint32_t)floor(65536.0 * m_dLambda);   // TComRdCost::setLambda, TComRdCost.cpp:194-218
+    hm355_planes org, rec;
+    for (Int c = 0; c < 3; c++) { org.plane[c] = pcPic->getPicYuvOrg()->getAddr(ComponentID(c)); rec.plane[c] = pcPic->getPicYuvRec()->getAddr(ComponentID(c)); }
+    hm355_slice_stats st;
+    const int rc = hm355_compress_slice_inter(m_pcEncTop->getDeviceContext(), &d, &org, &rec, pcPic->getCtu(0), pcPic->getCtuInter(0), &st);
+    if (rc != HM355_OK) { fprintf(stderr, "TEncSlice::compressSlice: device path failed (%d): %s\n", rc, hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
+    m_uiPicTotalBits = st.pic_total_bits; m_dPicRdCost = st.pic_rd_cost; m_uiPicDist = st.pic_dist;
+    return;
+  }
   hm355_slice_desc sd; sd.slice_type = (int32_t)pcSlice->getSliceType(); sd.qp = pcSlice->getSliceQp(); sd.lambda = m_dLambda; sd.chroma_weight = m_dChromaWeight;
   hm355_planes org, rec;
   for (Int c = 0; c < 3; c++) { org.plane[c] = pcPic->getPicYuvOrg()->getAddr(ComponentID(c)); rec.plane[c] = pcPic->getPicYuvRec()->getAddr(ComponentID(c)); }

@@ -32,9 +32,25 @@ private:
   Int m_w = 0, m_h = 0; std::vector<uint16_t> m_buf[3];
 };
 
+class TComPic;
+enum RefPicList { REF_PIC_LIST_0 = 0, REF_PIC_LIST_1 = 1 };
 // slice header fields compressSlice reads (TComSlice.h)
 class TComSlice {
 public:
+  // inter slices: what TEncGOP::compressGOP sets up between initEncSlice and compressSlice (TEncGOP.cpp:851-1058)
+  Void setDepth(Int d) { m_depth = d; } Int getDepth() const { return m_depth; }
+  Void setNumRefIdx(RefPicList e, Int n) { m_numRefIdx[e] = n; } Int getNumRefIdx(RefPicList e) const { return m_numRefIdx[e]; }
+  Void setRefPic(TComPic *p, RefPicList e, Int i) { m_refPic[e][i] = p; } TComPic *getRefPic(RefPicList e, Int i) const { return m_refPic[e][i]; }
+  Void setRefPOC(Int poc, RefPicList e, Int i) { m_refPOC[e][i] = poc; } Int getRefPOC(RefPicList e, Int i) const { return m_refPOC[e][i]; }
+  Bool isIntra() const { return m_type == I_SLICE; }
+  Void setColFromL0Flag(UInt f) { m_colFromL0 = f; } UInt getColFromL0Flag() const { return m_colFromL0; }
+  Void setColRefIdx(UInt i) { m_colRefIdx = i; } UInt getColRefIdx() const { return m_colRefIdx; }
+  Void setEnableTMVPFlag(Bool b) { m_tmvp = b; } Bool getEnableTMVPFlag() const { return m_tmvp; }
+  Void setMvdL1ZeroFlag(Bool b) { m_mvdL1Zero = b; } Bool getMvdL1ZeroFlag() const { return m_mvdL1Zero; }
+  Void setMaxNumMergeCand(UInt n) { m_maxMergeCand = n; } UInt getMaxNumMergeCand() const { return m_maxMergeCand; }
+  Void setCheckLDC(Bool b) { m_checkLDC = b; } Bool getCheckLDC() const { return m_checkLDC; }
+  Void setCabacInitType(Int t) { m_cabacInitType = t; } Int getCabacInitType() const { return m_cabacInitType; }   // table TEncSbac::resetEntropy uses (:106-115)
+  Void setLambda(Double l) { m_lambda = l; } Double getLambda() const { return m_lambda; }
   Void setSliceType(SliceType t) { m_type = t; } SliceType getSliceType() const { return m_type; }
   Void setSliceQp(Int qp) { m_qp = qp; } Int getSliceQp() const { return m_qp; }
   Void setPOC(Int p) { m_poc = p; } Int getPOC() const { return m_poc; }
@@ -44,6 +60,8 @@ public:
   UInt getNumberOfSubstreamSizes() const { return (UInt)m_substreamSizes.size(); } UInt getSubstreamSize(Int i) const { return m_substreamSizes[i]; }
 private:
   SliceType m_type = I_SLICE; Int m_qp = 32, m_poc = 0; UInt m_bits = 0; Bool m_sao[2] = {false, false}; std::vector<UInt> m_substreamSizes;
+  Int m_depth = 0, m_numRefIdx[2] = {0, 0}, m_refPOC[2][16] = {}, m_cabacInitType = 2; TComPic *m_refPic[2][16] = {};
+  UInt m_colFromL0 = 1, m_colRefIdx = 0, m_maxMergeCand = 5; Bool m_tmvp = true, m_mvdL1Zero = false, m_checkLDC = true; Double m_lambda = 0;
 };
 
 // byte FIFO of one substream (TComBitStream.h:89-160): only what encodeSlice's callers read
@@ -69,13 +87,26 @@ public:
   UInt getNumberOfCtusInFrame() const { return (UInt)m_ctus.size(); }
   Int getPOC() { return m_slice.getPOC(); }
   std::vector<TComOutputBitstream> &getSubstreams() { return m_substreams; }   // the slice data of the picture (kept where TEncGOP would hand it to the NAL writer)
+  hm355_ctu_inter_out *getCtuInter(UInt ctuRsAddr) { return &m_ictus[ctuRsAddr]; }   // m_acCUMvField / merge / skip arrays of TComDataCU (inter slices)
+  Void setReconMark(Bool b) { m_reconMark = b; } Bool getReconMark() const { return m_reconMark; }
+  Void setDeviceRef(hm355_ref *r) { m_devRef = r; } hm355_ref *getDeviceRef() const { return m_devRef; }   // the finished picture as a device-resident reference
 private:
   TComPicYuv m_org, m_rec; TComSlice m_slice; std::vector<hm355_ctu_out> m_ctus; std::vector<TComOutputBitstream> m_substreams;
+  std::vector<hm355_ctu_inter_out> m_ictus; Bool m_reconMark = false; hm355_ref *m_devRef = nullptr;
 };
 
+// one line of the GOP table of a cfg file (TEncCfg.h GOPEntry): "Frame1: P 1 3 0.4624 0 0 0 4 4 -1 -5 -9 -13 0"
+struct GOPEntry {
+  Int m_POC = 1, m_QPOffset = 0; Double m_QPFactor = 0.57; Int m_temporalId = 0, m_numRefPicsActive = 0, m_numRefPics = 0, m_referencePics[16] = {}; char m_sliceType = 'I';
+};
 // configuration holder (TEncCfg.h): the subset the hot path reads; unsupported values are rejected by create()
 class TEncCfg {
 public:
+  Void setGOPEntry(Int i, const GOPEntry &e) { m_GOPList[i] = e; } const GOPEntry &getGOPEntry(Int i) const { return m_GOPList[i]; }
+  Void setUseHADME(Bool b) { m_bUseHADME = b; } Bool getUseHADME() const { return m_bUseHADME; }
+  Void setMaxNumMergeCand(UInt n) { m_maxNumMergeCand = n; } UInt getMaxNumMergeCand() const { return m_maxNumMergeCand; }
+  Void setTMVPModeId(Int m) { m_TMVPModeId = m; } Int getTMVPModeId() const { return m_TMVPModeId; }
+  Int getFramesToBeEncoded() const { return m_framesToBeEncoded; }
   Void setSourceWidth(Int v) { m_iSourceWidth = v; } Void setSourceHeight(Int v) { m_iSourceHeight = v; }
   Void setInternalBitDepth(Int v) { m_bitDepth = v; } Void setQP(Int v) { m_iQP = v; }
   Void setIntraPeriod(Int v) { m_uiIntraPeriod = v; } Void setGOPSize(Int v) { m_iGOPSize = v; }
@@ -88,6 +119,7 @@ public:
 protected:
   Int m_iSourceWidth = 0, m_iSourceHeight = 0, m_bitDepth = 8, m_iQP = 32, m_uiIntraPeriod = 1, m_iGOPSize = 1, m_iWaveFrontSynchro = 0, m_framesToBeEncoded = 0;
   Bool m_bLoopFilterDisable = true, m_bUseSAO = false;      // the loop filters are opt-in here (the reference's cfg files switch both on)
+  GOPEntry m_GOPList[16]; Bool m_bUseHADME = true; UInt m_maxNumMergeCand = 5; Int m_TMVPModeId = 1;
 };
 
 class TEncTop;
@@ -134,6 +166,9 @@ public:
   // TEncGOP::compressGOP (TEncGOP.cpp:527): one picture per call for the all-intra GOP (GOPSize 1)
   Void compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &rcListPic);
 private:
+  // reference picture set and list 0 of a P slice (TEncTop::selectReferencePictureSet, the extra sets TAppEncCfg::xCheckParameter builds for
+  // the start of the sequence, TComSlice::setRefPicList): low-delay configurations, no list modification
+  Void xSetReferences(TComSlice *pcSlice, Int pocCurr, Int iGOPid, std::list<TComPic *> &rcListPic);
   TEncTop *m_pcEncTop = nullptr; TEncSlice *m_pcSliceEncoder = nullptr; TComLoopFilter *m_pcLoopFilter = nullptr; TEncSampleAdaptiveOffset *m_pcSAO = nullptr;
 };
 
@@ -148,7 +183,9 @@ public:
   TComLoopFilter *getLoopFilter() { return &m_cLoopFilter; }
   TEncSampleAdaptiveOffset *getSAO() { return &m_cEncSAO; }
   hm355_ctx *getDeviceContext() { return m_ctx; }
+  Void setEncCABACTableIdx(Int i) { m_encCABACTableIdx = i; } Int getEncCABACTableIdx() const { return m_encCABACTableIdx; }   // TComPPS::m_encCABACTableIdx
 private:
+  Int m_encCABACTableIdx = I_SLICE;
   hm355_ctx *m_ctx = nullptr; TEncGOP m_cGOPEncoder; TEncSlice m_cSliceEncoder; TComLoopFilter m_cLoopFilter; TEncSampleAdaptiveOffset m_cEncSAO;
   std::list<TComPic *> m_cListPic; Int m_iPOCLast = -1, m_iNumPicRcvd = 0;
 };

@@ -2,6 +2,9 @@
 // 4:2:0 file, feeds TEncTop::encode picture by picture and dumps what compressSlice left behind in the
 // same "HMD1" format the reference harness writes (oracle/ref_harness.cpp), for the parity tests.
 //   hm355_encmain <in.yuv> <w> <h> <bitdepth> <frames> <qp> <wpp> <dump.bin> [lf]     lf: run deblocking + SAO, the dump then holds the finished pictures
+//   ... <dump.bin> ldp : the GOP table of cfg/encoder_lowdelay_P_main.cfg (IntraPeriod -1, GOPSize 4, P slices with up to 4 references, loop filters
+//   on); the dump is then a "HMD3" stream in coding order: per picture i32 poc, sliceType, qp, depth, cabacInitType, numRefIdx0, refPoc0[16]; f64 lambda;
+//   u32 numCtus; per CTU the record of tests/hmd2.py CTU_DT (cost, bits, dist, decision arrays, motion arrays, coefficients); the finished planes.
 // The slice data of every picture (TEncSlice::encodeSlice) goes to <dump.bin>.bits: per picture u32 numSubstreams, then per substream u32 size + bytes.
 #include "TEncTop.h"
 #include <stdio.h>
@@ -18,11 +21,22 @@ int main(int argc, char **argv)
   TEncTop enc;
   enc.setSourceWidth(w); enc.setSourceHeight(h); enc.setInternalBitDepth(bd); enc.setQP(qp); enc.setIntraPeriod(1); enc.setGOPSize(1);
   enc.setWaveFrontSynchro(wpp); enc.setFramesToBeEncoded(frames);
-  if (argc > 9 && !strcmp(argv[9], "lf")) { enc.setLoopFilterDisable(false); enc.setUseSAO(true); }
+  const bool ldp = argc > 9 && !strcmp(argv[9], "ldp");
+  if (argc > 9 && (!strcmp(argv[9], "lf") || ldp)) { enc.setLoopFilterDisable(false); enc.setUseSAO(true); }
+  if (ldp) { // cfg/encoder_lowdelay_P_main.cfg:20-27
+    enc.setIntraPeriod(-1); enc.setGOPSize(4);
+    static const int qpOff[4] = { 3, 2, 3, 1 }; static const double qpFac[4] = { 0.4624, 0.4624, 0.4624, 0.578 };
+    static const int refs[4][4] = { { -1, -5, -9, -13 }, { -1, -2, -6, -10 }, { -1, -3, -7, -11 }, { -1, -4, -8, -12 } };
+    for (int i = 0; i < 4; i++) {
+      GOPEntry e; e.m_sliceType = 'P'; e.m_POC = i + 1; e.m_QPOffset = qpOff[i]; e.m_QPFactor = qpFac[i]; e.m_temporalId = 0; e.m_numRefPicsActive = 4; e.m_numRefPics = 4;
+      for (int k = 0; k < 4; k++) e.m_referencePics[k] = refs[i][k];
+      enc.setGOPEntry(i, e);
+    }
+  }
   enc.create(); enc.init();
   FILE *fb = fopen((std::string(argv[8]) + ".bits").c_str(), "wb");
   if (!fb) { perror("open"); return 1; }
-  fwrite("HMD1", 1, 4, fo);
+  fwrite(ldp ? "HMD3" : "HMD1", 1, 4, fo);
   uint32_t hdr[5] = { (uint32_t)w, (uint32_t)h, (uint32_t)bd, 64, (uint32_t)frames }; fwrite(hdr, 4, 5, fo);
   TComPicYuv org; org.create(w, h);
   for (int f = 0; f < frames; f++) {
@@ -34,6 +48,29 @@ int main(int argc, char **argv)
     std::list<TComPic *> out; Int numEncoded = 0;
     enc.encode(f == frames - 1, &org, out, numEncoded);
     if (!numEncoded) continue;
+    if (ldp) { // the pictures this call encoded, in coding order (= POC order in a low-delay GOP)
+      for (TComPic *pic : out) {
+        if (!pic->getReconMark() || pic->getPOC() <= f - numEncoded) continue;
+        TComSlice *sl = pic->getSlice(0);
+        int32_t h[6 + 16] = { pic->getPOC(), (int32_t)sl->getSliceType(), sl->getSliceQp(), sl->getDepth(), sl->getCabacInitType(), sl->getNumRefIdx(REF_PIC_LIST_0) };
+        for (int i = 0; i < 16; i++) h[6 + i] = i < sl->getNumRefIdx(REF_PIC_LIST_0) ? sl->getRefPOC(REF_PIC_LIST_0, i) : 0;
+        fwrite(h, 4, 22, fo);
+        const double lambda = sl->getLambda(); fwrite(&lambda, 8, 1, fo);
+        const uint32_t n = pic->getNumberOfCtusInFrame(); fwrite(&n, 4, 1, fo);
+        for (UInt a = 0; a < n; a++) {
+          const hm355_ctu_out *c = pic->getCtu(a); const hm355_ctu_inter_out *m = pic->getCtuInter(a);
+          fwrite(&c->total_cost, 8, 1, fo); fwrite(&c->total_bits, 4, 1, fo); fwrite(&c->total_dist, 4, 1, fo);
+          fwrite(c->depth, 1, 256 * 12, fo);
+          fwrite(m->skip, 1, 256 * 4, fo);
+          for (int l = 0; l < 2; l++) { fwrite(m->mv[l], 2, 512, fo); fwrite(m->mvd[l], 2, 512, fo); fwrite(m->ref_idx[l], 1, 256, fo); fwrite(m->mvp_idx[l], 1, 256, fo); fwrite(m->mvp_num[l], 1, 256, fo); }
+          fwrite(c->coeff_y, 4, 6144, fo);
+        }
+        for (int c = 0; c < 3; c++) fwrite(pic->getPicYuvRec()->getAddr(ComponentID(c)), 2, (size_t)org.getWidth(ComponentID(c)) * org.getHeight(ComponentID(c)), fo);
+        const uint32_t ns = (uint32_t)pic->getSubstreams().size(); fwrite(&ns, 4, 1, fb);
+        for (uint32_t k = 0; k < ns; k++) { const std::vector<uint8_t> &b = pic->getSubstreams()[k].getFIFO(); const uint32_t nb = (uint32_t)b.size(); fwrite(&nb, 4, 1, fb); if (nb) fwrite(b.data(), 1, nb, fb); }
+      }
+      continue;
+    }
     TComPic *pic = out.back();
     uint32_t u[2] = { (uint32_t)pic->getPOC(), pic->getNumberOfCtusInFrame() }; fwrite(u, 4, 2, fo);
     for (UInt a = 0; a < pic->getNumberOfCtusInFrame(); a++) {

@@ -482,3 +482,53 @@ def test_cpp_host_mirror_with_loop_filters(built, tmp_path):
         want_subs, _, _ = oracle.encode_slice(w, h, bd, wpp, 2, qp, ctus, sao=params, sao_enabled=(int(en[0]), int(en[1])))
         assert bits[i] == want_subs, f"frame {i}: slice data of the C++ mirror differs"
 
+
+
+@pytest.mark.parametrize("name", common.LDP_CASES)
+def test_cpp_host_mirror_low_delay_p(tmp_path, name):
+    """The C++ mirror driven like the reference's encoder on encoder_lowdelay_P_main.cfg: TEncTop::encode queues the GOP, TEncGOP::compressGOP
+    derives slice type, QP, lambda, temporal depth, reference list and context table per picture (initEncSlice, the reference picture sets of
+    the sequence start, determineCabacInitIdx feedback) and runs search -> deblocking -> SAO -> slice data -> device-resident reference on the
+    device.  Everything it derives and everything the device returns must equal the reference's own run of the same clip: slice parameters,
+    per-CTU decisions and motion, coefficients, finished pictures and the bytes of every substream."""
+    import os, struct, subprocess
+    import hmd2
+    sd, bd = {}, {}
+    cfg, slices, finals = common.load_ldp_case(name, sao=sd, bits=bd)
+    w, h = cfg["width"], cfg["height"]
+    yuv = tmp_path / "in.yuv"
+    synth.write_yuv(str(yuv), w, h, cfg["bit_depth"], cfg["frames"], cfg["seed"])
+    dump = tmp_path / "dump.bin"
+    exe = os.path.join(common.ROOT, "hm-16.2_amd", "hm355_encmain")
+    qp0 = int(slices[0]["qp"])
+    subprocess.run([exe, str(yuv), str(w), str(h), str(cfg["bit_depth"]), str(cfg["frames"]), str(qp0), str(cfg["wpp"]), str(dump), "ldp"], check=True)
+    buf = open(dump, "rb").read()
+    assert buf[:4] == b"HMD3"
+    off = 4 + 20
+    bits = common.read_mirror_bits(str(dump) + ".bits", cfg["frames"])
+    assert len(slices) == cfg["frames"]
+    for i, r in enumerate(slices):
+        hdr = struct.unpack_from("<22i", buf, off); off += 88
+        lam, = struct.unpack_from("<d", buf, off); off += 8
+        n, = struct.unpack_from("<I", buf, off); off += 4
+        ctus = np.frombuffer(buf, hmd2.CTU_DT, n, off); off += n * hmd2.CTU_DT.itemsize
+        rec = []
+        for c in range(3):
+            cw, ch = (w, h) if c == 0 else (w // 2, h // 2)
+            rec.append(np.frombuffer(buf, "<u2", cw * ch, off).reshape(ch, cw)); off += 2 * cw * ch
+        poc, st = int(r["poc"]), int(r["slice_type"])
+        nref = int(r["num_ref_idx"][0])
+        what = f"{name} POC {poc}"
+        assert hdr[:6] == (poc, st, int(r["qp"]), sd[poc]["depth"], int(r["cabac_init_type"]), nref), f"{what}: slice parameters {hdr[:6]}"
+        assert list(hdr[6:6 + nref]) == [int(v) for v in r["ref_poc"][0][:nref]], f"{what}: reference list {hdr[6:6 + nref]}"
+        assert lam == float(r["lambda"]), f"{what}: lambda {lam} vs {float(r['lambda'])}"
+        fields = ["total_cost", "total_bits", "total_dist", "depth", "part_size", "pred_mode", "intra_dir_luma", "intra_dir_chroma", "tr_idx", "cbf", "tskip",
+                  "coeff_y", "coeff_cb", "coeff_cr"]
+        if st != 2:
+            fields += ["skip", "merge_flag", "merge_idx", "inter_dir", "mv0", "mvd0", "ref_idx0", "mvp_idx0", "mvp_num0"]
+        for f in fields:
+            assert np.array_equal(ctus[f], r["ctus"][f]), f"{what}: {f} differs"
+        for c in range(3):
+            assert np.array_equal(rec[c], finals[poc]["rec"][c]), f"{what}: finished picture plane {c}"
+        assert bits[i] == bd[poc]["substreams"], f"{what}: slice data bytes"
+    assert off == len(buf)
