@@ -62,11 +62,17 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
     TComSlice *pcSlice = nullptr;
     m_pcSliceEncoder->initEncSlice(pcPic, iPOCLast, pocCurr, iNumPicRcvd, iGOPid, pcSlice);            // :783
     if (pcSlice->getSliceType() == B_SLICE && m_pcEncTop->getGOPEntry(iGOPid).m_sliceType == 'P') pcSlice->setSliceType(P_SLICE);   // :800
-    if (pcSlice->getSliceType() == B_SLICE) { fprintf(stderr, "TEncGOP::compressGOP: B slices are not mirrored on the host side yet\n"); exit(EXIT_FAILURE); }
     if (!pcSlice->isIntra()) xSetReferences(pcSlice, pocCurr, iGOPid, rcListPic);                      // :851-959
-    pcSlice->setColFromL0Flag(1); pcSlice->setColRefIdx(0); pcSlice->setCheckLDC(true);                // P slices: :961-999
+    if (pcSlice->getSliceType() == B_SLICE && pcSlice->getNumRefIdx(REF_PIC_LIST_1) == 0) pcSlice->setSliceType(P_SLICE);   // :961
+    // collocated picture (:644-690, :967-996): uiColDir stays 1 when no reference follows the picture, so B slices of a low-delay GOP take it
+    // from list 1; every reference precedes the picture: checkLDC
+    pcSlice->setColFromL0Flag(pcSlice->getSliceType() == B_SLICE ? 0 : 1); pcSlice->setColRefIdx(0); pcSlice->setCheckLDC(true);
     pcSlice->setEnableTMVPFlag(m_pcEncTop->getTMVPModeId() == 1);                                     // :1017-1025
-    pcSlice->setMvdL1ZeroFlag(false);                                                                  // :1042-1058 (B slices only)
+    { // mvd_l1_zero_flag when both lists hold the same pictures in the same order (:1027-1058)
+      Bool same = pcSlice->getSliceType() == B_SLICE && pcSlice->getNumRefIdx(REF_PIC_LIST_0) == pcSlice->getNumRefIdx(REF_PIC_LIST_1);
+      for (Int i = 0; same && i < pcSlice->getNumRefIdx(REF_PIC_LIST_1); i++) same = pcSlice->getRefPOC(REF_PIC_LIST_1, i) == pcSlice->getRefPOC(REF_PIC_LIST_0, i);
+      pcSlice->setMvdL1ZeroFlag(same);
+    }
     pcSlice->setMaxNumMergeCand(m_pcEncTop->getMaxNumMergeCand());
     { // context table of the slice: TEncSbac::resetEntropy :106-115 with cabac_init_present_flag (TEncTop::xInitPPS)
       const Int idx = m_pcEncTop->getEncCABACTableIdx();
@@ -98,9 +104,9 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
     pcPic->setReconMark(true);
     if (m_pcEncTop->getGOPSize() > 1) {
       // the finished picture becomes a reference on the device: border extension + TComPic::compressMotion (:1660), no host round trip
-      int32_t numRef[2] = { pcSlice->getNumRefIdx(REF_PIC_LIST_0), 0 }, refPoc[2][16], refLT[2][16];
+      int32_t numRef[2] = { pcSlice->getNumRefIdx(REF_PIC_LIST_0), pcSlice->getNumRefIdx(REF_PIC_LIST_1) }, refPoc[2][16], refLT[2][16];
       memset(refPoc, 0, sizeof(refPoc)); memset(refLT, 0, sizeof(refLT));
-      for (Int i = 0; i < numRef[0]; i++) refPoc[0][i] = pcSlice->getRefPOC(REF_PIC_LIST_0, i);
+      for (Int l = 0; l < 2; l++) for (Int i = 0; i < numRef[l]; i++) refPoc[l][i] = pcSlice->getRefPOC(RefPicList(l), i);
       hm355_ref *ref = nullptr;
       if (hm355_ref_from_slot(ctx, 0, pocCurr, pcSlice->isIntra() ? 0 : 1, numRef, refPoc, refLT, &ref) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
       pcPic->setDeviceRef(ref);
@@ -114,7 +120,9 @@ Void TEncGOP::xSetReferences(TComSlice *pcSlice, Int pocCurr, Int iGOPid, std::l
   const GOPEntry &ge = m_pcEncTop->getGOPEntry(iGOPid);
   auto find = [&](Int poc) -> TComPic * { for (auto p : rcListPic) if (p->getPOC() == poc && p->getReconMark() && p->getDeviceRef()) return p; return nullptr; };
   std::vector<Int> refs; Bool missing = false;
-  for (Int i = 0; i < ge.m_numRefPics; i++) { const Int poc = pocCurr + ge.m_referencePics[i]; if (poc >= 0 && find(poc)) refs.push_back(poc); else missing = true; }
+  for (Int i = 0; i < ge.m_numRefPics; i++) {
+    if (ge.m_referencePics[i] > 0) { fprintf(stderr, "TEncGOP::xSetReferences: references that follow the picture (random access GOPs) are not mirrored on the host side yet\n"); exit(EXIT_FAILURE); }
+    const Int poc = pocCurr + ge.m_referencePics[i]; if (poc >= 0 && find(poc)) refs.push_back(poc); else missing = true; }
   // start of the sequence (TAppEncCfg.cpp xCheckParameter, the extra reference picture sets): pictures before POC 0 are replaced by the most
   // recently coded ones, stepping backwards in coding order (= POC order in a low-delay GOP), up to the number of active references
   if (missing)
@@ -125,8 +133,11 @@ Void TEncGOP::xSetReferences(TComSlice *pcSlice, Int pocCurr, Int iGOPid, std::l
   // TComSlice::setRefPicList: list 0 = pictures before the current one, closest first (no list modification; nothing follows in a low-delay GOP)
   for (size_t i = 0; i < refs.size(); i++) for (size_t j = i + 1; j < refs.size(); j++) if (refs[j] > refs[i]) { const Int t = refs[i]; refs[i] = refs[j]; refs[j] = t; }
   const Int n = (Int)refs.size() < ge.m_numRefPicsActive ? (Int)refs.size() : ge.m_numRefPicsActive;     // TEncGOP.cpp:951
-  pcSlice->setNumRefIdx(REF_PIC_LIST_0, n); pcSlice->setNumRefIdx(REF_PIC_LIST_1, 0);
-  for (Int i = 0; i < n; i++) { pcSlice->setRefPic(find(refs[i]), REF_PIC_LIST_0, i); pcSlice->setRefPOC(refs[i], REF_PIC_LIST_0, i); }
+  // list 1 of a B slice = pictures after the current one, then the ones before it: the same order as list 0 when nothing follows
+  const Bool isB = pcSlice->getSliceType() == B_SLICE;
+  pcSlice->setNumRefIdx(REF_PIC_LIST_0, n); pcSlice->setNumRefIdx(REF_PIC_LIST_1, isB ? n : 0);
+  for (Int l = 0; l < (isB ? 2 : 1); l++)
+    for (Int i = 0; i < n; i++) { pcSlice->setRefPic(find(refs[i]), RefPicList(l), i); pcSlice->setRefPOC(refs[i], RefPicList(l), i); }
 }
 
 // ---- loop filters: the picture is still resident in device slot 0 after TEncSlice::compressSlice ----
@@ -134,7 +145,7 @@ Void TComLoopFilter::loopFilterPic(TComPic *pcPic)
 {
   hm355_dbk_desc dd; memset(&dd, 0, sizeof(dd));
   dd.slice_type = (int32_t)pcPic->getSlice(0)->getSliceType(); dd.qp = pcPic->getSlice(0)->getSliceQp();
-  for (Int i = 0; i < pcPic->getSlice(0)->getNumRefIdx(REF_PIC_LIST_0); i++) dd.ref_poc[0][i] = pcPic->getSlice(0)->getRefPOC(REF_PIC_LIST_0, i);
+  for (Int l = 0; l < 2; l++) for (Int i = 0; i < pcPic->getSlice(0)->getNumRefIdx(RefPicList(l)); i++) dd.ref_poc[l][i] = pcPic->getSlice(0)->getRefPOC(RefPicList(l), i);
   if (hm355_deblock_run(m_pcEncTop->getDeviceContext(), 1, &dd) != HM355_OK) { fprintf(stderr, "TComLoopFilter::loopFilterPic: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
 }
 Void TEncSampleAdaptiveOffset::SAOProcess(TComPic *pPic, Bool *sliceEnabled, const Double *lambdas)
@@ -218,12 +229,14 @@ Void TEncSlice::encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, U
 Void TEncSlice::compressSlice(TComPic *pcPic)
 {
   TComSlice *pcSlice = pcPic->getSlice(0);
-  if (!pcSlice->isIntra()) { // P slice: the reference pictures are device-resident (hm355_ref_from_slot)
+  if (!pcSlice->isIntra()) { // P / B slice: the reference pictures are device-resident (hm355_ref_from_slot)
     hm355_inter_slice_desc d; memset(&d, 0, sizeof(d));
     d.base.slice_type = (int32_t)pcSlice->getSliceType(); d.base.qp = pcSlice->getSliceQp(); d.base.lambda = m_dLambda; d.base.chroma_weight = m_dChromaWeight;
     d.poc = pcSlice->getPOC(); d.cabac_init_type = pcSlice->getCabacInitType();
-    d.num_ref_idx[0] = pcSlice->getNumRefIdx(REF_PIC_LIST_0); d.num_ref_idx[1] = 0;
-    for (Int i = 0; i < d.num_ref_idx[0]; i++) d.dev_ref[0][i] = pcSlice->getRefPic(REF_PIC_LIST_0, i)->getDeviceRef();
+    for (Int l = 0; l < 2; l++) {
+      d.num_ref_idx[l] = pcSlice->getNumRefIdx(RefPicList(l));
+      for (Int i = 0; i < d.num_ref_idx[l]; i++) d.dev_ref[l][i] = pcSlice->getRefPic(RefPicList(l), i)->getDeviceRef();
+    }
     d.col_from_l0 = (int32_t)pcSlice->getColFromL0Flag(); d.col_ref_idx = (int32_t)pcSlice->getColRefIdx(); d.tmvp = pcSlice->getEnableTMVPFlag();
     d.mvd_l1_zero = pcSlice->getMvdL1ZeroFlag(); d.max_merge_cand = (int32_t)pcSlice->getMaxNumMergeCand(); d.check_ldc = pcSlice->getCheckLDC();
     d.lambda_motion_sad = (uint32_t)floor(65536.0 * sqrt(m_dLambda)); d.lambda_motion_sse = (uint32_t)floor(65536.0 * m_dLambda);   // TComRdCost::setLambda, TComRdCost.cpp:194-218

@@ -2,8 +2,8 @@
 // 4:2:0 file, feeds TEncTop::encode picture by picture and dumps what compressSlice left behind in the
 // same "HMD1" format the reference harness writes (oracle/ref_harness.cpp), for the parity tests.
 //   hm355_encmain <in.yuv> <w> <h> <bitdepth> <frames> <qp> <wpp> <dump.bin> [lf]     lf: run deblocking + SAO, the dump then holds the finished pictures
-//   ... <dump.bin> ldp : the GOP table of cfg/encoder_lowdelay_P_main.cfg (IntraPeriod -1, GOPSize 4, P slices with up to 4 references, loop filters
-//   on); the dump is then a "HMD3" stream in coding order: per picture i32 poc, sliceType, qp, depth, cabacInitType, numRefIdx0, refPoc0[16]; f64 lambda;
+//   ... <dump.bin> ldp | ldb : the GOP table of cfg/encoder_lowdelay_P_main.cfg / encoder_lowdelay_main.cfg (IntraPeriod -1, GOPSize 4, P slices with up to 4 references, loop filters
+//   on); the dump is then a "HMD3" stream in coding order: per picture i32 poc, sliceType, qp, depth, cabacInitType, numRefIdx0, numRefIdx1, colFromL0, mvdL1Zero, refPoc[2][16]; f64 lambda;
 //   u32 numCtus; per CTU the record of tests/hmd2.py CTU_DT (cost, bits, dist, decision arrays, motion arrays, coefficients); the finished planes.
 // The slice data of every picture (TEncSlice::encodeSlice) goes to <dump.bin>.bits: per picture u32 numSubstreams, then per substream u32 size + bytes.
 #include "TEncTop.h"
@@ -21,14 +21,15 @@ int main(int argc, char **argv)
   TEncTop enc;
   enc.setSourceWidth(w); enc.setSourceHeight(h); enc.setInternalBitDepth(bd); enc.setQP(qp); enc.setIntraPeriod(1); enc.setGOPSize(1);
   enc.setWaveFrontSynchro(wpp); enc.setFramesToBeEncoded(frames);
-  const bool ldp = argc > 9 && !strcmp(argv[9], "ldp");
+  const bool ldb = argc > 9 && !strcmp(argv[9], "ldb");            // cfg/encoder_lowdelay_main.cfg: the same table with B slices
+  const bool ldp = ldb || (argc > 9 && !strcmp(argv[9], "ldp"));
   if (argc > 9 && (!strcmp(argv[9], "lf") || ldp)) { enc.setLoopFilterDisable(false); enc.setUseSAO(true); }
   if (ldp) { // cfg/encoder_lowdelay_P_main.cfg:20-27
     enc.setIntraPeriod(-1); enc.setGOPSize(4);
     static const int qpOff[4] = { 3, 2, 3, 1 }; static const double qpFac[4] = { 0.4624, 0.4624, 0.4624, 0.578 };
     static const int refs[4][4] = { { -1, -5, -9, -13 }, { -1, -2, -6, -10 }, { -1, -3, -7, -11 }, { -1, -4, -8, -12 } };
     for (int i = 0; i < 4; i++) {
-      GOPEntry e; e.m_sliceType = 'P'; e.m_POC = i + 1; e.m_QPOffset = qpOff[i]; e.m_QPFactor = qpFac[i]; e.m_temporalId = 0; e.m_numRefPicsActive = 4; e.m_numRefPics = 4;
+      GOPEntry e; e.m_sliceType = ldb ? 'B' : 'P'; e.m_POC = i + 1; e.m_QPOffset = qpOff[i]; e.m_QPFactor = qpFac[i]; e.m_temporalId = 0; e.m_numRefPicsActive = 4; e.m_numRefPics = 4;
       for (int k = 0; k < 4; k++) e.m_referencePics[k] = refs[i][k];
       enc.setGOPEntry(i, e);
     }
@@ -52,9 +53,10 @@ int main(int argc, char **argv)
       for (TComPic *pic : out) {
         if (!pic->getReconMark() || pic->getPOC() <= f - numEncoded) continue;
         TComSlice *sl = pic->getSlice(0);
-        int32_t h[6 + 16] = { pic->getPOC(), (int32_t)sl->getSliceType(), sl->getSliceQp(), sl->getDepth(), sl->getCabacInitType(), sl->getNumRefIdx(REF_PIC_LIST_0) };
-        for (int i = 0; i < 16; i++) h[6 + i] = i < sl->getNumRefIdx(REF_PIC_LIST_0) ? sl->getRefPOC(REF_PIC_LIST_0, i) : 0;
-        fwrite(h, 4, 22, fo);
+        int32_t h[9 + 32] = { pic->getPOC(), (int32_t)sl->getSliceType(), sl->getSliceQp(), sl->getDepth(), sl->getCabacInitType(), sl->getNumRefIdx(REF_PIC_LIST_0),
+                              sl->getNumRefIdx(REF_PIC_LIST_1), (int32_t)sl->getColFromL0Flag(), sl->getMvdL1ZeroFlag() ? 1 : 0 };
+        for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) h[9 + 16 * l + i] = i < sl->getNumRefIdx(RefPicList(l)) ? sl->getRefPOC(RefPicList(l), i) : 0;
+        fwrite(h, 4, 41, fo);
         const double lambda = sl->getLambda(); fwrite(&lambda, 8, 1, fo);
         const uint32_t n = pic->getNumberOfCtusInFrame(); fwrite(&n, 4, 1, fo);
         for (UInt a = 0; a < n; a++) {

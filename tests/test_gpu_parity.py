@@ -484,9 +484,10 @@ def test_cpp_host_mirror_with_loop_filters(built, tmp_path):
 
 
 
-@pytest.mark.parametrize("name", common.LDP_CASES)
-def test_cpp_host_mirror_low_delay_p(tmp_path, name):
-    """The C++ mirror driven like the reference's encoder on encoder_lowdelay_P_main.cfg: TEncTop::encode queues the GOP, TEncGOP::compressGOP
+@pytest.mark.parametrize("name", common.LDP_CASES + [common.B_CASES[1]])
+def test_cpp_host_mirror_low_delay(tmp_path, name):
+    """The C++ mirror driven like the reference's encoder on encoder_lowdelay_P_main.cfg (P slices) and encoder_lowdelay_main.cfg (B slices,
+    list 1 = list 0, mvd_l1_zero, collocated picture from list 1): TEncTop::encode queues the GOP, TEncGOP::compressGOP
     derives slice type, QP, lambda, temporal depth, reference list and context table per picture (initEncSlice, the reference picture sets of
     the sequence start, determineCabacInitIdx feedback) and runs search -> deblocking -> SAO -> slice data -> device-resident reference on the
     device.  Everything it derives and everything the device returns must equal the reference's own run of the same clip: slice parameters,
@@ -501,14 +502,14 @@ def test_cpp_host_mirror_low_delay_p(tmp_path, name):
     dump = tmp_path / "dump.bin"
     exe = os.path.join(common.ROOT, "hm-16.2_amd", "hm355_encmain")
     qp0 = int(slices[0]["qp"])
-    subprocess.run([exe, str(yuv), str(w), str(h), str(cfg["bit_depth"]), str(cfg["frames"]), str(qp0), str(cfg["wpp"]), str(dump), "ldp"], check=True)
+    subprocess.run([exe, str(yuv), str(w), str(h), str(cfg["bit_depth"]), str(cfg["frames"]), str(qp0), str(cfg["wpp"]), str(dump), "ldb" if name.startswith("ldb") else "ldp"], check=True)
     buf = open(dump, "rb").read()
     assert buf[:4] == b"HMD3"
     off = 4 + 20
     bits = common.read_mirror_bits(str(dump) + ".bits", cfg["frames"])
     assert len(slices) == cfg["frames"]
     for i, r in enumerate(slices):
-        hdr = struct.unpack_from("<22i", buf, off); off += 88
+        hdr = struct.unpack_from("<41i", buf, off); off += 164
         lam, = struct.unpack_from("<d", buf, off); off += 8
         n, = struct.unpack_from("<I", buf, off); off += 4
         ctus = np.frombuffer(buf, hmd2.CTU_DT, n, off); off += n * hmd2.CTU_DT.itemsize
@@ -517,15 +518,18 @@ def test_cpp_host_mirror_low_delay_p(tmp_path, name):
             cw, ch = (w, h) if c == 0 else (w // 2, h // 2)
             rec.append(np.frombuffer(buf, "<u2", cw * ch, off).reshape(ch, cw)); off += 2 * cw * ch
         poc, st = int(r["poc"]), int(r["slice_type"])
-        nref = int(r["num_ref_idx"][0])
+        nref, nref1 = int(r["num_ref_idx"][0]), int(r["num_ref_idx"][1])
         what = f"{name} POC {poc}"
-        assert hdr[:6] == (poc, st, int(r["qp"]), sd[poc]["depth"], int(r["cabac_init_type"]), nref), f"{what}: slice parameters {hdr[:6]}"
-        assert list(hdr[6:6 + nref]) == [int(v) for v in r["ref_poc"][0][:nref]], f"{what}: reference list {hdr[6:6 + nref]}"
+        assert hdr[:7] == (poc, st, int(r["qp"]), sd[poc]["depth"], int(r["cabac_init_type"]), nref, nref1), f"{what}: slice parameters {hdr[:7]}"
+        if st != 2:
+            assert hdr[7:9] == (int(r["col_from_l0"]), int(r["mvd_l1_zero"])), f"{what}: collocated list / mvd_l1_zero {hdr[7:9]}"
+        assert list(hdr[9:9 + nref]) == [int(v) for v in r["ref_poc"][0][:nref]], f"{what}: list 0 {hdr[9:9 + nref]}"
+        assert list(hdr[25:25 + nref1]) == [int(v) for v in r["ref_poc"][1][:nref1]], f"{what}: list 1 {hdr[25:25 + nref1]}"
         assert lam == float(r["lambda"]), f"{what}: lambda {lam} vs {float(r['lambda'])}"
         fields = ["total_cost", "total_bits", "total_dist", "depth", "part_size", "pred_mode", "intra_dir_luma", "intra_dir_chroma", "tr_idx", "cbf", "tskip",
                   "coeff_y", "coeff_cb", "coeff_cr"]
         if st != 2:
-            fields += ["skip", "merge_flag", "merge_idx", "inter_dir", "mv0", "mvd0", "ref_idx0", "mvp_idx0", "mvp_num0"]
+            fields += ["skip", "merge_flag", "merge_idx", "inter_dir", "mv0", "mvd0", "ref_idx0", "mvp_idx0", "mvp_num0", "mv1", "mvd1", "ref_idx1", "mvp_idx1", "mvp_num1"]
         for f in fields:
             assert np.array_equal(ctus[f], r["ctus"][f]), f"{what}: {f} differs"
         for c in range(3):
