@@ -64,9 +64,28 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
     if (pcSlice->getSliceType() == B_SLICE && m_pcEncTop->getGOPEntry(iGOPid).m_sliceType == 'P') pcSlice->setSliceType(P_SLICE);   // :800
     if (!pcSlice->isIntra()) xSetReferences(pcSlice, pocCurr, iGOPid, rcListPic);                      // :851-959
     if (pcSlice->getSliceType() == B_SLICE && pcSlice->getNumRefIdx(REF_PIC_LIST_1) == 0) pcSlice->setSliceType(P_SLICE);   // :961
-    // collocated picture (:644-690, :967-996): uiColDir stays 1 when no reference follows the picture, so B slices of a low-delay GOP take it
-    // from list 1; every reference precedes the picture: checkLDC
-    pcSlice->setColFromL0Flag(pcSlice->getSliceType() == B_SLICE ? 0 : 1); pcSlice->setColRefIdx(0); pcSlice->setCheckLDC(true);
+    { // collocated picture of a B slice (:644-690, :967-996): from list 1 unless the closest following reference has a lower QP offset than
+      // the closest preceding one; checkLDC when no reference follows the picture
+      const GOPEntry &ge = m_pcEncTop->getGOPEntry(iGOPid);
+      UInt uiColDir = 1; Int iCloseLeft = 1, iCloseRight = -1;
+      for (Int i = 0; i < ge.m_numRefPics; i++) {
+        const Int iRef = ge.m_referencePics[i];
+        if (iRef > 0 && (iRef < iCloseRight || iCloseRight == -1)) iCloseRight = iRef;
+        else if (iRef < 0 && (iRef > iCloseLeft || iCloseLeft == 1)) iCloseLeft = iRef;
+      }
+      if (iCloseRight > -1) iCloseRight = iCloseRight + ge.m_POC - 1;
+      if (iCloseLeft < 1) { iCloseLeft = iCloseLeft + ge.m_POC - 1; while (iCloseLeft < 0) iCloseLeft += gopSize; }
+      Int iLeftQP = 0, iRightQP = 0;
+      for (Int i = 0; i < gopSize; i++) {
+        if (m_pcEncTop->getGOPEntry(i).m_POC == (iCloseLeft % gopSize) + 1) iLeftQP = m_pcEncTop->getGOPEntry(i).m_QPOffset;
+        if (iCloseRight > -1 && m_pcEncTop->getGOPEntry(i).m_POC == (iCloseRight % gopSize) + 1) iRightQP = m_pcEncTop->getGOPEntry(i).m_QPOffset;
+      }
+      if (iCloseRight > -1 && iRightQP < iLeftQP) uiColDir = 0;
+      pcSlice->setColFromL0Flag(pcSlice->getSliceType() == B_SLICE ? 1 - uiColDir : 1); pcSlice->setColRefIdx(0);
+      Bool bLowDelay = true;
+      for (Int l = 0; l < 2; l++) for (Int i = 0; i < pcSlice->getNumRefIdx(RefPicList(l)); i++) if (pcSlice->getRefPOC(RefPicList(l), i) > pocCurr) bLowDelay = false;
+      pcSlice->setCheckLDC(pcSlice->getSliceType() == B_SLICE ? bLowDelay : true);
+    }
     pcSlice->setEnableTMVPFlag(m_pcEncTop->getTMVPModeId() == 1);                                     // :1017-1025
     { // mvd_l1_zero_flag when both lists hold the same pictures in the same order (:1027-1058)
       Bool same = pcSlice->getSliceType() == B_SLICE && pcSlice->getNumRefIdx(REF_PIC_LIST_0) == pcSlice->getNumRefIdx(REF_PIC_LIST_1);
@@ -101,7 +120,7 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
       hm355_planes rec; for (Int c = 0; c < 3; c++) rec.plane[c] = pcPic->getPicYuvRec()->getAddr(ComponentID(c));
       if (hm355_download(ctx, 0, &rec, NULL, NULL) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: download failed: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
     }
-    pcPic->setReconMark(true);
+    pcPic->setReconMark(true); m_codedPics.push_back(pcPic);
     if (m_pcEncTop->getGOPSize() > 1) {
       // the finished picture becomes a reference on the device: border extension + TComPic::compressMotion (:1660), no host round trip
       int32_t numRef[2] = { pcSlice->getNumRefIdx(REF_PIC_LIST_0), pcSlice->getNumRefIdx(REF_PIC_LIST_1) }, refPoc[2][16], refLT[2][16];
@@ -110,7 +129,7 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
       hm355_ref *ref = nullptr;
       if (hm355_ref_from_slot(ctx, 0, pocCurr, pcSlice->isIntra() ? 0 : 1, numRef, refPoc, refLT, &ref) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
       pcPic->setDeviceRef(ref);
-      for (auto p : rcListPic) if (p->getDeviceRef() && p->getPOC() < pocCurr - 16) { hm355_ref_release(ctx, p->getDeviceRef()); p->setDeviceRef(nullptr); }   // out of every reference picture set
+      for (auto p : rcListPic) if (p->getDeviceRef() && p->getPOC() < pocCurr - 24) { hm355_ref_release(ctx, p->getDeviceRef()); p->setDeviceRef(nullptr); }   // out of every reference picture set
     }
   }
 }
@@ -120,24 +139,30 @@ Void TEncGOP::xSetReferences(TComSlice *pcSlice, Int pocCurr, Int iGOPid, std::l
   const GOPEntry &ge = m_pcEncTop->getGOPEntry(iGOPid);
   auto find = [&](Int poc) -> TComPic * { for (auto p : rcListPic) if (p->getPOC() == poc && p->getReconMark() && p->getDeviceRef()) return p; return nullptr; };
   std::vector<Int> refs; Bool missing = false;
-  for (Int i = 0; i < ge.m_numRefPics; i++) {
-    if (ge.m_referencePics[i] > 0) { fprintf(stderr, "TEncGOP::xSetReferences: references that follow the picture (random access GOPs) are not mirrored on the host side yet\n"); exit(EXIT_FAILURE); }
-    const Int poc = pocCurr + ge.m_referencePics[i]; if (poc >= 0 && find(poc)) refs.push_back(poc); else missing = true; }
+  for (Int i = 0; i < ge.m_numRefPics; i++) { const Int poc = pocCurr + ge.m_referencePics[i]; if (poc >= 0 && find(poc)) refs.push_back(poc); else missing = true; }
   // start of the sequence (TAppEncCfg.cpp xCheckParameter, the extra reference picture sets): pictures before POC 0 are replaced by the most
-  // recently coded ones, stepping backwards in coding order (= POC order in a low-delay GOP), up to the number of active references
+  // recently coded ones of the same or a lower temporal layer, stepping backwards in coding order, up to the number of active references
   if (missing)
-    for (Int poc = pocCurr - 1; poc >= 0 && (Int)refs.size() < ge.m_numRefPicsActive; poc--) {
-      Bool have = false; for (Int r : refs) have = have || r == poc;
-      if (!have && find(poc)) refs.push_back(poc);
+    for (Int k = (Int)m_codedPics.size() - 1; k >= 0 && (Int)refs.size() < ge.m_numRefPicsActive; k--) {
+      TComPic *p = m_codedPics[k];
+      Bool have = false; for (Int r : refs) have = have || r == p->getPOC();
+      if (!have && p->getDeviceRef() && p->getTLayer() <= ge.m_temporalId) refs.push_back(p->getPOC());
     }
-  // TComSlice::setRefPicList: list 0 = pictures before the current one, closest first (no list modification; nothing follows in a low-delay GOP)
-  for (size_t i = 0; i < refs.size(); i++) for (size_t j = i + 1; j < refs.size(); j++) if (refs[j] > refs[i]) { const Int t = refs[i]; refs[i] = refs[j]; refs[j] = t; }
-  const Int n = (Int)refs.size() < ge.m_numRefPicsActive ? (Int)refs.size() : ge.m_numRefPicsActive;     // TEncGOP.cpp:951
-  // list 1 of a B slice = pictures after the current one, then the ones before it: the same order as list 0 when nothing follows
+  // TComSlice::setRefPicList (no list modification): list 0 = the pictures before the current one, closest first, then the ones after it, closest
+  // first; list 1 the other way round
+  std::vector<Int> before, after;
+  for (Int r : refs) (r < pocCurr ? before : after).push_back(r);
+  for (size_t i = 0; i < before.size(); i++) for (size_t j = i + 1; j < before.size(); j++) if (before[j] > before[i]) { const Int t = before[i]; before[i] = before[j]; before[j] = t; }
+  for (size_t i = 0; i < after.size(); i++) for (size_t j = i + 1; j < after.size(); j++) if (after[j] < after[i]) { const Int t = after[i]; after[i] = after[j]; after[j] = t; }
+  std::vector<Int> l0(before), l1(after);
+  l0.insert(l0.end(), after.begin(), after.end()); l1.insert(l1.end(), before.begin(), before.end());
+  const Int n = (Int)refs.size() < ge.m_numRefPicsActive ? (Int)refs.size() : ge.m_numRefPicsActive;     // TEncGOP.cpp:951-952
   const Bool isB = pcSlice->getSliceType() == B_SLICE;
   pcSlice->setNumRefIdx(REF_PIC_LIST_0, n); pcSlice->setNumRefIdx(REF_PIC_LIST_1, isB ? n : 0);
-  for (Int l = 0; l < (isB ? 2 : 1); l++)
-    for (Int i = 0; i < n; i++) { pcSlice->setRefPic(find(refs[i]), RefPicList(l), i); pcSlice->setRefPOC(refs[i], RefPicList(l), i); }
+  for (Int i = 0; i < n; i++) {
+    pcSlice->setRefPic(find(l0[i]), REF_PIC_LIST_0, i); pcSlice->setRefPOC(l0[i], REF_PIC_LIST_0, i);
+    if (isB) { pcSlice->setRefPic(find(l1[i]), REF_PIC_LIST_1, i); pcSlice->setRefPOC(l1[i], REF_PIC_LIST_1, i); }
+  }
 }
 
 // ---- loop filters: the picture is still resident in device slot 0 after TEncSlice::compressSlice ----
@@ -204,6 +229,7 @@ Void TEncSlice::initEncSlice(TComPic *pcPic, Int pocLast, Int pocCurr, Int, Int 
   rpcSlice->setSliceQp(iQP); rpcSlice->setLambda(dLambda);
   rpcSlice->setNumRefIdx(REF_PIC_LIST_0, 0); rpcSlice->setNumRefIdx(REF_PIC_LIST_1, 0);
   rpcSlice->setDepth(depth);
+  pcPic->setTLayer(eSliceType == I_SLICE ? 0 : ge.m_temporalId);                // :457-462
 }
 Void TEncSlice::encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, UInt &numBinsCoded)
 { // the picture (CU / TU data, coefficients, SAO parameters) is still resident in device slot 0

@@ -89,10 +89,11 @@ public:
   std::vector<TComOutputBitstream> &getSubstreams() { return m_substreams; }   // the slice data of the picture (kept where TEncGOP would hand it to the NAL writer)
   hm355_ctu_inter_out *getCtuInter(UInt ctuRsAddr) { return &m_ictus[ctuRsAddr]; }   // m_acCUMvField / merge / skip arrays of TComDataCU (inter slices)
   Void setReconMark(Bool b) { m_reconMark = b; } Bool getReconMark() const { return m_reconMark; }
+  Void setTLayer(Int t) { m_tLayer = t; } Int getTLayer() const { return m_tLayer; }
   Void setDeviceRef(hm355_ref *r) { m_devRef = r; } hm355_ref *getDeviceRef() const { return m_devRef; }   // the finished picture as a device-resident reference
 private:
   TComPicYuv m_org, m_rec; TComSlice m_slice; std::vector<hm355_ctu_out> m_ctus; std::vector<TComOutputBitstream> m_substreams;
-  std::vector<hm355_ctu_inter_out> m_ictus; Bool m_reconMark = false; hm355_ref *m_devRef = nullptr;
+  std::vector<hm355_ctu_inter_out> m_ictus; Bool m_reconMark = false; hm355_ref *m_devRef = nullptr; Int m_tLayer = 0;
 };
 
 // one line of the GOP table of a cfg file (TEncCfg.h GOPEntry): "Frame1: P 1 3 0.4624 0 0 0 4 4 -1 -5 -9 -13 0"
@@ -165,9 +166,11 @@ public:
   Void init(TEncTop *pcTEncTop);
   // TEncGOP::compressGOP (TEncGOP.cpp:527): one picture per call for the all-intra GOP (GOPSize 1)
   Void compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &rcListPic);
+  const std::vector<TComPic *> &getCodedPictures() const { return m_codedPics; }   // every picture encoded so far, in coding order
 private:
-  // reference picture set and list 0 of a P slice (TEncTop::selectReferencePictureSet, the extra sets TAppEncCfg::xCheckParameter builds for
-  // the start of the sequence, TComSlice::setRefPicList): low-delay configurations, no list modification
+  std::vector<TComPic *> m_codedPics;
+  // reference picture set and lists of a P / B slice (TEncTop::selectReferencePictureSet, the extra sets TAppEncCfg::xCheckParameter builds for
+  // the start of the sequence, TComSlice::setRefPicList): no list modification, no long-term pictures
   Void xSetReferences(TComSlice *pcSlice, Int pocCurr, Int iGOPid, std::list<TComPic *> &rcListPic);
   TEncTop *m_pcEncTop = nullptr; TEncSlice *m_pcSliceEncoder = nullptr; TComLoopFilter *m_pcLoopFilter = nullptr; TEncSampleAdaptiveOffset *m_pcSAO = nullptr;
 };
@@ -183,6 +186,7 @@ public:
   TComLoopFilter *getLoopFilter() { return &m_cLoopFilter; }
   TEncSampleAdaptiveOffset *getSAO() { return &m_cEncSAO; }
   hm355_ctx *getDeviceContext() { return m_ctx; }
+  TEncGOP *getGOPEncoder() { return &m_cGOPEncoder; }
   Void setEncCABACTableIdx(Int i) { m_encCABACTableIdx = i; } Int getEncCABACTableIdx() const { return m_encCABACTableIdx; }   // TComPPS::m_encCABACTableIdx
 private:
   Int m_encCABACTableIdx = I_SLICE;

@@ -484,10 +484,11 @@ def test_cpp_host_mirror_with_loop_filters(built, tmp_path):
 
 
 
-@pytest.mark.parametrize("name", common.LDP_CASES + [common.B_CASES[1]])
-def test_cpp_host_mirror_low_delay(tmp_path, name):
-    """The C++ mirror driven like the reference's encoder on encoder_lowdelay_P_main.cfg (P slices) and encoder_lowdelay_main.cfg (B slices,
-    list 1 = list 0, mvd_l1_zero, collocated picture from list 1): TEncTop::encode queues the GOP, TEncGOP::compressGOP
+@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES)
+def test_cpp_host_mirror_inter_configurations(tmp_path, name):
+    """The C++ mirror driven like the reference's encoder on encoder_lowdelay_P_main.cfg (P slices), encoder_lowdelay_main.cfg (B slices,
+    list 1 = list 0, mvd_l1_zero, collocated picture from list 1) and encoder_randomaccess_main10.cfg (hierarchical GOP of 8 in coding order,
+    references on both sides, the collocated-direction rule): TEncTop::encode queues the GOP, TEncGOP::compressGOP
     derives slice type, QP, lambda, temporal depth, reference list and context table per picture (initEncSlice, the reference picture sets of
     the sequence start, determineCabacInitIdx feedback) and runs search -> deblocking -> SAO -> slice data -> device-resident reference on the
     device.  Everything it derives and everything the device returns must equal the reference's own run of the same clip: slice parameters,
@@ -502,7 +503,7 @@ def test_cpp_host_mirror_low_delay(tmp_path, name):
     dump = tmp_path / "dump.bin"
     exe = os.path.join(common.ROOT, "hm-16.2_amd", "hm355_encmain")
     qp0 = int(slices[0]["qp"])
-    subprocess.run([exe, str(yuv), str(w), str(h), str(cfg["bit_depth"]), str(cfg["frames"]), str(qp0), str(cfg["wpp"]), str(dump), "ldb" if name.startswith("ldb") else "ldp"], check=True)
+    subprocess.run([exe, str(yuv), str(w), str(h), str(cfg["bit_depth"]), str(cfg["frames"]), str(qp0), str(cfg["wpp"]), str(dump), "ldb" if name.startswith("ldb") else ("ra" if name.startswith("ra_") else "ldp")], check=True)
     buf = open(dump, "rb").read()
     assert buf[:4] == b"HMD3"
     off = 4 + 20
