@@ -321,6 +321,7 @@ extern "C" long long hm355_read_trace(hm355_ctx *c, unsigned long long *out, lon
 }
 #endif
 #ifdef HM355_PROFILE
+extern "C" int hm355_reset_profile(hm355_ctx *c) { return hipMemset(c->hp.prof, 0, 2 * HM_PROF_N * sizeof(unsigned long long)) == hipSuccess ? 0 : HM355_ERR_DEVICE; }
 extern "C" int hm355_read_profile(hm355_ctx *c, unsigned long long *out32)
 { return hipMemcpy(out32, c->hp.prof, 2 * HM_PROF_N * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : HM355_ERR_DEVICE; }
 #endif

@@ -115,7 +115,11 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
     HM_PAR_FOR(i, 184) { w->s[i] = src->s[i]; w->used[i] = src->used[i]; }
     HM_SYNC();
   }
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  for (int i = 0; i < HM_PROF_N; i++) { e->prof[i] = 0; e->profCnt[i] = 0; }
+#endif
   for (int a = first; a < last; a++) {
+    HM_PROF_BEGIN(e, PR_TOTAL);
     e->ctuX = a % wCtu; e->ctuY = a / wCtu; e->ctuAddr = a;
     e->cc = e->fb.coef + (size_t)a * HM_COEF_CTU;
     e->im = e->fb.imeta ? e->fb.imeta + a : (InterMeta *)0;
@@ -125,7 +129,8 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
       HM_SYNC();
     }
     if (saoOn) bits_sao_blk_param(e, w, bp->sao + (size_t)a * 105, bp->saoEnabled, e->ctuX > 0, e->ctuY > 0, maxOffQ);
-    encode_ctu(e, w, a == numCtus - 1);
+    { HM_PROF_BEGIN(e, PR_ENCCU); encode_ctu(e, w, a == numCtus - 1); HM_PROF_END(e, PR_ENCCU); }
+    HM_PROF_END(e, PR_TOTAL);
     if (wpp && a == first + 1) { // m_entropyCodingSyncContextState.loadContexts, TEncSlice.cpp:1050
       HM_SYNC();
       CabacW *dst = bp->sync + sub;
@@ -138,6 +143,9 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
       HM_SYNC();
     }
   }
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  if (hm_lane() == 0 && P->prof) for (int i = 0; i < HM_PROF_N; i++) { atomicAdd(P->prof + i, e->prof[i]); atomicAdd(P->prof + HM_PROF_N + i, e->profCnt[i]); }
+#endif
   // end of the substream (TEncSlice.cpp:1056-1072): end_of_subset_one_bit / end_of_slice_segment_flag = 1, flush, byte alignment
   enc_trm(e, w, 1);
   cabw_finish(w);

@@ -1429,11 +1429,19 @@ HM_DEV inline int hm_min_in_group(int g) { return g < 4 ? g : ((2 + (g & 1)) << 
 // wave-max, coefficient-group flags by ballot); per coefficient group the 16 levels, their significance contexts
 // and the >0 / >1 / >2 masks are produced lane-parallel, and the bins are coded by the serial context chain on
 // register-resident data (CabacR).
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+#define HM_BPROF(id) do { if (real) { const unsigned long long t_ = __builtin_readcyclecounter(); e->prof[id] += t_ - profT1; e->profCnt[id] += 1; profT1 = t_; } } while (0)
+#else
+#define HM_BPROF(id) ((void)0)
+#endif
 template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const TCoeff *coef, int n, int comp, int scanType, int tskipFlag)
 {
   HM_ENTRY(e); n = HM_UNI(n); comp = HM_UNI(comp); scanType = HM_UNI(scanType); tskipFlag = HM_UNI(tskipFlag); c = hm_uni_ptr(c); HM_ASSUME_LDS(c); coef = hm_uni_ptr(coef);
   const int chroma = comp != 0, log2n = hm_log2(n), wg = n >> 2;
   const bool real = EngOf<C>::REAL != 0;          // the arithmetic coder also needs the values of the bypass bins
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  const unsigned long long profT0 = __builtin_readcyclecounter();
+#endif
   typename EngOf<C>::R r; cabr_load(r, c);
   if (n == 4) enc_bin(e, &r, C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
@@ -1449,6 +1457,10 @@ template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const
   }
   const int scanPosLast = hm_wave_max_i(lastLocal);
   HM_SYNC();
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  if (real) { e->prof[PR_ADI] += __builtin_readcyclecounter() - profT0; e->profCnt[PR_ADI] += 1; }
+  unsigned long long profT1 = __builtin_readcyclecounter();
+#endif
   uint64_t cgMask = 0;                    // coefficient-group flags, bit = raster position of the group
   HM_LV(int32_t, vScanCG);                // raster position of the group at scan index = lane
   HM_WAVE_FOR(k) { HM_BALLOT(cgMask, k, cgFlag[k] != 0); HM_LVK(vScanCG, k) = k < wg * wg ? scanCG[k] : 0; }
@@ -1467,6 +1479,7 @@ template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const
     if (gx > 3) enc_epv(&r, (uint32_t)(px - hm_min_in_group(gx)), (gx - 2) >> 1);
     if (gy > 3) enc_epv(&r, (uint32_t)(py - hm_min_in_group(gy)), (gy - 2) >> 1);
   }
+  HM_BPROF(PR_INV);       // last position
   const int firstCtx = first_sig_ctx(n, scanType, chroma), sigOff = C_SIG + (chroma ? 28 : 0);
   const int lastScanSet = scanPosLast >> 4;
   int c1 = 1;
@@ -1490,6 +1503,7 @@ template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const
       HM_LVK(vCtx, k) = sig_ctx_inc(pattern, firstCtx, sposArr[sp], log2n, chroma);
       HM_BALLOT(nz, k, a != 0 && k < 16); HM_BALLOT(g1, k, a > 1 && k < 16); HM_BALLOT(g2, k, a > 2 && k < 16);
     }
+    HM_BPROF(PR_SATD35);  // per-group preparation
     { // significance flags; the last significant coefficient itself is implied
       int seen = isLastSet ? 1 : 0;
       for (int p = isLastSet ? top - 1 : 15; p >= 0; p--) {
@@ -1498,6 +1512,7 @@ template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const
         seen += sig;
       }
     }
+    HM_BPROF(PR_TUBLK);   // significance flags
     const int numNonZero = __builtin_popcountll(nz);
     if (numNonZero > 0) {
       const int lastNZ = 63 - __builtin_clzll(nz), firstNZ = __builtin_ctzll(nz);
@@ -1536,8 +1551,12 @@ template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const
         }
       }
     }
+    HM_BPROF(PR_CHROMA);  // levels, signs, remaining
   }
   cabr_store(r, c);
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  if (real) { e->prof[PR_FWD] += __builtin_readcyclecounter() - profT0; e->profCnt[PR_FWD] += 1; }
+#endif
 }
 
 
@@ -2129,8 +2148,14 @@ template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, C *c, int
   const CtuMeta *m = (&e->meta);
   if (e->im) { code_skip_flag(e, c, cuZ); enc_bin(e, c, C_PRED_MODE, 1); }
   if (cuDepth == 3) enc_bin(e, c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  const unsigned long long profDir0 = __builtin_readcyclecounter();
+#endif
   code_intra_dir_luma(e, c, cuZ, 1);
   code_intra_dir_chroma(e, c, cuZ);
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  if (EngOf<C>::REAL) { e->prof[PR_SAVE] += __builtin_readcyclecounter() - profDir0; e->profCnt[PR_SAVE] += 1; }
+#endif
   const TU root = tu_root(e, cuZ, cuDepth);
   TuWalk &w = e->walkOuter; walk_begin(&w, &root);
   while (w.sp >= 0) {
