@@ -302,6 +302,30 @@ def test_hip_ingest_search_output_chain_matches_oracle(built, hm):
     enc.close()
 
 
+@pytest.mark.parametrize("wpp", [0, 1])
+def test_hip_bitstream_pass_batch_matches_oracle(built, hm, wpp):
+    """six different pictures resident in six slots, one bitstream-pass launch (items = rows x pictures, row-major): every picture's
+    substreams equal the oracle's on the same search results, and equal the picture coded alone"""
+    import oracle
+    w, h, bd, qp, n = 192, 136, 8, 28, 6
+    enc = hm.Encoder(w, h, bd, wpp, max_batch=n)
+    pics = [synth.frame(w, h, bd, i, 300 + i) for i in range(n)]
+    res = enc.compress(pics, qp)
+    got = enc.encode_slices_run([dict(slice_type=2, qp=qp)] * n)
+    for i in range(n):
+        oc = np.zeros(len(res[i][1]), oracle.CTU_DTYPE)
+        for f in oc.dtype.names:
+            oc[f] = res[i][1][f]
+        want = oracle.encode_slice(w, h, bd, wpp, 2, qp, oc)
+        assert got[i][0] == want[0] and got[i][1:] == want[1:], f"picture {i} of the batch"
+    enc.close()
+    one = hm.Encoder(w, h, bd, wpp, max_batch=1)
+    one.compress([pics[3]], qp)
+    (alone,) = one.encode_slices_run([dict(slice_type=2, qp=qp)])
+    assert alone == got[3]
+    one.close()
+
+
 def test_hip_bitstream_pass_rejects_bad_parameters(hm):
     enc = hm.Encoder(128, 64, 8, 0, max_batch=1)
     with pytest.raises(RuntimeError):
