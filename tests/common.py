@@ -144,6 +144,7 @@ def ldp_slice_inputs(r, finals):
     return sp, refs
 
 
+LDP_LONG_CASES = ["ldp2gop_256x128_8b_qp34"]     # I + two low-delay GOPs: reference picture sets beyond the first GOP, a P slice on the B context table
 DBK_CASES = ["dbk_ldp_200x136_8b_qp30", "dbk_ldb_192x128_10b_qp34"]    # SAO off: 'F' record = deblocked 'S' record
 
 

@@ -113,6 +113,8 @@ LDP_CASES = [
     # B slices: random access (hierarchical GOP 8, both directions) and low-delay B (list 1 == list 0, mvd_l1_zero)
     ("ra_192x128_10b_qp32", 192, 128, 10, 9, 32, 4321, 0, "encoder_randomaccess_main10.cfg"),
     ("ldb_200x136_8b_qp30", 200, 136, 8, 4, 30, 99, 0, "encoder_lowdelay_main.cfg"),
+    # two full low-delay GOPs after the I picture (pins the C++ host mirror's reference picture sets beyond the first GOP)
+    ("ldp2gop_256x128_8b_qp34", 256, 128, 8, 9, 34, 2024),
     # deblocking pins: SAO off, so the finished picture ('F' record) is the deblocked pre-deblock reconstruction of the 'S' record
     ("dbk_ldp_200x136_8b_qp30", 200, 136, 8, 3, 30, 31, 0, "encoder_lowdelay_P_main.cfg", ("--SAO=0",)),
     ("dbk_ldb_192x128_10b_qp34", 192, 128, 10, 3, 34, 32, 0, "encoder_lowdelay_main10.cfg", ("--SAO=0",)),
@@ -198,4 +200,6 @@ if __name__ == "__main__":
             for c in CASES:
                 run_case(*c)
         for c in LDP_CASES:
+            if "--only" in sys.argv and c[0] != sys.argv[sys.argv.index("--only") + 1]:
+                continue
             run_ldp_case(*c)

@@ -119,7 +119,7 @@ def fixture_bits_args(cfg, r, sao_rec, with_sao):
                 max_merge_cand=int(r["max_merge_cand"]), sao=sao_rec["sao"] if with_sao else None, sao_enabled=tuple(sao_rec["enabled"]) if with_sao else (0, 0))
 
 
-@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES + common.DBK_CASES)
+@pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES + common.DBK_CASES + common.LDP_LONG_CASES)
 def test_oracle_bitstream_pass_matches_reference(built, name):
     """TEncSlice::encodeSlice: from the reference's own CTU decisions and SAO parameters the oracle's arithmetic coder must write the same
     substream bytes as the reference (I, P and B slices, 8 and 10 bit, one substream or one per CTU row, SAO syntax on and off), code the
