@@ -189,8 +189,9 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
 
 #ifndef HM355_HOSTSIM
 __shared__ CabacW g_cabw;
-// grid: min(numSubstreams * n, workspaces) workgroups striding over the (row, picture) items in row-major order, so that the row a
-// substream waits for always belongs to an earlier item: taken by a running workgroup, or finished
+// grid: min(numSubstreams * n, workspaces, resident workgroups) workgroups striding over the (row, picture) items in row-major order.  The
+// smallest unfinished item never waits: the row it depends on is an earlier item, hence finished, and its owner has finished its own earlier
+// items, hence is working on it -- provided every workgroup of the grid is resident, which the host guarantees when it sizes the grid.
 extern "C" __global__ void __launch_bounds__(64) hm355_bits_kernel(const Params *P, BitsParams *bps, int n)
 {
   const int numSub = P->wpp ? P->hCtu : 1, total = numSub * n;

@@ -326,6 +326,26 @@ def test_hip_bitstream_pass_batch_matches_oracle(built, hm, wpp):
     one.close()
 
 
+def test_hip_bitstream_pass_more_substreams_than_resident_workgroups(built, hm):
+    """2,720 substreams (80 pictures of 2 x 34 CTUs, WPP) in one launch: more than the workgroups the GPU keeps resident (about 2,300), with
+    the WPP hand-off between the rows of every picture -- the ticket order of the kernel must drain them; every picture against the oracle"""
+    import oracle
+    w, h, bd, qp, n = 128, 2176, 8, 36, 80
+    enc = hm.Encoder(w, h, bd, 1, max_batch=n)
+    pics = [synth.frame(w, h, bd, i % 5, 900 + i % 5) for i in range(n)]
+    res = enc.compress(pics, qp)
+    got = enc.encode_slices_run([dict(slice_type=2, qp=qp)] * n)
+    enc.close()
+    want = {}
+    for i in range(n):
+        if i % 5 not in want:
+            oc = np.zeros(len(res[i][1]), oracle.CTU_DTYPE)
+            for f in oc.dtype.names:
+                oc[f] = res[i][1][f]
+            want[i % 5] = oracle.encode_slice(w, h, bd, 1, 2, qp, oc)
+        assert len(got[i][0]) == 34 and got[i][0] == want[i % 5][0] and got[i][1:] == want[i % 5][1:], f"picture {i}"
+
+
 def test_hip_bitstream_pass_rejects_bad_parameters(hm):
     enc = hm.Encoder(128, 64, 8, 0, max_batch=1)
     with pytest.raises(RuntimeError):
