@@ -324,6 +324,14 @@ def run_ingest(args, torch):
     ms_total = ms_in + ms_out
     alg = 2 * per_pic * F * args.steps                  # ingest + output
     ach = alg / (ms_total * 1e-3) / 1e9
+    # HBM bytes per step from the committed PMC passes of this workload (profiles/r01e_traffic_ingest.json), if they match its size
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01e_traffic_ingest.json")))
+        if (tj["width"], tj["height"], tj["frames"]) == (w, h, F):
+            traffic = tj["hbm_bytes_per_step"]
+    except (OSError, KeyError, ValueError):
+        pass
     line = {"metric": "CTUs/sec (picture ingest + output, TVideoIOYuv read / write) at 4K main10; byte-exact vs HM", "value": n / (ms_total * 1e-3), "unit": "CTU/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_total / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
@@ -332,8 +340,9 @@ def run_ingest(args, torch):
                        "output_ms_per_step": ms_out / args.steps, "ingest_ms_per_step_with_pcie": 1e3 * wall_in / args.steps,
                        "output_ms_per_step_with_pcie": 1e3 * wall_out / args.steps, "roundtrip_identical": bool(ok)},
             "roofline": {"bound": "hbm", "kernel": "hm355_ingest_kernel + hm355_output_kernel (1 launch each per step)",
-                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "note": f"algorithmic bytes = {per_pic} B per picture and direction (every 16-bit sample read once + written once)"}}
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": f"algorithmic bytes = {per_pic} B per picture and direction (every 16-bit sample read once + written once) = {2 * per_pic * F} B per step; "
+                                 "traffic = PMC FETCH_SIZE (x2, gfx950 correction for 16 B/lane streams) + WRITE_SIZE of both kernels, separate passes"}}
     if not args.no_cpu_baseline:
         import oracle
         t0 = time.time()
