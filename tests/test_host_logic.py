@@ -100,7 +100,7 @@ def test_hostsim_of_kernel_source_matches_reference_fixture(tmp_path):
             assert np.array_equal(got[i][1], rec)
 
 
-@pytest.mark.parametrize("name", common.LDP_CASES[1:] + common.B_CASES)
+@pytest.mark.parametrize("name", common.LDP_CASES[1:] + common.B_CASES + common.LDP_LONG_CASES)
 def test_hostsim_of_kernel_source_matches_reference_p_slices(tmp_path, name):
     """The P-slice part of the kernel source (hm355_inter.h / hm355_inter_cu.h) compiled for the host with one lane, forwards and
     with every lane-parallel loop reversed: self-checking replay of the reference's HMD2 record stream (rebuilt from the fixture),
