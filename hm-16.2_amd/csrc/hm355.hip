@@ -802,11 +802,11 @@ extern "C" int hm355_encode_slices_run(hm355_ctx *c, int n, hm355_bits_desc *des
   HM_CHECK(c, hipStreamSynchronize(c->stream));
   HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
   // Workgroups stride over the (row, picture) items; a waiting row's predecessor must be running or done, so every workgroup of the grid has to
-  // be resident: the grid is capped at what the device keeps in flight for this kernel (with a margin), besides the number of workspaces.
+  // be resident: the grid is capped at what the device keeps in flight for this kernel, besides the number of workspaces.
   int perCu = 0, dev = 0, cus = 0;
   HM_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, hm355_bits_kernel, 64, 0));
   HM_CHECK(c, hipGetDevice(&dev)); HM_CHECK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int resident = perCu * cus * 3 / 4; if (resident < 1) resident = 1;
+  int resident = perCu * cus; if (resident < 1) resident = 1;    // nothing else runs beside this launch on the device (the stream orders the copies around it)
   const int total = numSub * n;
   int grid = total < (int)c->wsCount ? total : (int)c->wsCount; if (grid > resident) grid = resident;
   hipLaunchKernelGGL(hm355_bits_kernel, dim3(grid), dim3(64), 0, c->stream, c->dP, c->dBits, n);

@@ -115,15 +115,15 @@ HM_DEV inline void cabw_finish(CabacW *w)
   cabw_put_bits(w, w->low >> 8, 24 - w->bitsLeft);
 }
 
-// Register-resident form for code_coeff_nxn (the bulk of the bins): context states, their "coded" flags, the LPS range table and the
-// LPS transitions live in lane registers as in CabacR (4 bytes per lane, read with v_readlane), low / range / bitsLeft / the bin count
-// in scalars; only the byte output (once per 8 bits) goes through the LDS copy.
-struct CabacWR { CabacW *w; HM_LV(int32_t, st); HM_LV(int32_t, us); HM_LV(int32_t, lpsRow); HM_LV(int32_t, nlps); uint32_t low, range; int32_t bitsLeft; uint32_t bins; };
+// Register-resident form for code_coeff_nxn (the bulk of the bins): context states, the LPS range table and the LPS transitions live in lane
+// registers as in CabacR (4 bytes per lane, read with v_readlane), low / range / bitsLeft / the bin count in scalars; only the byte output
+// (once per 8 bits) goes through the LDS copy.  A state needs 7 bits: bit 7 of its byte carries the "coded" flag while it is in registers.
+struct CabacWR { CabacW *w; HM_LV(int32_t, st); HM_LV(int32_t, lpsRow); HM_LV(int32_t, nlps); uint32_t low, range; int32_t bitsLeft; uint32_t bins; };
 HM_DEV inline void cabr_load(CabacWR &r, CabacW *c)
 {
   r.w = c;
   HM_WAVE_FOR(k) {
-    HM_LVK(r.st, k) = k < 46 ? ((const int32_t *)c->s)[k] : 0; HM_LVK(r.us, k) = k < 46 ? ((const int32_t *)c->used)[k] : 0;
+    HM_LVK(r.st, k) = k < 46 ? (((const int32_t *)c->s)[k] | ((((const int32_t *)c->used)[k] & 0x01010101) << 7)) : 0;
     HM_LVK(r.lpsRow, k) = c->tabLps[k];
     HM_LVK(r.nlps, k) = c->tabNlps[k & 31];
   }
@@ -131,7 +131,7 @@ HM_DEV inline void cabr_load(CabacWR &r, CabacW *c)
 }
 HM_DEV inline void cabr_store(const CabacWR &r, CabacW *c)
 {
-  HM_WAVE_FOR(k) { if (k < 46) { ((int32_t *)c->s)[k] = HM_LVK(r.st, k); ((int32_t *)c->used)[k] = HM_LVK(r.us, k); } }
+  HM_WAVE_FOR(k) { if (k < 46) { ((int32_t *)c->s)[k] = HM_LVK(r.st, k) & 0x7f7f7f7f; ((int32_t *)c->used)[k] = (int32_t)(((uint32_t)HM_LVK(r.st, k) >> 7) & 0x01010101u); } }
   c->low = r.low; c->range = r.range; c->bitsLeft = r.bitsLeft; c->bins = r.bins;
   HM_SYNC();
 }
@@ -152,7 +152,7 @@ HM_DEV inline void cabwr_write_out(CabacWR *r)
 HM_DEV inline void enc_bin(const Shared *e, CabacWR *r, int ctx, int bin)
 {
   (void)e;
-  const int wd = HM_LV_GET(r->st, ctx >> 2), sh = (ctx & 3) * 8, s = (wd >> sh) & 0xff;
+  const int wd = HM_LV_GET(r->st, ctx >> 2), sh = (ctx & 3) * 8, s = (int)(((uint32_t)wd >> sh) & 0x7f);
   const uint32_t lps = ((uint32_t)HM_LV_GET(r->lpsRow, s >> 1) >> (((r->range >> 6) & 3) * 8)) & 0xff;
   uint32_t range = r->range - lps;
   if (bin != (s & 1)) {
@@ -162,8 +162,7 @@ HM_DEV inline void enc_bin(const Shared *e, CabacWR *r, int ctx, int bin)
   r->range = range; r->bins++;
   const int lw = HM_LV_GET(r->nlps, s >> 2);
   const int ns = (bin == (s & 1)) ? (s < 124 ? s + 2 : s) : ((lw >> ((s & 3) * 8)) & 0xff);
-  HM_LV_SET(r->st, ctx >> 2, (wd & ~(0xff << sh)) | (ns << sh));
-  HM_LV_SET(r->us, ctx >> 2, HM_LV_GET(r->us, ctx >> 2) | (1 << sh));
+  HM_LV_SET(r->st, ctx >> 2, (int32_t)(((uint32_t)wd & ~(0xffu << sh)) | ((uint32_t)(ns | 0x80) << sh)));
   if (r->bitsLeft < 12) cabwr_write_out(r);
 }
 HM_DEV inline void enc_epv(CabacWR *r, uint32_t val, int n)
