@@ -59,6 +59,39 @@ Profile : main10
 """
 
 
+DISTINCT_FRAMES = 16
+
+
+def rank_frame_numbers(rank, count=DISTINCT_FRAMES):
+    """frame numbers of the synthetic clip that rank `rank` encodes: every rank owns its own pictures (weak scaling by picture)"""
+    return [DISTINCT_FRAMES * rank + f for f in range(count)]
+
+
+def plan_steps(step_s, warmup, steps, budget_s):
+    """(warm-up, timed) steps that fit `budget_s` seconds of wall time when one step takes `step_s`; one warm-up step (the one that
+    was just timed) has already run.  The requested counts are kept whenever they fit."""
+    warmup = max(1, warmup)
+    if step_s * (warmup + steps) <= budget_s:
+        return warmup, steps
+    return 1, max(1, min(steps, int((budget_s - step_s) / max(step_s, 1e-9))))
+
+
+def _frame_job(a):
+    import synth
+    return synth.frame(*a)
+
+
+def distinct_frames(width, height, bit_depth, numbers, seed):
+    """the synthetic frames `numbers`, generated on a few host cores (call before the process touches the GPU: the pool forks)"""
+    import synth
+    jobs = [(width, height, bit_depth, f, seed) for f in numbers]
+    if len(jobs) < 4:
+        return [synth.frame(*j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(8, len(jobs), os.cpu_count() or 1)) as pool:
+        return pool.map(_frame_job, jobs)
+
+
 def cpu_baseline(width, bit_depth, qp, seed):
     """The reference's own CPU path (oracle/_ref/hm_encoder, built from /root/reference in the dev container),
     timed on a bounded sample of the same workload: the top 4 CTU rows (width x 256) of frame 0, 1 core
@@ -418,8 +451,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao", "bits", "ingest"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--budget-s", type=float, default=300.0, help="wall-time bound of warm-up + timed steps (intra4k); fewer steps run when the request does not fit")
     ap.add_argument("--frames", type=int, default=192, help="independent pictures per GPU per step")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -427,10 +461,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if "RANK" in os.environ or args.gpus < 1:
+            raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+        # started without a launcher: one rank per GPU as child processes of torch.distributed.run (nothing here has touched the GPU yet)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+    pre_frames = None
+    if args.workload == "intra4k":      # the frame pool forks: before anything initialises the GPU
+        pre_frames = distinct_frames(args.width, args.height, 10, rank_frame_numbers(rank, min(DISTINCT_FRAMES, args.frames)), 1234)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: hm355 has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -449,13 +493,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import hm355
-    import synth
     bd, seed = 10, 1234
     enc = hm355.Encoder(args.width, args.height, bd, 1, args.frames)
-    # synthetic clip: a few distinct frames, cycled over the batch slots; resident in HBM before timing
-    distinct = [synth.frame(args.width, args.height, bd, f + 16 * rank, seed) for f in range(min(4, args.frames))]
+    # synthetic clip: 16 distinct frames per rank (rank r takes frames 16r .. 16r+15), cycled over the batch slots; resident in HBM before timing
+    distinct = pre_frames
     for i in range(args.frames):
         enc.upload(i, distinct[i % len(distinct)])
+    del distinct
 
     def barrier():
         torch.cuda.synchronize()
@@ -463,42 +507,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def agree(v, op):
+        """a host value every rank must share (slowest / smallest over the ranks)"""
+        if dist is None:
+            return v
+        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    # Warm-up.  The first step is timed: when the requested warm-up + timed steps would not fit the wall budget (the driver's
+    # 600 s limit covers start-up, the steps and the CPU baseline), the warm-up stops after that step and as many timed steps
+    # run as fit (at least one); the line reports the steps actually run next to the ones requested.
+    t0 = time.perf_counter()
+    enc.run(args.frames, args.qp)
+    barrier()
+    step_s = agree(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
+    warmup, steps = plan_steps(step_s, args.warmup, args.steps, args.budget_s)
+    for _ in range(warmup - 1):
         enc.run(args.frames, args.qp)
     barrier()
     t0 = time.perf_counter()
     kernel_ms, launches = 0.0, 0
-    for _ in range(args.steps):
+    for _ in range(steps):
         ms, l = enc.run(args.frames, args.qp)   # blocking: returns after the last kernel of the step finished
         kernel_ms += ms
         launches += l
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ctus_per_rank = enc.num_ctus * args.frames * args.steps
+        dt = agree(dt, dist.ReduceOp.MAX)
+    ctus_per_rank = enc.num_ctus * args.frames * steps
     total_ctus = ctus_per_rank * world
     if rank == 0:
-        # HBM bytes per launch from the committed PMC passes of this workload (profiles/r01_traffic.json), if they match
+        # HBM bytes per launch from the committed PMC passes of this workload, if they match its size
         traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if (tj["width"], tj["height"], tj["frames"]) == (args.width, args.height, args.frames):
-                traffic = tj["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if (tj["width"], tj["height"], tj["frames"]) == (args.width, args.height, args.frames):
+                    traffic = tj["hbm_bytes_per_launch"]
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         ach = ALG_BYTES_PER_CTU * ctus_per_rank / (kernel_ms * 1e-3) / 1e9    # GB/s of the CTU-search kernel on this rank
         line = {
             "metric": "CTUs/sec (enc) at 4K main10; bit-exact CU partition vs HM",
-            "value": total_ctus / dt, "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": total_ctus / dt, "unit": "CTU/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "steps_requested": args.steps, "warmup_requested": args.warmup,
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"encoder_intra_main10, synthetic {args.width}x{args.height} 10-bit, QP {args.qp}, WaveFrontSynchro=1, "
-                                   f"{args.frames} independent I pictures per GPU per step, inputs resident in HBM",
+                                   f"{args.frames} independent I pictures per GPU per step ({min(DISTINCT_FRAMES, args.frames)} distinct frames per GPU), inputs resident in HBM",
                        "frames_per_gpu": args.frames, "ctus_per_step": enc.num_ctus * args.frames * world,
-                       "parallelism": f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture"},
+                       "parallelism": f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture",
+                       "step_budget": f"warm-up + timed steps bounded to {args.budget_s:.0f} s of wall time: {warmup}+{steps} of the requested {args.warmup}+{args.steps} steps run"},
             "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches,
@@ -508,7 +570,7 @@ def main():
         if not args.no_cpu_baseline and world >= 1:
             line["cpu_baseline"] = cpu_baseline(args.width, bd, args.qp, seed)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     enc.close()
     if dist is not None:
         dist.barrier()
