@@ -139,7 +139,7 @@ struct hm355_ctx {
   FrameBuf *dFrames;
   WorkSpace *dWs; size_t wsCount;
   WorkItem *dItems; size_t itemsCap;
-  unsigned int *dSched; unsigned int epoch;
+  unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort of the search launch; [8] ticket, [9] abort of the bitstream launch
   std::vector<Slot> slots;
   std::vector<WorkItem> items; std::vector<int> stepStart; int schedFrames;
   hipStream_t stream; hipEvent_t ev0, ev1;
@@ -763,7 +763,7 @@ extern "C" int hm355_encode_slices_run(hm355_ctx *c, int n, hm355_bits_desc *des
   const int numSub = P.wpp ? P.hCtu : 1;
   const size_t rawBytes = (size_t)c->numCtus * HM_BITS_CAP_PER_CTU;
   std::vector<FrameBuf> fbs(n); std::vector<BitsParams> bps(n);
-  c->epoch++;
+  c->epoch++; if (c->epoch == 0) c->epoch = 1;          // 0 is what a fresh flag array holds
   for (int f = 0; f < n; f++) {
     hm355_bits_desc &d = descs[f];
     if (d.slice_type < 0 || d.slice_type > 2 || d.qp < 0 || d.qp > 51 || !d.out || !d.sub_sizes) return fail(c, HM355_ERR_ARG, "bad bitstream pass parameters");
@@ -778,7 +778,7 @@ extern "C" int hm355_encode_slices_run(hm355_ctx *c, int n, hm355_bits_desc *des
     if (!sl.bitsPacked) HM_CHECK(c, hipMalloc((void **)&sl.bitsPacked, rawBytes));
     if (!sl.bitsSizes) HM_CHECK(c, hipMalloc((void **)&sl.bitsSizes, sizeof(uint32_t) * P.hCtu));
     if (!sl.bitsSync) HM_CHECK(c, hipMalloc((void **)&sl.bitsSync, sizeof(CabacW) * P.hCtu));
-    if (!sl.bitsFlag) { HM_CHECK(c, hipMalloc((void **)&sl.bitsFlag, sizeof(uint32_t) * (P.hCtu + 1))); HM_CHECK(c, hipMemset(sl.bitsFlag, 0, sizeof(uint32_t) * (P.hCtu + 1))); }
+    if (!sl.bitsFlag) { HM_CHECK(c, hipMalloc((void **)&sl.bitsFlag, sizeof(uint32_t) * P.hCtu)); HM_CHECK(c, hipMemset(sl.bitsFlag, 0, sizeof(uint32_t) * P.hCtu)); }
     fbs[f] = sl.fb; fbs[f].imeta = NULL; fbs[f].ip = NULL;
     if (d.slice_type != 2) {
       if (!sl.bitsIp) HM_CHECK(c, hipMalloc((void **)&sl.bitsIp, sizeof(InterPic)));
@@ -794,34 +794,32 @@ extern "C" int hm355_encode_slices_run(hm355_ctx *c, int n, hm355_bits_desc *des
     bp.saoEnabled[0] = d.sao_enabled[0]; bp.saoEnabled[1] = bp.saoEnabled[2] = d.sao_enabled[1];
     bp.sao = (d.sao_enabled[0] || d.sao_enabled[1]) ? (const int32_t *)sl.saoCoded : NULL;
     bp.raw = sl.bitsRaw; bp.capPerCtu = HM_BITS_CAP_PER_CTU; bp.packed = sl.bitsPacked; bp.subSizes = sl.bitsSizes;
-    bp.sync = sl.bitsSync; bp.syncFlag = sl.bitsFlag; bp.epoch = c->epoch; bp.nextInitType = d.slice_type;
+    bp.sync = sl.bitsSync; bp.syncFlag = sl.bitsFlag; bp.sched = c->dSched + 8; bp.epoch = c->epoch; bp.nextInitType = d.slice_type;
+    HM_CHECK(c, hipMemsetAsync(sl.bitsSizes, 0, sizeof(uint32_t) * P.hCtu, c->stream));     // a substream nobody coded (abandoned launch) has length 0
   }
   if (!c->dBits) HM_CHECK(c, hipMalloc((void **)&c->dBits, sizeof(BitsParams) * c->slots.size()));
   HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
   HM_CHECK(c, hipMemcpyAsync(c->dBits, bps.data(), sizeof(BitsParams) * n, hipMemcpyHostToDevice, c->stream));
   HM_CHECK(c, hipStreamSynchronize(c->stream));
   HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
-  // Workgroups stride over the (row, picture) items; a waiting row's predecessor must be running or done, so every workgroup of the grid has to
-  // be resident: the grid is capped at what the device keeps in flight for this kernel, besides the number of workspaces.
-  int perCu = 0, dev = 0, cus = 0;
-  HM_CHECK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, hm355_bits_kernel, 64, 0));
-  HM_CHECK(c, hipGetDevice(&dev)); HM_CHECK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int resident = perCu * cus; if (resident < 1) resident = 1;    // nothing else runs beside this launch on the device (the stream orders the copies around it)
+  // persistent grid, items handed out by ticket in dependency order (hm355_bits_kernel): any grid size drains, so the only bound is the number
+  // of per-workgroup scratch areas
+  HM_CHECK(c, hipMemsetAsync(c->dSched + 8, 0, 8, c->stream));          // ticket = 0, abort = 0 for this launch
   const int total = numSub * n;
-  int grid = total < (int)c->wsCount ? total : (int)c->wsCount; if (grid > resident) grid = resident;
-  hipLaunchKernelGGL(hm355_bits_kernel, dim3(grid), dim3(64), 0, c->stream, c->dP, c->dBits, n);
-  hipLaunchKernelGGL(hm355_bits_pack_kernel, dim3(numSub, n), dim3(64), 0, c->stream, c->dP, c->dBits);
+  const int grid = total < (int)c->wsCount ? total : (int)c->wsCount;
+  hipLaunchKernelGGL(hm355_bits_kernel, dim3(grid), dim3(64), 0, c->stream, c->dP, c->dBits, n, c->dSched + 8);
+  hipLaunchKernelGGL(hm355_bits_pack_kernel, dim3(numSub, n), dim3(64), 0, c->stream, c->dP, c->dBits, (const unsigned int *)(c->dSched + 8));
   HM_CHECK(c, hipGetLastError());
   HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
   HM_CHECK(c, hipStreamSynchronize(c->stream));
   float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   c->lastKernelMs = ms; c->lastLaunches = 2;
   HM_CHECK(c, hipMemcpy(bps.data(), c->dBits, sizeof(BitsParams) * n, hipMemcpyDeviceToHost));
+  unsigned int bsched[2] = {0, 0};
+  HM_CHECK(c, hipMemcpy(bsched, c->dSched + 8, sizeof(bsched), hipMemcpyDeviceToHost));
+  if (bsched[1]) return fail(c, HM355_ERR_DEVICE, "bitstream pass: a WPP hand-off wait was abandoned");
   for (int f = 0; f < n; f++) {
     hm355_bits_desc &d = descs[f]; Slot &sl = c->slots[f];
-    uint32_t abortWord = 0;
-    HM_CHECK(c, hipMemcpy(&abortWord, sl.bitsFlag + P.hCtu, 4, hipMemcpyDeviceToHost));
-    if (abortWord) { hipMemset(sl.bitsFlag + P.hCtu, 0, 4); return fail(c, HM355_ERR_DEVICE, "bitstream pass: a WPP hand-off wait was abandoned"); }
     if (bps[f].overflow) return fail(c, HM355_ERR_DEVICE, "bitstream pass: a substream outgrew its buffer");
     HM_CHECK(c, hipMemcpy(d.sub_sizes, sl.bitsSizes, sizeof(uint32_t) * numSub, hipMemcpyDeviceToHost));
     size_t tot = 0; for (int k = 0; k < numSub; k++) tot += d.sub_sizes[k];

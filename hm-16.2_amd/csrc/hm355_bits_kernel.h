@@ -13,7 +13,8 @@ struct BitsParams {                   // one picture of the batch
   uint8_t *packed;                    // the substreams back to back (hm355_bits_pack_kernel)
   uint32_t *subSizes;                 // [numSubstreams] bytes
   CabacW *sync;                       // [hCtu] contexts after the 2nd CTU of each CTU row (m_entropyCodingSyncContextState)
-  uint32_t *syncFlag;                 // [hCtu] == epoch once sync[row] is published; [hCtu] = abort word
+  uint32_t *syncFlag;                 // [hCtu] == epoch once sync[row] is published
+  uint32_t *sched;                    // per launch, shared by the pictures of the batch: [0] ticket counter, [1] abort word
   uint32_t epoch;
   int32_t nextInitType; uint32_t bins; int32_t overflow;    // results
 };
@@ -103,8 +104,8 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
       const unsigned long long t0 = wall_clock64();
       while (__hip_atomic_load(bp->syncFlag + (sub - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != bp->epoch) {
         __builtin_amdgcn_s_sleep(16);
-        if (__hip_atomic_load(bp->syncFlag + P->hCtu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 10ull * 100000000ull) {
-          __hip_atomic_store(bp->syncFlag + P->hCtu, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break;   // everybody drains
+        if (__hip_atomic_load(bp->sched + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 10ull * 100000000ull) {
+          __hip_atomic_store(bp->sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break;   // every workgroup of the launch drains
         }
       }
     }
@@ -189,26 +190,35 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
 
 #ifndef HM355_HOSTSIM
 __shared__ CabacW g_cabw;
-// grid: min(numSubstreams * n, workspaces, resident workgroups) workgroups striding over the (row, picture) items in row-major order.  The
-// smallest unfinished item never waits: the row it depends on is an earlier item, hence finished, and its owner has finished its own earlier
-// items, hence is working on it -- provided every workgroup of the grid is resident, which the host guarantees when it sizes the grid.
-extern "C" __global__ void __launch_bounds__(64) hm355_bits_kernel(const Params *P, BitsParams *bps, int n)
+// Persistent grid over the (row, picture) items, handed out by ticket in row-major order (item = row * n + picture), exactly like the search
+// kernel's scheduler: row r of a picture waits for the contexts row r-1 of the same picture publishes, which is item - n, a ticket that was
+// taken earlier by a workgroup that is running (a workgroup only takes a ticket while it runs and never waits before taking one).  The oldest
+// unfinished ticket therefore never waits, whatever the grid size and whatever else occupies the device: no residency assumption.
+// The launch owns sched[0] (ticket) and sched[1] (abort), both zeroed by the host in the stream before every launch.
+extern "C" __global__ void __launch_bounds__(64) hm355_bits_kernel(const Params *P, BitsParams *bps, int n, unsigned int *sched)
 {
+  __shared__ int curTicket;
   const int numSub = P->wpp ? P->hCtu : 1, total = numSub * n;
-  for (int item = (int)blockIdx.x; item < total; item += (int)gridDim.x) {
+  for (;;) {
+    if (threadIdx.x == 0) curTicket = (int)atomicAdd(&sched[0], 1u);
+    __syncthreads();
+    const int item = curTicket;
+    __syncthreads();                  // every lane has read the ticket before lane 0 may overwrite it
+    if (item >= total) break;
     const int sub = item / n, f = item - sub * n;
     if (bits_encode_substream(&g_sh, &g_cabw, P, f, bps + f, sub, (int)blockIdx.x)) break;
-    __syncthreads();
   }
 }
-// substreams of a picture back to back: one workgroup per (substream, picture)
-extern "C" __global__ void __launch_bounds__(64) hm355_bits_pack_kernel(const Params *P, BitsParams *bps)
+// substreams of a picture back to back: one workgroup per (substream, picture); nothing is packed after an abandoned launch
+extern "C" __global__ void __launch_bounds__(64) hm355_bits_pack_kernel(const Params *P, BitsParams *bps, const unsigned int *sched)
 {
+  if (sched[1] != 0u) return;
   const int sub = (int)blockIdx.x, wCtu = P->wCtu;
   const BitsParams *bp = bps + blockIdx.y;
+  const uint32_t cap = (uint32_t)(P->wpp ? wCtu : wCtu * P->hCtu) * bp->capPerCtu;
   uint32_t off = 0;
-  for (int k = 0; k < sub; k++) off += bp->subSizes[k];
-  const uint32_t len = bp->subSizes[sub];
+  for (int k = 0; k < sub; k++) off += bp->subSizes[k] < cap ? bp->subSizes[k] : cap;
+  uint32_t len = bp->subSizes[sub]; if (len > cap) len = cap;       // an overflowing substream is reported through bp->overflow
   const uint8_t *src = bp->raw + (size_t)(P->wpp ? sub * wCtu : 0) * bp->capPerCtu;
   for (uint32_t i = threadIdx.x; i < len; i += 64) bp->packed[off + i] = src[i];
 }
