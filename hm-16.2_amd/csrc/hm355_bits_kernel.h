@@ -197,16 +197,17 @@ __shared__ CabacW g_cabw;
 // The launch owns sched[0] (ticket) and sched[1] (abort), both zeroed by the host in the stream before every launch.
 extern "C" __global__ void __launch_bounds__(64) hm355_bits_kernel(const Params *P, BitsParams *bps, int n, unsigned int *sched)
 {
-  __shared__ int curTicket;
   const int numSub = P->wpp ? P->hCtu : 1, total = numSub * n;
   for (;;) {
-    if (threadIdx.x == 0) curTicket = (int)atomicAdd(&sched[0], 1u);
-    __syncthreads();
-    const int item = curTicket;
-    __syncthreads();                  // every lane has read the ticket before lane 0 may overwrite it
+    // the ticket travels from lane 0 to the wavefront through v_readfirstlane: a scalar value, so the scheduler loop and everything that
+    // depends on (row, picture) stay wave-uniform for the compiler as well (handing it over through LDS made the loop "divergent": see DESIGN.md)
+    int item = 0;
+    if (threadIdx.x == 0) item = (int)atomicAdd(&sched[0], 1u);
+    item = __builtin_amdgcn_readfirstlane(item);
     if (item >= total) break;
     const int sub = item / n, f = item - sub * n;
-    if (bits_encode_substream(&g_sh, &g_cabw, P, f, bps + f, sub, (int)blockIdx.x)) break;
+    if (__builtin_amdgcn_readfirstlane(bits_encode_substream(&g_sh, &g_cabw, P, f, bps + f, sub, (int)blockIdx.x))) break;
+    __syncthreads();
   }
 }
 // substreams of a picture back to back: one workgroup per (substream, picture); nothing is packed after an abandoned launch

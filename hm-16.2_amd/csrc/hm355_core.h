@@ -336,6 +336,7 @@ struct Shared {
   RqtFrame rqt[4]; uint32_t rqtRetDist[5]; double rqtRetCost[5];
   CuFrame cuf[4];
   int32_t absCoeff[16];
+  int32_t ebits[128];                  // HM_ENTROPY_BITS for per-lane lookups (hm355_simt4.h)
   int32_t rdModeList[12]; double candCost[12];
   uint8_t splitCbf[5][2];
   // results handed back by the big non-inlined stages (instead of pointers to private memory)
@@ -1928,6 +1929,8 @@ HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
   }
 }
 
+#include "hm355_simt4.h"
+
 // ------------------------------------------------------------------------------------------------
 // luma mode decision of one CU (TEncSearch::estIntraPredQT :2289-2692)
 // ------------------------------------------------------------------------------------------------
@@ -1988,6 +1991,17 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
         for (int i = 0; i < numModesForFullRD; i++) included |= (preds[j] == rdModeList[i]);
         if (!included) rdModeList[numModesForFullRD++] = preds[j];
       }
+    }
+    if (n == 4) {
+      // 4x4 PUs (NxN): every candidate with and without transform skip, one per lane (hm355_simt4.h).  The reference's closing pass
+      // with the best mode (:2566-2600) repeats the winner's evaluation unchanged -- a 4x4 TU cannot split -- and its strict "<" keeps
+      // the first result, so it is not run again.
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      simt4_luma_pu(e, t, numModesForFullRD);
+      overallDistY += e->outDistY;
+      if (pu != numPU - 1)
+        par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x, ps, ws->reco + t.y * 64 + t.x, 64, n);
+      continue;
     }
     int bestPUMode = 0; uint32_t bestPUDistY = 0; double bestPUCost = HM_MAX_DOUBLE;
     for (int pass = 0; pass <= numModesForFullRD; pass++) {
@@ -2116,6 +2130,19 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth);
   CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws; const int cuParts = 256 >> (2 * cuDepth);
   const TU t = tu_root(e, cuZ, cuDepth);
+  if (cuDepth == 3) {
+    // 8x8 CU: one 4x4 block per chroma component; unless that block tries transform skip (which chains Cb into Cr), the five modes x two
+    // components are ten independent evaluations: one per lane (hm355_simt4.h)
+    const int split = m->tr[cuZ] != 0;
+    int tsLuma = 0;
+    if (split) for (int s = 0; s < 4; s++) tsLuma += m->ts[0][cuZ + s];
+    if (!tsLuma) {
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      const uint32_t d = HM_UCALL(simt4_chroma_cu(e, split ? tu_child(&t, 0, 0) : t, cuZ));
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      return d;
+    }
+  }
   int bestMode = 0; uint32_t bestDist = 0; double bestCost = HM_MAX_DOUBLE;
   int modeList[5] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX, DM_CHROMA_IDX};       // getAllowedChromaDir, TComDataCU.cpp:1486
   for (int i = 0; i < 4; i++) if (m->dirL[cuZ] == modeList[i]) { modeList[i] = 34; break; }
@@ -2415,6 +2442,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
 #endif
   HM_PROF_BEGIN(e, PR_TOTAL);
   load_tmat(e);
+  HM_PAR_FOR(i, 128) e->ebits[i] = HM_ENTROPY_BITS[i];
   const int a = e->ctuAddr, numCtus = P->wCtu * P->hCtu;
   { // TComDataCU::initCtu, TComDataCU.cpp:357-470
     CtuMeta *m = (&e->meta);
