@@ -156,7 +156,7 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 
 // optional in-kernel cycle accounting (diagnostic build only: -DHM355_PROFILE, never in the product build)
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-#define HM_PROF_N 32
+#define HM_PROF_N 40
 #define HM_PROF_BEGIN(e, id) const unsigned long long prof_t0_##id = __builtin_readcyclecounter()
 #define HM_PROF_END(e, id) do { (e)->prof[id] += __builtin_readcyclecounter() - prof_t0_##id; (e)->profCnt[id] += 1; } while (0)
 #else
@@ -164,6 +164,7 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 #define HM_PROF_END(e, id) ((void)0)
 #endif
 enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBLK, PR_SAVE, PR_CHROMA, PR_LUMA, PR_ENCCU, PR_TOTAL,
+       PR_S4L = 32, PR_S4C, PR_D0, PR_D1, PR_D2, PR_D3, PR_NXN, PR_S8L,
        PR_ME_INT = 16, PR_ME_FRAC, PR_AMVP, PR_MRG_EST, PR_MC, PR_IRQ, PR_IRES, PR_MRG2N, PR_INTERCU, PR_INTRA_IN_P, PR_IQ_FULL, PR_IQ_FWD, PR_IQ_RDOQ, PR_IQ_BITS, PR_IQ_INV, PR_IQ_ENC };
 
 #define HM_MAX_DOUBLE 1.7e+308
@@ -1930,6 +1931,7 @@ HM_DEV inline void set_intra_result_qt(Shared *e, const TU *root)
 }
 
 #include "hm355_simt4.h"
+#include "hm355_simt8.h"
 
 // ------------------------------------------------------------------------------------------------
 // luma mode decision of one CU (TEncSearch::estIntraPredQT :2289-2692)
@@ -1949,11 +1951,10 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
     const TU t = nxn ? tu_child(&root, pu, 0) : root;
     const int z = cuZ + t.relZ;
     int numModesForFullRD = HM_INTRA_MODE_NUM_FAST[puLog2 - 1];
-    int32_t *rdModeList = e->rdModeList; double *candCost = e->candCost;
+    int32_t *rdModeList = e->rdModeList;
     { // SATD pre-selection over the 35 modes, :2360-2410
       const int r = hm_z2r(z);
       init_adi_pattern(e, 0, e->ctuX * 64 + t.x, e->ctuY * 64 + t.y, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), n / 4, 1);
-      for (int i = 0; i < numModesForFullRD; i++) candCost[i] = HM_MAX_DOUBLE;
       const Pel *org = e->fb.org[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x;
       Pel *pred = ws->pred + t.y * 64 + t.x;
       int preds[3];
@@ -1964,26 +1965,38 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       const uint8_t st0 = e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)].s[C_INTRA_LUMA];
       HM_PROF_BEGIN(e, PR_SATD35);
       if (n <= 16) satd_all_modes_small(e, org, ps, n);
-      for (int mode = 0; mode < 35; mode++) {
-        uint32_t sad;
-        if (n <= 16) sad = e->satd[mode];
-        else {
+      else {
+        for (int mode = 0; mode < 35; mode++) {
           pred_intra(e, 0, mode, n, use_filtered_refs(0, mode, n), pred, 64);
-          sad = dist_hads(org, ps, pred, 64, n, bitDepth);
+          const uint32_t sad = dist_hads(org, ps, pred, 64, n, bitDepth);
+          if (hm_lane() == 0) e->satd[mode] = sad;
         }
-        int predIdx = -1;
-        for (int i = 0; i < 3; i++) if (mode == preds[i]) predIdx = i;
-        uint64_t fb = frac0 + (uint64_t)HM_ENTROPY_BITS[st0 ^ (predIdx != -1)];
-        fb += (uint64_t)32768 * (uint64_t)(predIdx == -1 ? 5 : (predIdx ? 2 : 1));
-        const uint32_t modeBits = (uint32_t)(fb >> 15);
-        const double cost = (double)sad + (double)modeBits * e->fb.sqrtLambda;
-        // xUpdateCandList, TEncSearch.cpp:5484-5505
-        int shift = 0;
-        while (shift < numModesForFullRD && cost < candCost[numModesForFullRD - 1 - shift]) shift++;
-        if (shift != 0) {
-          for (int i = 1; i < shift; i++) { rdModeList[numModesForFullRD - i] = rdModeList[numModesForFullRD - 1 - i]; candCost[numModesForFullRD - i] = candCost[numModesForFullRD - 1 - i]; }
-          rdModeList[numModesForFullRD - shift] = mode; candCost[numModesForFullRD - shift] = cost;
+        HM_SYNC();
+      }
+      // xUpdateCandList (TEncSearch.cpp:5484-5505) over the 35 modes in order keeps the numModesForFullRD cheapest, a mode going behind
+      // the equally cheap ones already listed: the list is the modes sorted by (cost, mode number), cut off.  One lane per mode
+      // computes its cost and its rank among all of them.
+      {
+        HM_LV(double, vCost);
+        HM_WAVE_FOR(k) {
+          double cost = HM_MAX_DOUBLE;
+          if (k < 35) {
+            int predIdx = -1;
+            for (int i = 0; i < 3; i++) if (k == preds[i]) predIdx = i;
+            uint64_t fb = frac0 + (uint64_t)HM_ENTROPY_BITS[st0 ^ (predIdx != -1)];
+            fb += (uint64_t)32768 * (uint64_t)(predIdx == -1 ? 5 : (predIdx ? 2 : 1));
+            const uint32_t modeBits = (uint32_t)(fb >> 15);
+            cost = (double)e->satd[k] + (double)modeBits * e->fb.sqrtLambda;
+          }
+          HM_LVK(vCost, k) = cost;
         }
+        HM_WAVE_FOR(k) {
+          const double ck = HM_LVK(vCost, k);
+          int rank = 0;
+          for (int j = 0; j < 35; j++) { const double cj = HM_LV_GETD(vCost, j); rank += (cj < ck || (cj == ck && j < k)) ? 1 : 0; }
+          if (k < 35 && rank < numModesForFullRD) rdModeList[rank] = k;
+        }
+        HM_SYNC();
       }
       HM_PROF_END(e, PR_SATD35);
       for (int j = 0; j < numMpm; j++) { // numCand = *piMode quirk, TEncSearch.cpp:2415-2420
@@ -1997,14 +2010,26 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       // with the best mode (:2566-2600) repeats the winner's evaluation unchanged -- a 4x4 TU cannot split -- and its strict "<" keeps
       // the first result, so it is not run again.
       cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
-      simt4_luma_pu(e, t, numModesForFullRD);
+      { HM_PROF_BEGIN(e, PR_S4L); simt4_luma_pu(e, t, numModesForFullRD); HM_PROF_END(e, PR_S4L); }
       overallDistY += e->outDistY;
       if (pu != numPU - 1)
         par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + t.y) * ps + e->ctuX * 64 + t.x, ps, ws->reco + t.y * 64 + t.x, 64, n);
       continue;
     }
     int bestPUMode = 0; uint32_t bestPUDistY = 0; double bestPUCost = HM_MAX_DOUBLE;
-    for (int pass = 0; pass <= numModesForFullRD; pass++) {
+    int firstPass = 0;
+    if (n == 8) {
+      // 8x8 PU (2Nx2N CU of the smallest size): the first pass over the candidates only ranks them -- each is one unsplit 8x8 transform
+      // block from the same snapshot -- so it runs with the candidates in lanes (hm355_simt8.h) and only the closing pass with the full
+      // residual quadtree follows.  That pass starts with the very evaluation the winner had in the first pass, so its result is
+      // the first-pass result or better, and is taken as the reference takes it (:2566-2600).
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      HM_PROF_BEGIN(e, PR_S8L);
+      bestPUMode = HM_UCALL(simt8_luma_first_pass(e, t, numModesForFullRD));
+      HM_PROF_END(e, PR_S8L);
+      firstPass = numModesForFullRD;
+    }
+    for (int pass = firstPass; pass <= numModesForFullRD; pass++) {
       const int last = (pass == numModesForFullRD);
       const int orgMode = last ? bestPUMode : rdModeList[pass];
       par_set8(m->dirL + z, orgMode, puParts);
@@ -2138,7 +2163,9 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
     if (split) for (int s = 0; s < 4; s++) tsLuma += m->ts[0][cuZ + s];
     if (!tsLuma) {
       cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      HM_PROF_BEGIN(e, PR_S4C);
       const uint32_t d = HM_UCALL(simt4_chroma_cu(e, split ? tu_child(&t, 0, 0) : t, cuZ));
+      HM_PROF_END(e, PR_S4C);
       cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
       return d;
     }
@@ -2284,6 +2311,9 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize);
   CtuMeta *m = (&e->meta); const int parts = 256 >> (2 * cuDepth);
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  const unsigned long long profCu0 = __builtin_readcyclecounter();
+#endif
   init_est_data(e, cuZ, cuDepth);
   HM_PAR_FOR(i, parts) { m->part[cuZ + i] = (uint8_t)partSize; m->pred[cuZ + i] = MODE_INTRA; }
   HM_SYNC();
@@ -2300,6 +2330,9 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
   cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
   e->outBits = num_bits(&e->cur); e->outDist = d;
   e->outCost = calc_rd_cost(e, e->outBits, e->outDist);
+#if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
+  { const int pid = partSize == SIZE_NxN ? PR_NXN : PR_D0 + cuDepth; e->prof[pid] += __builtin_readcyclecounter() - profCu0; e->profCnt[pid] += 1; }
+#endif
 }
 
 
