@@ -76,6 +76,15 @@ def plan_steps(step_s, warmup, steps, budget_s):
     return 1, max(1, min(steps, int((budget_s - step_s) / max(step_s, 1e-9))))
 
 
+def agree_over_ranks(dist, torch, v, op, device):
+    """a host value every rank must share: all-reduce with `op` (MAX for times: the slowest rank's clock counts)"""
+    if dist is None:
+        return v
+    t = torch.tensor([float(v)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=op)
+    return float(t.item())
+
+
 def _frame_job(a):
     import synth
     return synth.frame(*a)
@@ -508,12 +517,7 @@ def main():
         torch.cuda.synchronize()
 
     def agree(v, op):
-        """a host value every rank must share (slowest / smallest over the ranks)"""
-        if dist is None:
-            return v
-        t = torch.tensor([float(v)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=op)
-        return float(t.item())
+        return agree_over_ranks(dist, torch, v, op, "cuda")
 
     # Warm-up.  The first step is timed: when the requested warm-up + timed steps would not fit the wall budget (the driver's
     # 600 s limit covers start-up, the steps and the CPU baseline), the warm-up stops after that step and as many timed steps

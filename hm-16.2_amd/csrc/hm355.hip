@@ -141,7 +141,7 @@ struct hm355_ctx {
   WorkItem *dItems; size_t itemsCap;
   unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort of the search launch; [8] ticket, [9] abort of the bitstream launch
   std::vector<Slot> slots;
-  std::vector<WorkItem> items; std::vector<int> stepStart; int schedFrames;
+  std::vector<WorkItem> items; std::vector<int> stepStart; long long schedKey;
   hipStream_t stream; hipEvent_t ev0, ev1;
   double lastKernelMs; int lastLaunches;
   std::string err;
@@ -178,7 +178,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
-  c->cfg = *cfg; c->schedFrames = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
+  c->cfg = *cfg; c->schedKey = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
   c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
@@ -262,23 +262,23 @@ extern "C" int hm355_upload(hm355_ctx *c, int slot, const hm355_planes *org)
   return HM355_OK;
 }
 
-extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
+// the search over CTU rows [row0, row1] of the pictures in slots [slot0, slot0 + n); rows above row0 hold finished (or imported) CTUs
+static int run_rows_impl(hm355_ctx *c, int slot0, int n, const hm355_slice_desc *slices, int row0, int row1)
 {
-  if (!c || !slices || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
   const Params &P = c->hp;
   std::vector<FrameBuf> fbs(n);
   for (int f = 0; f < n; f++) {
     if (slices[f].slice_type != 2) return fail(c, HM355_ERR_ARG, "only I slices are supported");
     if (slices[f].qp < 0 || slices[f].qp > 51 || !(slices[f].lambda > 0) || !(slices[f].chroma_weight > 0)) return fail(c, HM355_ERR_ARG, "bad slice parameters");
-    hm355_fill_slice_params(&c->slots[f].fb, P.bitDepth, slices[f].qp, slices[f].lambda, slices[f].chroma_weight);
-    fbs[f] = c->slots[f].fb;
+    hm355_fill_slice_params(&c->slots[slot0 + f].fb, P.bitDepth, slices[f].qp, slices[f].lambda, slices[f].chroma_weight);
+    fbs[f] = c->slots[slot0 + f].fb;
   }
-  HM_CHECK(c, hipMemcpyAsync(c->dFrames, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipMemcpyAsync(c->dFrames + slot0, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
   int carry = 0;
-  for (int f = 0; f < n; f++) carry |= c->slots[f].fb.imeta != NULL && (P.height & 63) != 0;
-  const int schedKey = n * 2 + carry;
-  if (c->schedFrames != schedKey) {
-    hm355_build_schedule(P.wCtu, P.hCtu, P.wpp, n, c->items, c->stepStart, carry);
+  for (int f = 0; f < n; f++) carry |= c->slots[slot0 + f].fb.imeta != NULL && (P.height & 63) != 0;
+  const long long schedKey = ((((long long)slot0 * 4096 + n) * 2 + carry) * 1024 + row0) * 1024 + row1;
+  if (c->schedKey != schedKey) {
+    hm355_build_schedule(P.wCtu, P.hCtu, P.wpp, n, c->items, c->stepStart, carry, slot0, row0, row1);
     if (c->items.size() > c->itemsCap) {
       if (c->dItems) hipFree(c->dItems);
       c->dItems = NULL; c->itemsCap = 0;
@@ -286,10 +286,12 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
       c->itemsCap = c->items.size();
     }
     HM_CHECK(c, hipMemcpyAsync(c->dItems, c->items.data(), sizeof(WorkItem) * c->items.size(), hipMemcpyHostToDevice, c->stream));
-    c->schedFrames = schedKey;
+    c->schedKey = schedKey;
   }
   c->epoch++; if (c->epoch == 0) c->epoch = 1;
   HM_CHECK(c, hipMemsetAsync(c->dSched, 0, 64, c->stream));        // ticket = 0, abort = 0
+  if (row0 > 0)    // the row above the band is complete: its CTUs count as published in this run
+    for (int f = 0; f < n; f++) HM_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(c->slots[slot0 + f].fb.done + (size_t)(row0 - 1) * P.wCtu), (int)c->epoch, P.wCtu, c->stream));
   HM_CHECK(c, hipStreamSynchronize(c->stream));   // fbs / items must stay valid until copied
   HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
   const int total = (int)c->items.size();
@@ -306,6 +308,52 @@ extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
   c->lastKernelMs = ms; c->lastLaunches = launches;
   return HM355_OK;
 }
+
+extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
+{
+  if (!c || !slices || n < 1 || n > (int)c->slots.size()) return HM355_ERR_ARG;
+  return run_rows_impl(c, 0, n, slices, 0, c->hp.hCtu - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CTU-row bands: one device searches rows [first_row, last_row] of its pictures; what the band below needs from the
+// band's last row travels through hm355_export_boundary / hm355_import_boundary (host buffers; the transport is the caller's)
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm355_run_rows(hm355_ctx *c, int first_slot, int n, const hm355_slice_desc *slices, int first_row, int last_row)
+{
+  if (!c || !slices || n < 1 || first_slot < 0 || first_slot + n > (int)c->slots.size()) return HM355_ERR_ARG;
+  if (first_row < 0 || last_row < first_row || last_row >= c->hp.hCtu) return fail(c, HM355_ERR_ARG, "hm355_run_rows: bad row range");
+  if (first_row > 0 && !c->hp.wpp) return fail(c, HM355_ERR_ARG, "hm355_run_rows: a band below the first row needs WaveFrontSynchro=1 (without it the CABAC state chains through every CTU)");
+  for (int f = 0; f < n; f++) if (c->slots[first_slot + f].fb.imeta) return fail(c, HM355_ERR_ARG, "hm355_run_rows: I slices only");
+  return run_rows_impl(c, first_slot, n, slices, first_row, last_row);
+}
+// bytes of one picture's boundary row: the bottom sample line of the three planes, the decision arrays and the CABAC state after each CTU of the row
+extern "C" size_t hm355_boundary_bytes(const hm355_ctx *c)
+{
+  if (!c) return 0;
+  const Params &P = c->hp;
+  return (size_t)(P.stride[0] + P.stride[1] + P.stride[2]) * sizeof(Pel) + (size_t)P.wCtu * (sizeof(CtuMeta) + sizeof(Cabac));
+}
+static int boundary_copy(hm355_ctx *c, int slot, int row, void *buf, int toHost)
+{
+  if (!c || !buf || slot < 0 || slot >= (int)c->slots.size() || row < 0 || row >= c->hp.hCtu) return HM355_ERR_ARG;
+  const Params &P = c->hp; FrameBuf &fb = c->slots[slot].fb;
+  uint8_t *p = (uint8_t *)buf;
+  const hipMemcpyKind kind = toHost ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+  for (int k = 0; k < 3; k++) {         // the line right above the next CTU row: all that intra prediction reads across the boundary (TComPattern.cpp:107-165)
+    Pel *line = fb.rec[k] + ((size_t)(row + 1) * (k ? 32 : 64) - 1) * P.stride[k];
+    const size_t bytes = (size_t)P.stride[k] * sizeof(Pel);
+    HM_CHECK(c, toHost ? hipMemcpy(p, line, bytes, kind) : hipMemcpy(line, p, bytes, kind));
+    p += bytes;
+  }
+  CtuMeta *meta = fb.meta + (size_t)row * P.wCtu; Cabac *es = fb.endState + (size_t)row * P.wCtu;
+  HM_CHECK(c, toHost ? hipMemcpy(p, meta, sizeof(CtuMeta) * P.wCtu, kind) : hipMemcpy(meta, p, sizeof(CtuMeta) * P.wCtu, kind));
+  p += sizeof(CtuMeta) * P.wCtu;
+  HM_CHECK(c, toHost ? hipMemcpy(p, es, sizeof(Cabac) * P.wCtu, kind) : hipMemcpy(es, p, sizeof(Cabac) * P.wCtu, kind));
+  return HM355_OK;
+}
+extern "C" int hm355_export_boundary(hm355_ctx *c, int slot, int row, void *buf) { return boundary_copy(c, slot, row, buf, 1); }
+extern "C" int hm355_import_boundary(hm355_ctx *c, int slot, int row, const void *buf) { return boundary_copy(c, slot, row, (void *)buf, 0); }
 
 #if defined(HM355_TRACE)
 // diagnostic build only: copies and resets the RD-evaluation trace (3 words per record), returns the record count

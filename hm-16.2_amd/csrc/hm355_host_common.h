@@ -90,15 +90,17 @@ static inline int hm355_schedule_step(int wCtu, int hCtu, int wpp, int carryLast
   if (carryLastRow && hCtu > 1 && wCtu > 1 && y == hCtu - 1) return (wCtu - 1) + 2 * (hCtu - 2) + 1 + x;
   return x + 2 * y;
 }
-static inline void hm355_build_schedule(int wCtu, int hCtu, int wpp, int nFrames, std::vector<WorkItem> &items, std::vector<int> &stepStart, int carryLastRow = 0)
-{
+static inline void hm355_build_schedule(int wCtu, int hCtu, int wpp, int nFrames, std::vector<WorkItem> &items, std::vector<int> &stepStart, int carryLastRow = 0,
+                                        int firstFrame = 0, int firstRow = 0, int lastRow = -1)
+{ // rows [firstRow, lastRow] of the pictures in slots [firstFrame, firstFrame + nFrames): a band of CTU rows (the rows above it are complete)
   items.clear(); stepStart.clear();
+  if (lastRow < 0) lastRow = hCtu - 1;
   const int steps = hm355_schedule_step(wCtu, hCtu, wpp, carryLastRow, wCtu - 1, hCtu - 1) + 1;
   std::vector<std::vector<WorkItem> > bucket(steps);
-  for (int y = 0; y < hCtu; y++) for (int x = 0; x < wCtu; x++) { WorkItem w = {0, x, y, 0}; bucket[hm355_schedule_step(wCtu, hCtu, wpp, carryLastRow, x, y)].push_back(w); }
+  for (int y = firstRow; y <= lastRow; y++) for (int x = 0; x < wCtu; x++) { WorkItem w = {0, x, y, 0}; bucket[hm355_schedule_step(wCtu, hCtu, wpp, carryLastRow, x, y)].push_back(w); }
   for (int s = 0; s < steps; s++) {
     stepStart.push_back((int)items.size());
-    for (int f = 0; f < nFrames; f++) for (size_t i = 0; i < bucket[s].size(); i++) { WorkItem w = bucket[s][i]; w.frame = f; items.push_back(w); }
+    for (int f = 0; f < nFrames; f++) for (size_t i = 0; i < bucket[s].size(); i++) { WorkItem w = bucket[s][i]; w.frame = firstFrame + f; items.push_back(w); }
   }
   stepStart.push_back((int)items.size());
 }

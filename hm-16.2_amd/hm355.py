@@ -80,7 +80,7 @@ EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_
            "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_sao_run",
            "hm355_num_substreams", "hm355_encode_slices_run", "hm355_encode_slice",
            "hm355_upload_file_frames", "hm355_download_file_frames", "hm355_download_org",
-           "hm355_upload", "hm355_run", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
+           "hm355_upload", "hm355_run", "hm355_run_rows", "hm355_boundary_bytes", "hm355_export_boundary", "hm355_import_boundary", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
 
@@ -98,6 +98,11 @@ def load_library(path=LIB_PATH):
     lib.hm355_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes)]
     lib.hm355_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SliceDesc)]
     lib.hm355_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes), C.c_void_p, C.POINTER(SliceStats)]
+    lib.hm355_run_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(SliceDesc), C.c_int, C.c_int]
+    lib.hm355_boundary_bytes.argtypes = [C.c_void_p]
+    lib.hm355_boundary_bytes.restype = C.c_size_t
+    lib.hm355_export_boundary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.hm355_import_boundary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.hm355_last_run_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.hm355_compress_slice.argtypes = [C.c_void_p, C.POINTER(SliceDesc), C.POINTER(Planes), C.POINTER(Planes), C.c_void_p,
                                          C.POINTER(SliceStats)]
@@ -183,6 +188,29 @@ class Encoder:
         ms, launches = C.c_double(), C.c_int()
         self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
         return ms.value, launches.value
+
+    def run_rows(self, first_slot, n, qp, first_row, last_row):
+        """the search over CTU rows [first_row, last_row] of the pictures in slots [first_slot, first_slot + n) (a band; see hm355_run_rows)"""
+        lam, cw = intra_lambda(qp)
+        sl = (SliceDesc * n)(*[SliceDesc(2, qp, lam, cw) for _ in range(n)])
+        self._check(self.lib.hm355_run_rows(self.h_, first_slot, n, sl, first_row, last_row), "hm355_run_rows")
+        ms, launches = C.c_double(), C.c_int()
+        self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
+        return ms.value, launches.value
+
+    def boundary_bytes(self):
+        return int(self.lib.hm355_boundary_bytes(self.h_))
+
+    def export_boundary(self, slot, row):
+        """what the band below needs from CTU row `row` of the picture in `slot`, as a uint8 array"""
+        buf = np.empty(self.boundary_bytes(), np.uint8)
+        self._check(self.lib.hm355_export_boundary(self.h_, slot, row, buf.ctypes.data), "hm355_export_boundary")
+        return buf
+
+    def import_boundary(self, slot, row, data):
+        buf = np.ascontiguousarray(data, np.uint8)
+        assert buf.size == self.boundary_bytes()
+        self._check(self.lib.hm355_import_boundary(self.h_, slot, row, buf.ctypes.data), "hm355_import_boundary")
 
     def download(self, slot, want_ctus=True):
         rec = [np.zeros((self.h, self.w), np.uint16), np.zeros((self.h // 2, self.w // 2), np.uint16),

@@ -42,7 +42,7 @@ typedef struct {
 /* Slice-level parameters: what TEncSlice::initEncSlice / setUpLambda (TEncSlice.cpp:132-159,180-481)
  * push into TComRdCost / TComTrQuant before compressSlice runs. */
 typedef struct {
-  int32_t slice_type;             /* 2 = I_SLICE (only value supported this round) */
+  int32_t slice_type;             /* 2 = I_SLICE in the I-slice entry points; the inter entry points (hm355_inter_slice_desc::base) take 1 = P_SLICE or 0 = B_SLICE */
   int32_t qp;                     /* TComSlice::getSliceQp() */
   double  lambda;                 /* TComRdCost::m_dLambda */
   double  chroma_weight;          /* TComRdCost::m_distortionWeight[Cb]==[Cr] */
@@ -203,6 +203,19 @@ int hm355_download_org(hm355_ctx *ctx, int slot, hm355_planes *org);
 int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */
 int hm355_run(hm355_ctx *ctx, int n, const hm355_slice_desc *slices);         /* slots [0,n) -> results in HBM; blocking */
 int hm355_download(hm355_ctx *ctx, int slot, hm355_planes *rec, hm355_ctu_out *ctus, hm355_slice_stats *stats);
+
+/* CTU-row bands (TEncSlice.cpp:740-755,855-858 are the WPP hand-off points a band boundary cuts through): a picture is
+ * searched by several devices, each owning a band of whole CTU rows [first_row, last_row] of the pictures in slots
+ * [first_slot, first_slot + n) (WaveFrontSynchro=1, I slices).  The rows above first_row must be complete in the slot: searched by an
+ * earlier hm355_run_rows on this context, or -- the row right above -- brought in with hm355_import_boundary from the device that owns it.
+ * hm355_export_boundary copies out what the band below reads from CTU row `row`: the bottom sample line of the three planes (intra
+ * reference samples, TComPattern.cpp:107-165), the CTUs' decision arrays (split-flag contexts, TComDataCU.cpp:1587) and the CABAC
+ * state after each CTU (the WPP synchronisation source, TEncSlice.cpp:855-858); hm355_boundary_bytes() bytes per picture.  The buffers
+ * are host memory: the transport between devices (RCCL send / recv in bench.py and hm-16.2_amd/bands.py) is the caller's. */
+int hm355_run_rows(hm355_ctx *ctx, int first_slot, int n, const hm355_slice_desc *slices, int first_row, int last_row);
+size_t hm355_boundary_bytes(const hm355_ctx *ctx);
+int hm355_export_boundary(hm355_ctx *ctx, int slot, int row, void *buf);
+int hm355_import_boundary(hm355_ctx *ctx, int slot, int row, const void *buf);
 /* kernel time of the last hm355_run in milliseconds, measured with HIP events on the launch stream,
  * and the number of kernel launches it took */
 int hm355_last_run_info(const hm355_ctx *ctx, double *kernel_ms, int *launches);

@@ -1,56 +1,59 @@
-"""CPU suite: the N>1 path of bench.py -- pictures sharded over ranks, barrier + max-over-ranks timing --
-rehearsed with world_size 2 on the gloo backend (no GPU).  The per-rank work is replaced by the oracle on a
-tiny picture; what is under test is the sharding (disjoint frame ranges, whole-job aggregation)."""
+"""CPU suite: the N>1 paths of the product -- bench.py's picture replicas (rank partition, one step plan for all ranks,
+max-over-ranks time) and the CTU-row band pipeline of hm-16.2_amd/bands.py with its torch.distributed transport -- run with
+world_size 2 (and 3) on the gloo backend.  tests/mp_worker.py drives that product code around a recording engine; the GPU
+side of the same pipeline is tests/test_gpu_parity.py::test_hip_row_bands_match_unsplit_picture."""
+import json
 import os
 import subprocess
 import sys
-import textwrap
+
+import pytest
 
 import common
 
-WORKER = textwrap.dedent("""
-    import os, sys, time, json
-    sys.path[:0] = [r"{root}", r"{root}/hm-16.2_amd", r"{root}/oracle"]
-    import numpy as np, torch, torch.distributed as dist
-    import oracle, synth
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
-    frames_per_rank, w, h, bd, qp = 2, 64, 64, 8, 32
-    # weak scaling: rank r owns pictures [r*F, (r+1)*F) -- no data-path collective
-    mine = [synth.frame(w, h, bd, rank * frames_per_rank + i, 1234) for i in range(frames_per_rank)]
-    dist.barrier(); t0 = time.perf_counter()
-    bits = 0
-    for p in mine:
-        rec, ctus = oracle.compress(p, bd, qp, 1)
-        bits += int(ctus["total_bits"].sum())
-    dist.barrier(); dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    b = torch.tensor([bits], dtype=torch.int64); gathered = [torch.zeros_like(b) for _ in range(world)]; dist.all_gather(gathered, b)
-    if rank == 0:
-        print(json.dumps({{"max_dt": float(t.item()), "bits": [int(x.item()) for x in gathered], "ctus": world * frames_per_rank}}))
-    dist.destroy_process_group()
-""")
 
-
-def test_two_rank_sharding_with_gloo(built, tmp_path):
-    import json
-    import synth
-    import oracle
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=common.ROOT))
+def _run(world, port):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29533", str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-    assert out.returncode == 0, out.stderr.decode()[-2000:]
-    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["ctus"] == 4 and res["max_dt"] > 0
-    # every rank encoded ITS OWN pictures: the per-rank bit totals equal a single-process run of the same frames
-    want = []
-    for r in range(2):
-        bits = 0
-        for i in range(2):
-            _, ctus = oracle.compress(synth.frame(64, 64, 8, r * 2 + i, 1234), 8, 32, 1)
-            bits += int(ctus["total_bits"].sum())
-        want.append(bits)
-    assert res["bits"] == want
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(common.ROOT, "tests", "mp_worker.py")],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    return json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("world,port", [(2, 29533), (3, 29534)])
+def test_ranks_with_gloo(world, port):
+    import bands
+    import bench
+    res = _run(world, port)
+    # replicas: every rank its own 16 frames, nothing shared; all ranks run the plan of the slowest one
+    flat = [f for fr in res["frames"] for f in fr]
+    assert len(flat) == 16 * world == len(set(flat))
+    assert res["step_s"] == 10.0 + world - 1
+    assert all(tuple(p) == bench.plan_steps(res["step_s"], 5, 20, 300.0) for p in res["plans"])
+    # bands: the rows of every picture are covered exactly once, top to bottom, and every rank searched all 7 pictures in groups of 3
+    covered = []
+    for r, ((first, last), searched, launches, ms) in enumerate(res["bands"]):
+        assert (first, last) == bands.band_rows(5, world, r)
+        covered += list(range(first, last + 1))
+        assert searched == list(range(7)) and [tuple(l) for l in launches] == [(0, 3), (3, 3), (6, 1)] and ms == 3.0
+    assert covered == list(range(5))
+
+
+@pytest.mark.parametrize("h_ctu,world", [(34, 8), (34, 1), (4, 2), (5, 3), (3, 8), (17, 4)])
+def test_band_partition(h_ctu, world):
+    import bands
+    rows = []
+    for r in range(world):
+        first, last = bands.band_rows(h_ctu, world, r)
+        rows += list(range(first, last + 1))
+        assert last - first + 1 in (h_ctu // world, h_ctu // world + 1, 0)
+    assert rows == list(range(h_ctu))
+
+
+def test_step_plan():
+    import bench
+    assert bench.plan_steps(1.0, 5, 20, 300.0) == (5, 20)                # fits: as requested
+    assert bench.plan_steps(43.5, 5, 20, 300.0) == (1, 5)                # the driver's command on the round-1 kernel
+    assert bench.plan_steps(400.0, 5, 20, 300.0) == (1, 1)               # always at least one timed step
+    assert bench.plan_steps(1.0, 0, 3, 300.0) == (1, 3)                  # the timed first step is the warm-up
