@@ -462,6 +462,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shard", default="pictures", choices=["pictures", "rows"],
+                    help="N > 1: 'pictures' = every rank its own pictures (weak scaling, no data-path transfer; default); 'rows' = every rank a band of CTU rows "
+                         "of the SAME pictures, boundary rows handed down over RCCL send / recv (hm-16.2_amd/bands.py; strong scaling)")
+    ap.add_argument("--group", type=int, default=0, help="--shard rows: pictures per pipeline stage (default: frames / (4 * ranks))")
     ap.add_argument("--budget-s", type=float, default=300.0, help="wall-time bound of warm-up + timed steps (intra4k); fewer steps run when the request does not fit")
     ap.add_argument("--frames", type=int, default=192, help="independent pictures per GPU per step")
     ap.add_argument("--width", type=int, default=3840)
@@ -481,8 +485,9 @@ def main():
                "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd).returncode)
     pre_frames = None
+    rows_mode = args.shard == "rows" and world > 1
     if args.workload == "intra4k":      # the frame pool forks: before anything initialises the GPU
-        pre_frames = distinct_frames(args.width, args.height, 10, rank_frame_numbers(rank, min(DISTINCT_FRAMES, args.frames)), 1234)
+        pre_frames = distinct_frames(args.width, args.height, 10, rank_frame_numbers(0 if rows_mode else rank, min(DISTINCT_FRAMES, args.frames)), 1234)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: hm355 has no CPU fallback")
@@ -522,26 +527,43 @@ def main():
     # Warm-up.  The first step is timed: when the requested warm-up + timed steps would not fit the wall budget (the driver's
     # 600 s limit covers start-up, the steps and the CPU baseline), the warm-up stops after that step and as many timed steps
     # run as fit (at least one); the line reports the steps actually run next to the ones requested.
+    if rows_mode:
+        # every rank holds the same pictures and searches its band of CTU rows; the last row of a band goes down to the next rank (RCCL send / recv)
+        import bands
+        h_ctu = (args.height + 63) // 64
+        transport = bands.TorchTransport(dist, torch, torch.device("cuda", local_rank))
+        group = args.group or max(1, args.frames // (4 * world))
+
+        def one_step():
+            return bands.run_banded(enc, args.frames, group, h_ctu, rank, world, transport.send, transport.recv, args.qp), len(bands.picture_groups(args.frames, group))
+    else:
+        def one_step():
+            return enc.run(args.frames, args.qp)   # blocking: returns after the last kernel of the step finished
     t0 = time.perf_counter()
-    enc.run(args.frames, args.qp)
+    one_step()
     barrier()
     step_s = agree(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
     warmup, steps = plan_steps(step_s, args.warmup, args.steps, args.budget_s)
     for _ in range(warmup - 1):
-        enc.run(args.frames, args.qp)
+        one_step()
     barrier()
     t0 = time.perf_counter()
     kernel_ms, launches = 0.0, 0
     for _ in range(steps):
-        ms, l = enc.run(args.frames, args.qp)   # blocking: returns after the last kernel of the step finished
+        ms, l = one_step()
         kernel_ms += ms
         launches += l
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         dt = agree(dt, dist.ReduceOp.MAX)
-    ctus_per_rank = enc.num_ctus * args.frames * steps
-    total_ctus = ctus_per_rank * world
+    if rows_mode:      # the ranks share the pictures: the job is args.frames pictures per step whatever the number of ranks
+        first_row, last_row = bands.band_rows(h_ctu, world, rank)
+        ctus_per_rank = ((args.width + 63) // 64) * max(0, last_row - first_row + 1) * args.frames * steps
+        total_ctus = enc.num_ctus * args.frames * steps
+    else:
+        ctus_per_rank = enc.num_ctus * args.frames * steps
+        total_ctus = ctus_per_rank * world
     if rank == 0:
         # HBM bytes per launch from the committed PMC passes of this workload, if they match its size
         traffic = None
@@ -558,12 +580,14 @@ def main():
             "metric": "CTUs/sec (enc) at 4K main10; bit-exact CU partition vs HM",
             "value": total_ctus / dt, "unit": "CTU/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "steps_requested": args.steps, "warmup_requested": args.warmup,
-            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None,
             "dtype": "int32+f64", "data": "synthetic",
             "config": {"workload": f"encoder_intra_main10, synthetic {args.width}x{args.height} 10-bit, QP {args.qp}, WaveFrontSynchro=1, "
-                                   f"{args.frames} independent I pictures per GPU per step ({min(DISTINCT_FRAMES, args.frames)} distinct frames per GPU), inputs resident in HBM",
-                       "frames_per_gpu": args.frames, "ctus_per_step": enc.num_ctus * args.frames * world,
-                       "parallelism": f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture",
+                                   (f"{args.frames} independent I pictures per step shared by the ranks" if rows_mode else f"{args.frames} independent I pictures per GPU per step") +
+                                   f" ({min(DISTINCT_FRAMES, args.frames)} distinct frames), inputs resident in HBM",
+                       "frames_per_gpu": args.frames, "ctus_per_step": total_ctus // steps,
+                       "parallelism": (f"CTU rows of every picture sharded over {world} GPUs in bands, boundary rows handed down over RCCL send / recv, {group} pictures per pipeline stage"
+                                       if rows_mode else f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture"),
                        "step_budget": f"warm-up + timed steps bounded to {args.budget_s:.0f} s of wall time: {warmup}+{steps} of the requested {args.warmup}+{args.steps} steps run"},
             "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

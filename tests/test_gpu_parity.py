@@ -486,6 +486,86 @@ def test_hip_row_bands_match_unsplit_picture(hm, name, world, copies, group):
         enc.close()
 
 
+@pytest.mark.parametrize("kind,w,h,bd,nref", [("P", 1920, 1080, 8, 4), ("B", 3840, 2160, 10, 2)])
+def test_full_size_inter_properties(built, hm, kind, w, h, bd, nref):
+    """BASELINE.json configs[2] (encoder_lowdelay_P_main, 1920x1080 8-bit, 4 references, SearchRange 64) and configs[4]
+    (encoder_randomaccess_main10 B slice, 3840x2160 10-bit, 2 + 2 references) at full size, WaveFrontSynchro=1, through properties that do
+    not need the oracle at that size: (1) the same job in two batch slots gives identical results; (2) picture totals are the sums of
+    the per-CTU totals; (3) crop invariance: the four top-left CTUs only read the picture and the reference pictures inside the top-left
+    384x256 region (search range 64 + interpolation taps), so they equal the oracle's result on that crop with the cropped references."""
+    import math
+    import oracle
+    qp, seed, cw, ch = 32, 4321, 384, 256
+    enc = hm.Encoder(w, h, bd, 1, max_batch=2)
+    n = enc.num_ctus
+
+    def crop(planes):
+        return (planes[0][:ch, :cw].copy(), planes[1][:ch // 2, :cw // 2].copy(), planes[2][:ch // 2, :cw // 2].copy())
+
+    def motionless(nc):
+        mot = np.zeros(nc, [("pred_mode", "u1", 256), ("mv0", "<i2", (256, 2)), ("ref_idx0", "i1", 256), ("mv1", "<i2", (256, 2)), ("ref_idx1", "i1", 256)])
+        mot["pred_mode"] = 1; mot["ref_idx0"] = -1; mot["ref_idx1"] = -1
+        return mot
+    zero = np.zeros((2, 16), np.int32)
+    pocs = [3, 2, 1, 0][:nref] if kind == "P" else [0, 8]
+    cur_poc = 4
+    pics = {poc: synth.frame(w, h, bd, poc, seed) for poc in pocs}          # reference pictures: neighbouring frames of the clip as they are
+    finals = {poc: {"poc": poc, "slice_type": 2, "rec": list(pics[poc]), "motion": motionless(n), "num_ref_idx": (0, 0), "ref_poc": zero, "ref_long_term": zero}
+              for poc in pocs}
+    nc = ((cw + 63) // 64) * ((ch + 63) // 64)
+    finals_crop = {poc: dict(f, rec=list(crop(f["rec"])), motion=motionless(nc)) for poc, f in finals.items()}
+    ref_poc = np.zeros((2, 16), np.int32)
+    ref_poc[0, :len(pocs)] = pocs
+    if kind == "B":
+        ref_poc[1, :len(pocs)] = pocs[::-1]
+    qps = qp + (3 if kind == "P" else 2)
+    lam = (0.4624 if kind == "P" else 0.3536) * 2.0 ** ((qps - 12) / 3.0) * min(4.0, max(2.0, (qps - 12) / 6.0))
+    srec = {"poc": cur_poc, "slice_type": 1 if kind == "P" else 0, "qp": qps, "lambda": lam, "weight_cb": hm.intra_lambda(qps)[1],
+            "cabac_init_type": 1 if kind == "P" else 0, "num_ref_idx": (len(pocs), 0 if kind == "P" else len(pocs)), "ref_poc": ref_poc, "col_from_l0": 1,
+            "col_ref_idx": 0, "tmvp": 1, "mvd_l1_zero": 0, "max_merge_cand": 5, "check_ldc": 1 if kind == "P" else 0,
+            "lambda_motion_sad": int(math.floor(65536.0 * math.sqrt(lam))), "lambda_motion_sse": int(math.floor(65536.0 * lam))}
+    cur = synth.frame(w, h, bd, cur_poc, seed)
+    sp, refs = common.ldp_slice_inputs(srec, finals)
+    (rec0, ctus0, ictus0, st0), (rec1, ctus1, ictus1, st1) = enc.compress_inter_batch([(cur, sp, refs), (cur, sp, refs)])
+    enc.close()
+    for f in ctus0.dtype.names:
+        assert np.array_equal(ctus0[f], ctus1[f]), f"{kind} {w}x{h}: slot 0 and slot 1 differ in {f}"
+    for f in ictus0.dtype.names:
+        assert np.array_equal(ictus0[f], ictus1[f]), f"{kind} {w}x{h}: slot 0 and slot 1 differ in {f}"
+    for k in range(3):
+        assert np.array_equal(rec0[k], rec1[k])
+    assert st0[0] == int(ctus0["total_bits"].astype(np.uint64).sum()) and st0[2] == int(ctus0["total_dist"].astype(np.uint64).sum())
+    assert (ictus0["inter_dir"] != 0).any() and (kind == "P" or (ictus0["inter_dir"] == 3).any())
+    want_rec, want_ctus, want_ictus = oracle.compress_inter(crop(cur), bd, srec, finals_crop, wpp=1)
+    wc, wcc = (w + 63) // 64, (cw + 63) // 64
+    full_idx, crop_idx = [0, 1, wc, wc + 1], [0, 1, wcc, wcc + 1]
+    for f in ("total_bits", "total_dist", "total_cost", "depth", "part_size", "pred_mode", "tr_idx", "cbf", "tskip", "coeff_y", "coeff_cb", "coeff_cr"):
+        assert np.array_equal(ctus0[f][full_idx], want_ctus[f][crop_idx]), f"{kind} {w}x{h} vs oracle on the crop: {f} differs"
+    for f in ("skip", "merge_flag", "merge_idx", "inter_dir", "mv", "mvd", "ref_idx", "mvp_idx", "mvp_num"):
+        assert np.array_equal(ictus0[f][full_idx], want_ictus[f][crop_idx]), f"{kind} {w}x{h} vs oracle on the crop: {f} differs"
+    assert np.array_equal(rec0[0][:128, :128], want_rec[0][:128, :128])
+    for k in (1, 2):
+        assert np.array_equal(rec0[k][:64, :64], want_rec[k][:64, :64])
+
+
+def test_full_size_1080p_main10_batch_equals_single(hm):
+    """BASELINE.json configs[1]: encoder_intra_main10, 1920x1080 10-bit, 8 frames in one batch (WaveFrontSynchro=1 so that a picture
+    takes seconds, not a minute) == the same frames searched alone; totals = sums of the per-CTU totals"""
+    w, h, bd, qp = 1920, 1080, 10, 32
+    frames = [synth.frame(w, h, bd, f, 99) for f in range(8)]
+    enc = hm.Encoder(w, h, bd, 1, max_batch=8)
+    res = enc.compress(frames, qp)
+    for i in (0, 5):
+        (rec, ctus, st), = enc.compress([frames[i]], qp)
+        common.assert_ctus_equal(ctus, res[i][1], f"1080p frame {i}: alone vs in the batch")
+        for k in range(3):
+            assert np.array_equal(rec[k], res[i][0][k])
+    for rec, ctus, st in res:
+        assert st[0] == int(ctus["total_bits"].astype(np.uint64).sum()) and (ctus["total_bits"] > 0).all()
+    assert any(not np.array_equal(res[0][1]["depth"], res[i][1]["depth"]) for i in range(1, 8))
+    enc.close()
+
+
 def test_hip_primitive_kats(hm):
     """SAD/SSE/SATD and transform kernels vs the reference's known answers"""
     k = np.load(common.GOLD + "/kat_primitives.npz")
