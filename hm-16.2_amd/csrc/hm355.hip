@@ -288,6 +288,10 @@ static int run_rows_impl(hm355_ctx *c, int slot0, int n, const hm355_slice_desc 
     HM_CHECK(c, hipMemcpyAsync(c->dItems, c->items.data(), sizeof(WorkItem) * c->items.size(), hipMemcpyHostToDevice, c->stream));
     c->schedKey = schedKey;
   }
+  { // a WPP picture offers about 16 CTUs at a time (one when the CABAC state chains through all of them): can this launch keep ~5 searches per CU busy?
+    const int fewWaves = (long long)n * (P.wpp ? 16 : 1) < 1280 ? 1 : 0;
+    if (fewWaves != c->hp.fewWaves) { c->hp.fewWaves = fewWaves; HM_CHECK(c, hipMemcpyAsync(c->dP, &c->hp, sizeof(Params), hipMemcpyHostToDevice, c->stream)); }
+  }
   c->epoch++; if (c->epoch == 0) c->epoch = 1;
   HM_CHECK(c, hipMemsetAsync(c->dSched, 0, 64, c->stream));        // ticket = 0, abort = 0
   if (row0 > 0)    // the row above the band is complete: its CTUs count as published in this run

@@ -156,7 +156,7 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 
 // optional in-kernel cycle accounting (diagnostic build only: -DHM355_PROFILE, never in the product build)
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-#define HM_PROF_N 40
+#define HM_PROF_N 44
 #define HM_PROF_BEGIN(e, id) const unsigned long long prof_t0_##id = __builtin_readcyclecounter()
 #define HM_PROF_END(e, id) do { (e)->prof[id] += __builtin_readcyclecounter() - prof_t0_##id; (e)->profCnt[id] += 1; } while (0)
 #else
@@ -164,7 +164,7 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 #define HM_PROF_END(e, id) ((void)0)
 #endif
 enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBLK, PR_SAVE, PR_CHROMA, PR_LUMA, PR_ENCCU, PR_TOTAL,
-       PR_S4L = 32, PR_S4C, PR_D0, PR_D1, PR_D2, PR_D3, PR_NXN, PR_S8L,
+       PR_S4L = 32, PR_S4C, PR_D0, PR_D1, PR_D2, PR_D3, PR_NXN, PR_S8L, PR_S4LEAF, PR_S4CLEAF,
        PR_ME_INT = 16, PR_ME_FRAC, PR_AMVP, PR_MRG_EST, PR_MC, PR_IRQ, PR_IRES, PR_MRG2N, PR_INTERCU, PR_INTRA_IN_P, PR_IQ_FULL, PR_IQ_FWD, PR_IQ_RDOQ, PR_IQ_BITS, PR_IQ_INV, PR_IQ_ENC };
 
 #define HM_MAX_DOUBLE 1.7e+308
@@ -1831,6 +1831,7 @@ HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
 // luma residual quadtree (TEncSearch::xRecurIntraCodingQT :1364-1733, bLumaOnly), explicit stack
 // ------------------------------------------------------------------------------------------------
 // returns distortion through *distY and adds the RD cost to *rdCost, exactly like the recursive reference
+HM_DEV HM_NOINLINE void simt4_luma_leaf(Shared *e, TU tv);      // hm355_simt4.h
 HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirst)
 {
   HM_ENTRY(e); checkFirst = HM_UNI(checkFirst); rootv = hm_uni_struct(rootv);
@@ -1870,6 +1871,16 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
             par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
             cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_TEMP_BEST)]);
           }
+        } else if (log2 == 2 && e->P->fewWaves) {
+          // a 4x4 leaf (it cannot split, so no snapshot is taken): evaluated and priced on one lane (simt4_luma_leaf) when the launch leaves
+          // most of the device idle -- the per-lane form is the shorter dependency chain (one 4K picture: 14.1 s instead of 14.8 s) but issues
+          // more instructions, which costs 2.5 % of throughput once every SIMD is shared by several searches (measured A/B on one device)
+          par_set8(m->ts[0] + z, 0, t->parts);
+          HM_PROF_BEGIN(e, PR_S4LEAF);
+          simt4_luma_leaf(e, *t);
+          HM_PROF_END(e, PR_S4LEAF);
+          f->singleDist = e->outDistY;
+          f->singleCost = calc_rd_cost(e, e->outBits, f->singleDist);
         } else {
           if (f->checkSplit) cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
           par_set8(m->ts[0] + z, 0, t->parts);
@@ -2070,6 +2081,13 @@ HM_DEV inline uint32_t chroma_tu(Shared *e, const TU *t)
   int checkTS = (t->cW == 4) && (t->log2 == 2);
   if (checkTS) { int nb = 0; for (int s = 0; s < 4; s++) nb += m->ts[0][z + s]; checkTS = nb > 0; }
   const int zc = t->cuZ + t->cRelZ;
+  if (t->cW == 4 && !checkTS) {          // both 4x4 blocks at once, one per lane (simt4_chroma_leaf); nothing is coded, so the estimator stays as it is
+    cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+    HM_PROF_BEGIN(e, PR_S4CLEAF);
+    const uint32_t d2 = HM_UCALL(simt4_chroma_leaf(e, *t));
+    HM_PROF_END(e, PR_S4CLEAF);
+    return d2;
+  }
   uint32_t dist = 0;
   for (int comp = 1; comp < 3; comp++) {
     cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);

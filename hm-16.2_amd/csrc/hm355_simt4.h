@@ -638,3 +638,106 @@ HM_DEV HM_NOINLINE uint32_t simt4_chroma_cu(Shared *e, TU leafv, int cuZ)
   HM_SYNC();
   return bestDist;
 }
+
+// ------------------------------------------------------------------------------------------------
+// One 4x4 luma transform block inside a residual quadtree (xIntraCodingTUBlock :1074 + xGetIntraBitsQT :1038 of a leaf of
+// xRecurIntraCodingQT, no transform-skip trial: 2Nx2N CUs).  Nothing runs beside it -- the blocks of a quadtree chain through the
+// reconstruction and the CABAC state -- but for a block this small the per-lane form of the evaluation (hm355_simt4.h) on ONE lane
+// is shorter than the wave-uniform form with its 64-lane staging and its LDS / HBM round trips, so it runs there.  Side effects
+// are those of the two reference functions: coefficients and reconstruction in the quadtree layer buffers and the picture,
+// tr / cbf of the partition, the estimator (e->cur) advanced past the block's syntax.  Distortion / bits in e->outDistY / e->outBits.
+// ------------------------------------------------------------------------------------------------
+HM_DEV HM_NOINLINE void simt4_luma_leaf(Shared *e, TU tv)
+{
+  HM_ENTRY(e); tv = hm_uni_struct(tv);
+  const TU *t = &tv; CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
+  const int z = t->cuZ + t->relZ, ps = e->stride[0], r = hm_z2r(z), mode = m->dirL[z];
+  init_adi_pattern(e, 0, e->ctuX * 64 + t->x, e->ctuY * 64 + t->y, 4, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), 1, 0);
+  { // the bins in front of the block's own (xEncIntraHeader :965), on the estimator itself
+    CabacR cr; cabr_load(cr, &e->cur);
+    cr.frac &= 32767;
+    enc_intra_header(e, &cr, t, 1, 0);
+    cabr_store(cr, &e->cur);
+  }
+  Simt4A *A = s4_a(e); Simt4B *B = s4_b(e);
+  s4_setup(e, &e->cur, 0, 0, 0, C_INTRA_LUMA, 1);                  // luma cbf below the CU's root TU: context 0
+  const S4Par p = s4_params(e, 0);
+  const Pel *org = e->fb.org[0] + (e->ctuY * 64 + t->y) * ps + e->ctuX * 64 + t->x;
+  int dcVal;
+  { int s = 0; HM_PAR_FOR(i, 4) s += e->u.ref.refTop[0][i + 1] + e->u.ref.refLeft[0][i + 1]; dcVal = (hm_wave_sum_i(s) + 4) / 8; }
+  int scanType = SCAN_DIAG;
+  if (hm_abs(mode - VER_IDX) <= 4) scanType = SCAN_HOR; else if (hm_abs(mode - HOR_IDX) <= 4) scanType = SCAN_VER;
+  const uint32_t frac0 = (uint32_t)e->cur.frac;
+  HM_WAVE_FOR(k) {
+    if (k == 0) {
+      int32_t rec[16], lv[16]; int cbf;
+      const uint32_t dist = s4_eval(e, A, B, p, 0, 0, org, ps, mode, 0, scanType, dcVal, rec, lv, &cbf);
+      uint32_t frac = frac0;
+      s4_bin(e, A, 0, &frac, S4_CBF, cbf);                          // xEncSubdivCbfQT :856: a 4x4 block codes no split flag
+      if (cbf) s4_code_coeff(e, A, B, 0, 0, scanType, 0, &frac);
+      A->outDist[0] = dist; A->outBits[0] = frac; A->outCbf[0] = (uint8_t)cbf;
+      TCoeff *coef = ws->qtCoef[3] + z * 16; Pel *rq = ws->qtRec[3] + t->y * 64 + t->x;
+      Pel *recPic = e->fb.rec[0] + (e->ctuY * 64 + t->y) * ps + e->ctuX * 64 + t->x;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { coef[i] = lv[i]; rq[(i >> 2) * 64 + (i & 3)] = (Pel)rec[i]; recPic[(i >> 2) * ps + (i & 3)] = (Pel)rec[i]; }
+    }
+  }
+  HM_SYNC();
+  // the estimator after the block: the contexts the lane advanced, the bit count
+  HM_PAR_FOR(j, S4_MODE) {
+    int c;
+    if (j < S4_ONE) c = C_SIG + j; else if (j < S4_ABS) c = C_ONE + (j - S4_ONE); else if (j == S4_ABS) c = C_ABS;
+    else if (j < S4_LY) c = C_LASTX + (j - S4_LX); else if (j < S4_CBF) c = C_LASTY + (j - S4_LY);
+    else if (j == S4_CBF) c = C_QT_CBF; else c = C_TSKIP;
+    e->cur.s[c] = A->ctx[j][0];
+  }
+  const int cbf = A->outCbf[0];
+  e->cur.frac = (uint64_t)A->outBits[0];
+  e->outDistY = A->outDist[0]; e->outBits = A->outBits[0] >> 15;
+  if (hm_lane() == 0) { m->tr[z] = (uint8_t)t->trDepth; m->cbf[0][z] = (uint8_t)(cbf << t->trDepth); }
+  HM_SYNC();
+}
+
+// The 4x4 chroma blocks (Cb, Cr) of one transform unit under the CU's current chroma mode, no transform-skip trial
+// (xIntraCodingTUBlock :1074 twice, from xRecurIntraChromaCodingQT :1958): two independent evaluations from the same estimator
+// state, one per lane.  Side effects as the reference function's; returns the sum of the weighted distortions.
+HM_DEV HM_NOINLINE uint32_t simt4_chroma_leaf(Shared *e, TU tv)
+{
+  HM_ENTRY(e); tv = hm_uni_struct(tv);
+  const TU *t = &tv; CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
+  const int zc = t->cuZ + t->cRelZ, r = hm_z2r(zc), layer = 5 - t->log2;
+  const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4), px = e->ctuX * 32 + t->cx, py = e->ctuY * 32 + t->cy;
+  init_adi_pattern(e, 2, px, py, 4, x4, y4, 2, 0);
+  HM_PAR_FOR(i, 9) { e->u.ref.refTop[1][i] = e->u.ref.refTop[0][i]; e->u.ref.refLeft[1][i] = e->u.ref.refLeft[0][i]; }
+  HM_SYNC();
+  init_adi_pattern(e, 1, px, py, 4, x4, y4, 2, 0);
+  int mode = m->dirC[zc];
+  if (mode == DM_CHROMA_IDX) mode = m->dirL[zc & ~3];
+  int scanType = SCAN_DIAG;
+  if (hm_abs(mode - VER_IDX) <= 4) scanType = SCAN_HOR; else if (hm_abs(mode - HOR_IDX) <= 4) scanType = SCAN_VER;
+  Simt4A *A = s4_a(e); Simt4B *B = s4_b(e);
+  s4_setup(e, &e->cur, 1, 5 + t->trDepth, 5, C_CHROMA_PRED, 2);
+  const S4Par p = s4_params(e, 1);
+  int dcVal[2];
+  for (int c = 0; c < 2; c++) { int s = 0; HM_PAR_FOR(i, 4) s += e->u.ref.refTop[c][i + 1] + e->u.ref.refLeft[c][i + 1]; dcVal[c] = (hm_wave_sum_i(s) + 4) / 8; }
+  HM_WAVE_FOR(k) {
+    if (k < 2) {
+      const int ps = e->stride[1 + k], po = HM_PLANE_OFF(1 + k);
+      const Pel *org = e->fb.org[1 + k] + (size_t)py * ps + px;
+      int32_t rec[16], lv[16]; int cbf;
+      const uint32_t sse = s4_eval(e, A, B, p, k, k, org, ps, mode, 0, scanType, k ? dcVal[1] : dcVal[0], rec, lv, &cbf);
+      A->outDist[k] = (uint32_t)(e->fb.chromaWeight * (double)sse);
+      A->outCbf[k] = (uint8_t)cbf;
+      TCoeff *coef = ws->qtCoef[layer] + po + t->cOff; Pel *rq = ws->qtRec[layer] + po + t->cy * 32 + t->cx;
+      Pel *recPic = e->fb.rec[1 + k] + (size_t)py * ps + px;
+#pragma unroll
+      for (int i = 0; i < 16; i++) { coef[i] = lv[i]; rq[(i >> 2) * 32 + (i & 3)] = (Pel)rec[i]; recPic[(i >> 2) * ps + (i & 3)] = (Pel)rec[i]; }
+    }
+  }
+  HM_SYNC();
+  const int cbfU = A->outCbf[0], cbfV = A->outCbf[1];
+  const uint32_t dist = A->outDist[0] + A->outDist[1];
+  HM_PAR_FOR(i, t->cParts) { m->cbf[1][zc + i] = (uint8_t)(cbfU << t->trDepth); m->cbf[2][zc + i] = (uint8_t)(cbfV << t->trDepth); m->ts[1][zc + i] = 0; m->ts[2][zc + i] = 0; }
+  HM_SYNC();
+  return dist;
+}

@@ -124,6 +124,7 @@ struct Params {
   WorkSpace *ws;
   FrameBuf *frames;
   unsigned long long *prof;          // diagnostic builds only (HM355_PROFILE), else NULL
+  int32_t fewWaves;                  // the launch cannot fill the device: prefer the shortest dependency chain over the fewest instructions
 };
 
 struct WorkItem { int32_t frame, ctuX, ctuY, pad; };

@@ -20,6 +20,9 @@ int main(int argc, char **argv)
   if (!fi || !fo) { perror("open"); return 1; }
   Params P; memset(&P, 0, sizeof(P));
   P.width = w; P.height = h; P.bitDepth = bd; P.wpp = wpp; P.wCtu = (w + 63) / 64; P.hCtu = (h + 63) / 64;
+#ifdef HM355_HOSTSIM_REVERSE
+  P.fewWaves = 1;     // the reversed build also takes the small-launch code path (4x4 leaves of a quadtree on one lane)
+#endif
   P.stride[0] = P.wCtu * 64; P.stride[1] = P.stride[2] = P.wCtu * 32;
   const int nctu = P.wCtu * P.hCtu;
   Tables *tab = new Tables; hm355_build_tables(tab); P.tab = tab;

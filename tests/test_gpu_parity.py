@@ -402,6 +402,21 @@ def test_hip_batch_equals_single(hm):
     enc.close()
 
 
+def test_hip_large_batch_code_path_equals_small_batch(hm):
+    """A launch that can fill the device takes the fewest-instructions code path (Params::fewWaves == 0), a small one the shortest
+    dependency chain; both must give the same result: 96 pictures in one batch == the same pictures in batches of 3."""
+    w, h, bd, qp = 128, 64, 10, 27
+    planes = [synth.frame(w, h, bd, i % 6, 21) for i in range(96)]
+    enc = hm.Encoder(w, h, bd, 1, max_batch=96)
+    big = enc.compress(planes, qp)
+    small = enc.compress(planes[:3], qp) + enc.compress(planes[3:6], qp)
+    for i in range(96):
+        common.assert_ctus_equal(big[i][1], small[i % 6][1], f"picture {i}")
+        for k in range(3):
+            assert np.array_equal(big[i][0][k], small[i % 6][0][k])
+    enc.close()
+
+
 def test_full_size_4k_wpp_properties(built, hm):
     """BASELINE.json's full size (3840x2160 10-bit, WaveFrontSynchro=1), checked through properties that do not need
     the oracle at that size: (1) the same picture in two batch slots gives identical results; (2) picture totals are

@@ -32,7 +32,7 @@ k = hm355.C.c_double(); l = hm355.C.c_int(); enc.lib.hm355_last_run_info(enc.h_,
 print(f"{w}x{h} wpp={wpp} refs={nref}: {n} CTUs, kernel {k.value:.1f} ms ({n / k.value * 1000:.2f} CTU/s), wall {dt * 1000:.0f} ms; "
       f"skip {float((ictus['skip'] != 0).mean()):.2f} merge {float((ictus['merge_flag'] != 0).mean()):.2f} intra {float((ctus['pred_mode'] == 1).mean()):.2f} bits {st[0]}")
 if lib is not None and hasattr(lib, "hm355_read_profile"):
-    NP = 40
+    NP = 44
     out = (hm355.C.c_ulonglong * (2 * NP))()
     lib.hm355_read_profile.argtypes = [hm355.C.c_void_p, hm355.C.c_void_p]
     lib.hm355_read_profile(enc.h_, out)
