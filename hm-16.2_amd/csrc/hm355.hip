@@ -138,6 +138,7 @@ struct hm355_ctx {
   Tables *dTab;
   FrameBuf *dFrames;
   WorkSpace *dWs; size_t wsCount;
+  uint8_t *arena;       // the pictures' planes, decision arrays, coefficients, statistics, CABAC states, done words: one allocation
   WorkItem *dItems; size_t itemsCap;
   unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort of the search launch; [8] ticket, [9] abort of the bitstream launch
   std::vector<Slot> slots;
@@ -179,7 +180,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
   c->cfg = *cfg; c->schedKey = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
-  c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
+  c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
   P.wCtu = (cfg->width + 63) / 64; P.hCtu = (cfg->height + 63) / 64;
@@ -200,21 +201,29 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   HM_CHECK(c, hipMalloc((void **)&c->dFrames, sizeof(FrameBuf) * cfg->max_batch));
   HM_CHECK(c, hipMalloc((void **)&c->dP, sizeof(Params)));
   c->slots.resize(cfg->max_batch);
-  for (int s = 0; s < cfg->max_batch; s++) {
-    FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
-    c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCand = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
-    c->slots[s].rawIn = c->slots[s].rawOut = NULL;
-    c->slots[s].bitsRaw = c->slots[s].bitsPacked = NULL; c->slots[s].bitsSizes = NULL; c->slots[s].bitsSync = NULL; c->slots[s].bitsFlag = NULL; c->slots[s].bitsIp = NULL;
-    for (int k = 0; k < 3; k++) {
-      const size_t bytes = (size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel);
-      HM_CHECK(c, hipMalloc((void **)&fb.org[k], bytes)); HM_CHECK(c, hipMemset(fb.org[k], 0, bytes));
-      HM_CHECK(c, hipMalloc((void **)&fb.rec[k], bytes)); HM_CHECK(c, hipMemset(fb.rec[k], 0, bytes));
+  { // the pictures' buffers come out of ONE allocation (a batch of thousands of small pictures used to mean tens of thousands of hipMallocs)
+    size_t planeBytes[3], off = 0;
+    for (int k = 0; k < 3; k++) planeBytes[k] = ((size_t)P.stride[k] * P.hCtu * (k ? 32 : 64) * sizeof(Pel) + 255) & ~(size_t)255;
+    const size_t metaBytes = (sizeof(CtuMeta) * c->numCtus + 255) & ~(size_t)255, coefBytes = (sizeof(TCoeff) * (size_t)c->numCtus * HM_COEF_CTU + 255) & ~(size_t)255;
+    const size_t statBytes = (sizeof(CtuStat) * c->numCtus + 255) & ~(size_t)255, endBytes = (sizeof(Cabac) * c->numCtus + 255) & ~(size_t)255;
+    const size_t doneBytes = (sizeof(uint32_t) * c->numCtus + 255) & ~(size_t)255;
+    const size_t slotBytes = 2 * (planeBytes[0] + planeBytes[1] + planeBytes[2]) + metaBytes + coefBytes + statBytes + endBytes + doneBytes;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && slotBytes * (size_t)cfg->max_batch > freeB) {
+      c->err = "hm355_create: max_batch pictures of this size do not fit the device memory"; return HM355_ERR_NOMEM; }
+    HM_CHECK(c, hipMalloc((void **)&c->arena, slotBytes * (size_t)cfg->max_batch));
+    HM_CHECK(c, hipMemset(c->arena, 0, slotBytes * (size_t)cfg->max_batch));      // planes (padding included) and the done words start at zero
+    for (int s = 0; s < cfg->max_batch; s++) {
+      FrameBuf &fb = c->slots[s].fb; memset(&fb, 0, sizeof(fb));
+      c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCand = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
+      c->slots[s].rawIn = c->slots[s].rawOut = NULL;
+      c->slots[s].bitsRaw = c->slots[s].bitsPacked = NULL; c->slots[s].bitsSizes = NULL; c->slots[s].bitsSync = NULL; c->slots[s].bitsFlag = NULL; c->slots[s].bitsIp = NULL;
+      uint8_t *p = c->arena + off;
+      for (int k = 0; k < 3; k++) { fb.org[k] = (Pel *)p; p += planeBytes[k]; fb.rec[k] = (Pel *)p; p += planeBytes[k]; }
+      fb.meta = (CtuMeta *)p; p += metaBytes; fb.coef = (TCoeff *)p; p += coefBytes; fb.stat = (CtuStat *)p; p += statBytes;
+      fb.endState = (Cabac *)p; p += endBytes; fb.done = (uint32_t *)p; p += doneBytes;
+      off += slotBytes;
     }
-    HM_CHECK(c, hipMalloc((void **)&fb.meta, sizeof(CtuMeta) * c->numCtus));
-    HM_CHECK(c, hipMalloc((void **)&fb.coef, sizeof(TCoeff) * (size_t)c->numCtus * HM_COEF_CTU));
-    HM_CHECK(c, hipMalloc((void **)&fb.stat, sizeof(CtuStat) * c->numCtus));
-    HM_CHECK(c, hipMalloc((void **)&fb.endState, sizeof(Cabac) * c->numCtus));
-    HM_CHECK(c, hipMalloc((void **)&fb.done, sizeof(uint32_t) * c->numCtus)); HM_CHECK(c, hipMemset(fb.done, 0, sizeof(uint32_t) * c->numCtus));
   }
   P.tab = c->dTab; P.ws = c->dWs; P.frames = c->dFrames; P.prof = NULL;
 #ifdef HM355_PROFILE
@@ -230,15 +239,13 @@ extern "C" void hm355_destroy(hm355_ctx *c)
 {
   if (!c) return;
   for (size_t s = 0; s < c->slots.size(); s++) {
-    FrameBuf &fb = c->slots[s].fb;
-    for (int k = 0; k < 3; k++) { if (fb.org[k]) hipFree(fb.org[k]); if (fb.rec[k]) hipFree(fb.rec[k]); }
     if (c->slots[s].imeta) hipFree(c->slots[s].imeta);
     for (int k = 0; k < 3; k++) if (c->slots[s].saoSrc[k]) hipFree(c->slots[s].saoSrc[k]);
     { Slot &sl = c->slots[s]; if (sl.rawIn) hipFree(sl.rawIn); if (sl.rawOut) hipFree(sl.rawOut); if (sl.bitsRaw) hipFree(sl.bitsRaw); if (sl.bitsPacked) hipFree(sl.bitsPacked); if (sl.bitsSizes) hipFree(sl.bitsSizes);
       if (sl.bitsSync) hipFree(sl.bitsSync); if (sl.bitsFlag) hipFree(sl.bitsFlag); if (sl.bitsIp) hipFree(sl.bitsIp); }
     if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCand) hipFree(c->slots[s].saoCand); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
-    if (fb.meta) hipFree(fb.meta); if (fb.coef) hipFree(fb.coef); if (fb.stat) hipFree(fb.stat); if (fb.endState) hipFree(fb.endState); if (fb.done) hipFree(fb.done);
   }
+  if (c->arena) hipFree(c->arena);
   if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems); if (c->dSched) hipFree(c->dSched);
   if (c->staging) hipHostFree(c->staging);
   if (c->dDbk) hipFree(c->dDbk);
