@@ -94,7 +94,8 @@ def distinct_frames(width, height, bit_depth, numbers, seed):
     """the synthetic frames `numbers`, generated on a few host cores (call before the process touches the GPU: the pool forks)"""
     import synth
     jobs = [(width, height, bit_depth, f, seed) for f in numbers]
-    if len(jobs) < 4:
+    # under rocprofv3 the profiler's preloaded library has initialised the GPU before main(): no fork then
+    if len(jobs) < 4 or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("HM355_NO_FORK"):
         return [synth.frame(*j) for j in jobs]
     import multiprocessing as mp
     with mp.get_context("fork").Pool(min(8, len(jobs), os.cpu_count() or 1)) as pool:
@@ -456,6 +457,40 @@ def run_bits(args, torch):
     enc.close()
 
 
+def intra_line(args, world, rows_mode, group, steps, warmup, dt, kernel_ms, launches, total_ctus, ctus_per_rank):
+    """the JSON line of the intra4k workload (rank 0), without the CPU baseline"""
+    # HBM bytes per launch from the committed PMC passes of this workload, if they match its size
+    traffic = None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if (tj["width"], tj["height"], tj["frames"]) == (args.width, args.height, args.frames):
+                traffic = tj["hbm_bytes_per_launch"]
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    ach = ALG_BYTES_PER_CTU * ctus_per_rank / (kernel_ms * 1e-3) / 1e9    # GB/s of the CTU-search kernel on this rank
+    return {
+        "metric": "CTUs/sec (enc) at 4K main10; bit-exact CU partition vs HM",
+        "value": total_ctus / dt, "unit": "CTU/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "steps_requested": args.steps, "warmup_requested": args.warmup,
+        "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None,
+        "dtype": "int32+f64", "data": "synthetic",
+        "config": {"workload": f"encoder_intra_main10, synthetic {args.width}x{args.height} 10-bit, QP {args.qp}, WaveFrontSynchro=1, " +
+                               (f"{args.frames} independent I pictures per step shared by the ranks" if rows_mode else f"{args.frames} independent I pictures per GPU per step") +
+                               f" ({min(DISTINCT_FRAMES, args.frames)} distinct frames), inputs resident in HBM",
+                   "frames_per_gpu": args.frames, "ctus_per_step": total_ctus // steps,
+                   "parallelism": (f"CTU rows of every picture sharded over {world} GPUs in bands, boundary rows handed down over RCCL send / recv, {group} pictures per pipeline stage"
+                                   if rows_mode else f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture"),
+                   "step_budget": f"warm-up + timed steps bounded to {args.budget_s:.0f} s of wall time: {warmup}+{steps} of the requested {args.warmup}+{args.steps} steps run"},
+        "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                     "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches,
+                     "note": "algorithmic bytes 54,278 B/CTU (SURVEY 8d) x CTUs / HIP-event kernel time; the path is bound by the latency of its own "
+                             "dependent LDS / L2 round trips (profiles/r02_pmc_sq_summary.json), not by HBM"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao", "bits", "ingest"], help="intra4k = the BASELINE.json metric (default)")
@@ -565,36 +600,7 @@ def main():
         ctus_per_rank = enc.num_ctus * args.frames * steps
         total_ctus = ctus_per_rank * world
     if rank == 0:
-        # HBM bytes per launch from the committed PMC passes of this workload, if they match its size
-        traffic = None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                if (tj["width"], tj["height"], tj["frames"]) == (args.width, args.height, args.frames):
-                    traffic = tj["hbm_bytes_per_launch"]
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
-        ach = ALG_BYTES_PER_CTU * ctus_per_rank / (kernel_ms * 1e-3) / 1e9    # GB/s of the CTU-search kernel on this rank
-        line = {
-            "metric": "CTUs/sec (enc) at 4K main10; bit-exact CU partition vs HM",
-            "value": total_ctus / dt, "unit": "CTU/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "steps_requested": args.steps, "warmup_requested": args.warmup,
-            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None,
-            "dtype": "int32+f64", "data": "synthetic",
-            "config": {"workload": f"encoder_intra_main10, synthetic {args.width}x{args.height} 10-bit, QP {args.qp}, WaveFrontSynchro=1, "
-                                   (f"{args.frames} independent I pictures per step shared by the ranks" if rows_mode else f"{args.frames} independent I pictures per GPU per step") +
-                                   f" ({min(DISTINCT_FRAMES, args.frames)} distinct frames), inputs resident in HBM",
-                       "frames_per_gpu": args.frames, "ctus_per_step": total_ctus // steps,
-                       "parallelism": (f"CTU rows of every picture sharded over {world} GPUs in bands, boundary rows handed down over RCCL send / recv, {group} pictures per pipeline stage"
-                                       if rows_mode else f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture"),
-                       "step_budget": f"warm-up + timed steps bounded to {args.budget_s:.0f} s of wall time: {warmup}+{steps} of the requested {args.warmup}+{args.steps} steps run"},
-            "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches,
-                         "note": "algorithmic bytes 54,278 B/CTU (SURVEY 8d) x CTUs / HIP-event kernel time; the path is "
-                                 "dependency/latency bound, not HBM bound"},
-        }
+        line = intra_line(args, world, rows_mode, group if rows_mode else 0, steps, warmup, dt, kernel_ms, launches, total_ctus, ctus_per_rank)
         if not args.no_cpu_baseline and world >= 1:
             line["cpu_baseline"] = cpu_baseline(args.width, bd, args.qp, seed)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]

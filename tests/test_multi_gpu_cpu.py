@@ -57,3 +57,19 @@ def test_step_plan():
     assert bench.plan_steps(43.5, 5, 20, 300.0) == (1, 5)                # the driver's command on the round-1 kernel
     assert bench.plan_steps(400.0, 5, 20, 300.0) == (1, 1)               # always at least one timed step
     assert bench.plan_steps(1.0, 0, 3, 300.0) == (1, 3)                  # the timed first step is the warm-up
+
+
+@pytest.mark.parametrize("world,rows", [(1, False), (8, False), (8, True)])
+def test_bench_line_is_complete(world, rows):
+    """the JSON line bench.py prints for the headline workload carries every field of the contract (built without a GPU)"""
+    import argparse
+    import bench
+    args = argparse.Namespace(width=3840, height=2160, qp=32, frames=384, steps=20, warmup=5, budget_s=280.0)
+    line = bench.intra_line(args, world, rows, 12 if rows else 0, 7, 1, 250.0, 248000.0, 7, 2040 * 384 * 7 * (1 if rows else world), 2040 * 384 * 7)
+    json.dumps(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line
+    assert line["n_gpus"] == world and line["scaling"] == ("strong" if rows else "weak") and "workload" in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["unit"] == "GB/s"
+    assert abs(line["value"] - 2040 * 384 * 7 * (1 if rows else world) / 250.0) < 1e-6
