@@ -425,8 +425,11 @@ HM_DEV inline uint32_t mc_cost32(const Shared *e, uint32_t b) { return (uint32_t
 // integer search: TZ (xTZSearch :4027-4228, helpers :333-795)
 // ------------------------------------------------------------------------------------------------
 // Search points (xTZSearchHelp :333) are queued and evaluated in batches: the points of one diamond / 2-point / raster pattern do not
-// depend on each other's result, only the running best does, so the SADs of up to four points are accumulated together (one read of
-// the original block per four reference reads, four loads in flight) and the best is then updated in the reference's point order.
+// depend on each other's result, only the running best does.  One pass takes up to 16 queued points: the 64 lanes are split into as many
+// groups as there are points (4..64 lanes per point), a group accumulates its point's SAD over the (row sub-sampled) block with coalesced
+// row reads, a DPP prefix inside the group leaves the sum in its last lane, which also prices the motion vector; the pass's winner is the
+// cheapest point, the first one on a tie -- what the reference's one-by-one update with strict "<" arrives at -- and the running best is
+// updated once per pass on the scalar unit.
 #define TZ_PUSH(z, n, X, Y, PN, D) do { (z)->lx[n] = (int16_t)(X); (z)->ly[n] = (int16_t)(Y); (z)->lp[n] = (int8_t)(PN); (z)->ld[n] = (int8_t)(D); (n)++; } while (0)
 HM_DEV HM_NOINLINE void tz_eval_list(Shared *e, int n)
 {
@@ -434,36 +437,58 @@ HM_DEV HM_NOINLINE void tz_eval_list(Shared *e, int n)
   TZ *z = &e->tz;
   const Pel *org = hm_uni_ptr(z->org), *ref = hm_uni_ptr(z->ref);
   const int so = HM_UNI(z->orgStride), sr = HM_UNI(z->refStride), w = HM_UNI(z->w), h = HM_UNI(z->h), sub = HM_UNI(z->subShift), bd = e->bitDepth;
-  const int rows = h >> sub, so2 = so << sub, sr2 = sr << sub;
-  for (int b = 0; b < n; b += 4) {
-    const int k = n - b < 4 ? n - b : 4;
-    int px[4], py[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { const int jj = j < k ? b + j : b; px[j] = HM_UNI(z->lx[jj]); py[j] = HM_UNI(z->ly[jj]); }
-    const Pel *r0 = ref + (ptrdiff_t)py[0] * sr + px[0], *r1 = ref + (ptrdiff_t)py[1] * sr + px[1];
-    const Pel *r2 = ref + (ptrdiff_t)py[2] * sr + px[2], *r3 = ref + (ptrdiff_t)py[3] * sr + px[3];
-    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (k == 4) {
-      HM_PAR_FOR_XY(x, yy, w, rows * w) { const int o = org[yy * so2 + x], q = yy * sr2 + x; s0 += (uint32_t)hm_abs(o - r0[q]); s1 += (uint32_t)hm_abs(o - r1[q]); s2 += (uint32_t)hm_abs(o - r2[q]); s3 += (uint32_t)hm_abs(o - r3[q]); }
-    } else if (k >= 2) {
-      HM_PAR_FOR_XY(x, yy, w, rows * w) { const int o = org[yy * so2 + x], q = yy * sr2 + x; s0 += (uint32_t)hm_abs(o - r0[q]); s1 += (uint32_t)hm_abs(o - r1[q]); if (k == 3) s2 += (uint32_t)hm_abs(o - r2[q]); }
-    } else {
-      HM_PAR_FOR_XY(x, yy, w, rows * w) s0 += (uint32_t)hm_abs(org[yy * so2 + x] - r0[yy * sr2 + x]);
+  const int rows = h >> sub, so2 = so << sub, sr2 = sr << sub, S = rows * w;
+  const int groups = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : 16))), L = 64 / groups;      // lanes per point
+  HM_LV(int32_t, vCost);
+  HM_WAVE_FOR(k) {
+    const int pnt = k / L, j = k - pnt * L;
+    uint32_t sum = 0;
+    if (pnt < n) {
+      const Pel *r = ref + (ptrdiff_t)z->ly[pnt] * sr + z->lx[pnt];
+      const int sy = L / w, sx = L - sy * w;
+      int yy = j / w, x = j - yy * w;
+      for (int i = j; i < S; i += L) {
+        sum += (uint32_t)hm_abs(org[yy * so2 + x] - r[yy * sr2 + x]);
+        x += sx; yy += sy; if (x >= w) { x -= w; yy++; }
+      }
     }
-    uint32_t sad[4];
-    sad[0] = (hm_wave_sum(s0) << sub) >> (bd - 8);
-    sad[1] = k > 1 ? (hm_wave_sum(s1) << sub) >> (bd - 8) : 0;
-    sad[2] = k > 2 ? (hm_wave_sum(s2) << sub) >> (bd - 8) : 0;
-    sad[3] = k > 3 ? (hm_wave_sum(s3) << sub) >> (bd - 8) : 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (j >= k) break;
-      uint32_t v = sad[j];
-      HM_TRACE(e, 11, ((uint32_t)(uint16_t)px[j] << 16) | (uint16_t)py[j], v, (double)z->bestSad);
-      v += mc_cost32(e, mc_bits(e, px[j], py[j]));
-      if (v < z->bestSad) { z->bestSad = v; z->bestX = px[j]; z->bestY = py[j]; z->bestDist = z->ld[b + j]; z->bestRound = 0; z->pointNr = z->lp[b + j]; }
-    }
+    HM_LVK(vCost, k) = (int32_t)sum;
   }
+#ifdef HM355_HOSTSIM
+  for (int pnt = 0; pnt < groups; pnt++) { int32_t t = 0; for (int j = 0; j < L; j++) t += vCost[pnt * L + j]; vCost[pnt * L + L - 1] = t; }
+#else
+  { // inclusive prefix over the lanes of a group: its last lane ends up with the group's sum (row_shr never reaches past a 16-lane row,
+    // groups of 32 / 64 lanes add the row sums)
+    int v = vCost;
+    if (L >= 2) v += hm_dpp<0x111>(0, v);
+    if (L >= 4) v += hm_dpp<0x112>(0, v);
+    if (L >= 8) v += hm_dpp<0x114>(0, v);
+    if (L >= 16) v += hm_dpp<0x118>(0, v);
+    if (L == 32) { const int a = __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63); v = hm_lane() < 32 ? a : b; }
+    if (L == 64) v = __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) + __builtin_amdgcn_readlane(v, 63);
+    vCost = v;
+  }
+#endif
+  HM_WAVE_FOR(k) { // the last lane of a group: SAD -> cost of its point (TComRdCost::getCost(x, y), TComRdCost.h:160-189)
+    const int pnt = k / L;
+    int32_t c = 0x7fffffff;
+    if (pnt < n && k == pnt * L + L - 1) {
+      const uint32_t sad = ((uint32_t)HM_LVK(vCost, k) << sub) >> (bd - 8);
+      HM_TRACE(e, 11, ((uint32_t)(uint16_t)z->lx[pnt] << 16) | (uint16_t)z->ly[pnt], sad, (double)z->bestSad);
+      c = (int32_t)(sad + mc_cost32(e, mc_bits(e, z->lx[pnt], z->ly[pnt])));
+    }
+    HM_LVK(vCost, k) = c;
+  }
+  int best, bestPnt;
+#ifdef HM355_HOSTSIM
+  best = 0x7fffffff; bestPnt = 0;
+  for (int pnt = 0; pnt < n; pnt++) if (vCost[pnt * L + L - 1] < best) { best = vCost[pnt * L + L - 1]; bestPnt = pnt; }
+#else
+  best = 0x7fffffff - hm_wave_max_i(0x7fffffff - vCost);
+  bestPnt = (int)(__builtin_ctzll(__ballot(vCost == best))) / L;
+#endif
+  if ((uint32_t)best < z->bestSad) { z->bestSad = (uint32_t)best; z->bestX = z->lx[bestPnt]; z->bestY = z->ly[bestPnt]; z->bestDist = z->ld[bestPnt]; z->bestRound = 0; z->pointNr = z->lp[bestPnt]; }
+  HM_SYNC();
 }
 HM_DEV inline void tz_help(Shared *e, int sx, int sy, int pointNr, int dist)
 { TZ *z = &e->tz; int n = 0; TZ_PUSH(z, n, sx, sy, pointNr, dist); tz_eval_list(e, n); }
@@ -542,12 +567,17 @@ HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, Mv
   z->l = lt.x; z->r = rb.x; z->t = lt.y; z->b = rb.y;
   MvD c = clip_mv(e, *mv, cuX, cuY); c.x >>= 2; c.y >>= 2;
   z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0;
-  tz_help(e, c.x, c.y, 0, 0);
-  tz_help(e, 0, 0, 0, 0);
+  { // the start points (:4066-4090): predictor, zero vector, the 2Nx2N integer vector -- independent evaluations, one pass
+    int n_ = 0;
+    TZ_PUSH(z, n_, c.x, c.y, 0, 0); TZ_PUSH(z, n_, 0, 0, 0, 0);
+    if (useInt) {
+      MvD im; im.x = (int16_t)(intMv2Nx2N.x << 2); im.y = (int16_t)(intMv2Nx2N.y << 2);
+      im = clip_mv(e, im, cuX, cuY); im.x >>= 2; im.y >>= 2;
+      TZ_PUSH(z, n_, im.x, im.y, 0, 0);
+    }
+    tz_eval_list(e, n_);
+  }
   if (useInt) {
-    MvD im; im.x = (int16_t)(intMv2Nx2N.x << 2); im.y = (int16_t)(intMv2Nx2N.y << 2);
-    im = clip_mv(e, im, cuX, cuY); im.x >>= 2; im.y >>= 2;
-    tz_help(e, im.x, im.y, 0, 0);
     MvD nb, nlt, nrb; nb.x = (int16_t)(z->bestX << 2); nb.y = (int16_t)(z->bestY << 2);
     set_search_range(e, nb, searchRange, cuX, cuY, &nlt, &nrb);
     rl = nlt.x; rr = nrb.x; rt = nlt.y; rbm = nrb.y;
