@@ -164,15 +164,16 @@ Frame8:  B    7   4        0.68     0            0              1           2   
 }
 
 
-def cpu_baseline_inter(kind, qp):
-    """The reference's own encoder (oracle/_ref/hm_encoder) on one host core for the same configuration: a 416x240 clip encoded with
-    1 picture and with 1 + n inter pictures; the difference is the time of the n inter pictures (whole encoder: the search dominates)."""
+def cpu_baseline_inter(kind, qp, width):
+    """The reference's own encoder (oracle/_ref/hm_encoder) on one host core for the same configuration, on a bounded sample of the
+    benched picture size: the top 4 CTU rows (width x 256) of the same synthetic clip, encoded with 1 picture and with 1 + n inter
+    pictures; the difference is the time of the n inter pictures (whole encoder: the search dominates)."""
     import synth
     enc = os.path.join(ROOT, "oracle", "_ref", "hm_encoder")
     if not os.path.exists(enc):
         return None
     profile, bd, gop = REF_CFG_INTER[kind]
-    w, h, n_inter = 416, 240, 8
+    w, h, n_inter = width, 256, 4
     common = REF_CFG.split("IntraPeriod")[0] + "".join(l + "\n" for l in REF_CFG.splitlines() if l.split(" ")[0] in (
         "FastSearch", "SearchRange", "HadamardME", "FEN", "FDM", "QP", "MaxDeltaQP", "MaxCuDQPDepth", "DeltaQpRD", "RDOQ", "RDOQTS", "SAO", "AMP",
         "TransformSkip", "TransformSkipFast"))
@@ -180,7 +181,11 @@ def cpu_baseline_inter(kind, qp):
     times = []
     with tempfile.TemporaryDirectory() as td:
         yuv = os.path.join(td, "in.yuv")
-        synth.write_yuv(yuv, w, h, bd, 1 + n_inter, 1234)
+        with open(yuv, "wb") as fh:
+            for f in range(1 + n_inter):
+                y, u, v = synth.frame(w, 1080 if w == 1920 else 2160, bd, f, 1234)
+                for p in (y[:h], u[:h // 2], v[:h // 2]):
+                    fh.write(np.ascontiguousarray(p).astype(np.uint8 if bd == 8 else "<u2").tobytes())
         cfg = os.path.join(td, "inter.cfg")
         open(cfg, "w").write(cfg_text)
         for frames in (1, 1 + n_inter):
@@ -193,9 +198,9 @@ def cpu_baseline_inter(kind, qp):
                 if "Total Time" in line:
                     dt = float(line.split()[2])
             times.append(dt)
-    n_ctus = 7 * 4 * n_inter
+    n_ctus = ((w + 63) // 64) * 4 * n_inter
     return {"value": n_ctus / max(1e-9, times[1] - times[0]), "unit": "CTU/s", "cores": 1, "kind": "reference",
-            "sample": f"{n_inter} inter pictures of a 416x240 {bd}-bit clip ({n_ctus} CTUs), same cfg, QP {qp}; HM 'Total Time' of 1+{n_inter} pictures minus 1 picture"}
+            "sample": f"{n_inter} inter pictures of the top 4 CTU rows ({w}x{h}, {bd}-bit) of the benched clip ({n_ctus} CTUs), same cfg, QP {qp}; HM 'Total Time' of 1+{n_inter} pictures minus 1 picture"}
 
 
 def run_inter(args, torch):
@@ -270,7 +275,7 @@ def run_inter(args, torch):
         "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": None, "note": f"algorithmic bytes {alg} B/CTU (SURVEY 8d)"}}
     if not args.no_cpu_baseline:
-        cb = cpu_baseline_inter(kind, qp)
+        cb = cpu_baseline_inter(kind, qp, w)
         if cb:
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_1core"] = line["value"] / cb["value"]
