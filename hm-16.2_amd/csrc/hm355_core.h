@@ -164,7 +164,7 @@ __device__ __forceinline__ double hm_readlane_d(double v, int i)
 #define HM_PROF_END(e, id) ((void)0)
 #endif
 enum { PR_RDOQ = 0, PR_BITS, PR_ADI, PR_PRED, PR_FWD, PR_INV, PR_SATD35, PR_TUBLK, PR_SAVE, PR_CHROMA, PR_LUMA, PR_ENCCU, PR_TOTAL,
-       PR_S4L = 32, PR_S4C, PR_D0, PR_D1, PR_D2, PR_D3, PR_NXN, PR_S8L, PR_S4LEAF, PR_S4CLEAF,
+       PR_S4L = 32, PR_S4C, PR_D0, PR_D1, PR_D2, PR_D3, PR_NXN, PR_S8L, PR_S4LEAF, PR_S4CLEAF, PR_S8C,
        PR_ME_INT = 16, PR_ME_FRAC, PR_AMVP, PR_MRG_EST, PR_MC, PR_IRQ, PR_IRES, PR_MRG2N, PR_INTERCU, PR_INTRA_IN_P, PR_IQ_FULL, PR_IQ_FWD, PR_IQ_RDOQ, PR_IQ_BITS, PR_IQ_INV, PR_IQ_ENC };
 
 #define HM_MAX_DOUBLE 1.7e+308
@@ -2184,6 +2184,19 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
       HM_PROF_BEGIN(e, PR_S4C);
       const uint32_t d = HM_UCALL(simt4_chroma_cu(e, split ? tu_child(&t, 0, 0) : t, cuZ));
       HM_PROF_END(e, PR_S4C);
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      return d;
+    }
+  }
+  if (cuDepth == 2) {
+    // 16x16 CU with an unsplit luma transform: one 8x8 block per chroma component, five modes x two components in lanes (hm355_simt8.h)
+    int split = 0;
+    for (int i = 0; i < 16; i += 4) split |= m->tr[cuZ + i];
+    if (!split) {
+      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      HM_PROF_BEGIN(e, PR_S8C);
+      const uint32_t d = HM_UCALL(simt8_chroma_cu16(e, cuZ));
+      HM_PROF_END(e, PR_S8C);
       cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
       return d;
     }

@@ -32,44 +32,51 @@ static_assert(offsetof(RefLds, refMain) + sizeof(Simt8B) <= sizeof(((Shared *)0)
 HM_DEV inline Simt8A *s8_a(Shared *e) { return (Simt8A *)e->bufA; }
 HM_DEV inline Simt8B *s8_b(Shared *e) { return (Simt8B *)((char *)&e->u + offsetof(RefLds, refMain)); }
 
-struct S8Par { int bitDepth, qBits, quantCoef; double errScale, lambda; int64_t rdFactor; int dqShift, dqScale, dqMin, dqMax; };
-HM_DEV inline S8Par s8_params(const Shared *e)
+struct S8Par { int chroma, bitDepth, qBits, quantCoef; double errScale, lambda; int64_t rdFactor; int dqShift, dqScale, dqMin, dqMax; };
+HM_DEV inline S8Par s8_params(const Shared *e, int chroma)
 {
   S8Par p;
   const int tshift = 15 - e->bitDepth - 3;
-  p.bitDepth = e->bitDepth; p.qBits = 14 + e->fb.qpPer[0] + tshift; p.quantCoef = HM_QUANT_SCALES[e->fb.qpRem[0]];
-  p.errScale = e->fb.errScale[0][1]; p.lambda = e->fb.lambda; p.rdFactor = e->fb.rdFactor[0];
-  p.dqShift = 6 - (tshift + e->fb.qpPer[0]); p.dqScale = HM_INV_QUANT_SCALES[e->fb.qpRem[0]];
+  p.chroma = chroma;
+  p.bitDepth = e->bitDepth; p.qBits = 14 + e->fb.qpPer[chroma] + tshift; p.quantCoef = HM_QUANT_SCALES[e->fb.qpRem[chroma]];
+  p.errScale = e->fb.errScale[chroma][1]; p.lambda = chroma ? e->fb.lambdaC : e->fb.lambda; p.rdFactor = e->fb.rdFactor[chroma];
+  p.dqShift = 6 - (tshift + e->fb.qpPer[chroma]); p.dqScale = HM_INV_QUANT_SCALES[e->fb.qpRem[chroma]];
   int tgt = 25 + p.dqShift; if (tgt > 16) tgt = 16;
   p.dqMin = -(1 << (tgt - 1)); p.dqMax = (1 << (tgt - 1)) - 1;
   return p;
 }
 
-// bit costs of the start state (estBit, TEncSbac.cpp:1717-1956), per-candidate context copies, scans (8x8 luma)
-HM_DEV inline void s8_setup(Shared *e, const Cabac *cb, int jobs)
+// bit costs of the start state (estBit, TEncSbac.cpp:1717-1956), per-candidate context copies, scans of an 8x8 block of one component type.
+// Context numbering inside the tables / copies: significance contexts by their increment (0..20), greater-than-1 contexts 4 * set + c1 with
+// set = 0..3 for luma and 0..1 for chroma (whose sets are 4, 5 in the reference's numbering), greater-than-2 by set, the three last-position
+// contexts an 8x8 block uses per coordinate, the two coded-sub-block contexts.  cbfCtx / cbfCodeCtx: the cbf context RDOQ prices with / the one
+// the syntax codes with (indices inside C_QT_CBF); modeCtx: context of the prediction-mode bin.
+HM_DEV inline void s8_setup(Shared *e, const Cabac *cb, int jobs, int chroma, int cbfCtx, int cbfCodeCtx, int modeCtx)
 {
   Simt8A *A = s8_a(e); Simt8B *B = s8_b(e);
+  const int sigOff = C_SIG + (chroma ? 28 : 0), oneOff = C_ONE + (chroma ? 16 : 0), absOff = C_ABS + (chroma ? 4 : 0);
+  const int lxOff = chroma ? C_LASTX + 15 : C_LASTX + 3, lyOff = chroma ? C_LASTY + 15 : C_LASTY + 3, cgOff = C_SIG_CG + (chroma ? 2 : 0);
   HM_PAR_FOR(i, T8_N) {
     int v = 0;
-    if (i < T8_ONE) v = HM_ENTROPY_BITS[cb->s[C_SIG + (i >> 1)] ^ (i & 1)];
-    else if (i < T8_ABS) v = HM_ENTROPY_BITS[cb->s[C_ONE + ((i - T8_ONE) >> 1)] ^ (i & 1)];
-    else if (i < T8_LASTX) v = HM_ENTROPY_BITS[cb->s[C_ABS + ((i - T8_ABS) >> 1)] ^ (i & 1)];
-    else if (i < T8_CG) { // last-position group index g = 0..5 of an 8x8 luma block: contexts 3 + (g >> 1); g > 3 adds one bypass bit (xGetRateLast :2815)
-      const int g = (i - T8_LASTX) % 6, off = i < T8_LASTY ? C_LASTX : C_LASTY;
-      for (int c = 0; c < g; c++) v += HM_ENTROPY_BITS[cb->s[off + 3 + (c >> 1)] ^ 1];
-      if (g < 5) v += HM_ENTROPY_BITS[cb->s[off + 3 + (g >> 1)] ^ 0];
+    if (i < T8_ONE) v = (chroma && (i >> 1) >= 16) ? 0 : HM_ENTROPY_BITS[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
+    else if (i < T8_ABS) v = (chroma && ((i - T8_ONE) >> 1) >= 8) ? 0 : HM_ENTROPY_BITS[cb->s[oneOff + ((i - T8_ONE) >> 1)] ^ (i & 1)];
+    else if (i < T8_LASTX) v = (chroma && ((i - T8_ABS) >> 1) >= 2) ? 0 : HM_ENTROPY_BITS[cb->s[absOff + ((i - T8_ABS) >> 1)] ^ (i & 1)];
+    else if (i < T8_CG) { // last-position group index g = 0..5 of an 8x8 block: context (g >> 1) of the block's three; g > 3 adds one bypass bit (xGetRateLast :2815)
+      const int g = (i - T8_LASTX) % 6, off = i < T8_LASTY ? lxOff : lyOff;
+      for (int c = 0; c < g; c++) v += HM_ENTROPY_BITS[cb->s[off + (c >> 1)] ^ 1];
+      if (g < 5) v += HM_ENTROPY_BITS[cb->s[off + (g >> 1)] ^ 0];
       if (g > 3) v += 32768 * ((g - 2) >> 1);
-    } else if (i < T8_CBF) v = HM_ENTROPY_BITS[cb->s[C_SIG_CG + ((i - T8_CG) >> 1)] ^ (i & 1)];
-    else v = HM_ENTROPY_BITS[cb->s[C_QT_CBF + 1] ^ (i & 1)];          // luma cbf at the CU's root TU: context 1
+    } else if (i < T8_CBF) v = HM_ENTROPY_BITS[cb->s[cgOff + ((i - T8_CG) >> 1)] ^ (i & 1)];
+    else v = HM_ENTROPY_BITS[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
     A->tab[i] = v;
   }
   HM_PAR_FOR(i, 128) A->lps[i] = HM_NEXT_LPS[i];
   HM_PAR_FOR(i, S8_NCTX * HM_S8) {
     const int j = i / HM_S8, k = i - j * HM_S8;
     int c;
-    if (j < S8_ONE) c = C_SIG + j; else if (j < S8_ABS) c = C_ONE + (j - S8_ONE); else if (j < S8_LX) c = C_ABS + (j - S8_ABS);
-    else if (j < S8_LY) c = C_LASTX + 3 + (j - S8_LX); else if (j < S8_CG) c = C_LASTY + 3 + (j - S8_LY);
-    else if (j < S8_CBF) c = C_SIG_CG + (j - S8_CG); else if (j == S8_CBF) c = C_QT_CBF + 1; else c = C_INTRA_LUMA;
+    if (j < S8_ONE) c = sigOff + (chroma && j >= 16 ? 0 : j); else if (j < S8_ABS) c = oneOff + (chroma ? ((j - S8_ONE) & 7) : (j - S8_ONE)); else if (j < S8_LX) c = absOff + (chroma ? ((j - S8_ABS) & 1) : (j - S8_ABS));
+    else if (j < S8_LY) c = lxOff + (j - S8_LX); else if (j < S8_CG) c = lyOff + (j - S8_LY);
+    else if (j < S8_CBF) c = cgOff + (j - S8_CG); else if (j == S8_CBF) c = C_QT_CBF + cbfCodeCtx; else c = modeCtx;
     if (k < jobs) A->ctx[j][k] = cb->s[c];
   }
   HM_PAR_FOR(i, 192) { const int ty = i >> 6, sp = i & 63; B->scan[ty][sp] = (uint8_t)e->tab->scan[ty][1][sp]; }
@@ -108,21 +115,21 @@ HM_FINL int32_t s8_level_double(int sc, const S8Par &p)
   return (int32_t)(tl < cap ? tl : cap);
 }
 // significance context increment of scan position sp of candidate k's block, given the flags of the coefficient groups decided so far
-HM_FINL int s8_sig_idx(const Simt8B *B, int scanType, int firstCtx, int sp, int cgMask)
+HM_FINL int s8_sig_idx(const Simt8B *B, int scanType, int firstCtx, int sp, int cgMask, int chroma)
 {
   const int cgBlkPos = B->scanCG[scanType][sp >> 4], cgx = cgBlkPos & 1, cgy = cgBlkPos >> 1;
   const int sigRight = cgx < 1 ? ((cgMask >> (cgBlkPos + 1)) & 1) : 0, sigLower = cgy < 1 ? ((cgMask >> (cgBlkPos + 2)) & 1) : 0;
-  return sig_ctx_inc(sigRight + (sigLower << 1), firstCtx, B->scan[scanType][sp], 3, 0);
+  return sig_ctx_inc(sigRight + (sigLower << 1), firstCtx, B->scan[scanType][sp], 3, chroma);
 }
 
-// RDOQ of candidate k's 8x8 luma block (TComTrQuant::xRateDistOptQuant, TComTrQuant.cpp:1974-2511): coefficients in A->cs[.][k]
+// RDOQ of candidate k's 8x8 block (TComTrQuant::xRateDistOptQuant, TComTrQuant.cpp:1974-2511): coefficients in A->cs[.][k]
 // (scan order); leaves the signed levels in the high halves of B->dc[.][k]; returns the sum of their magnitudes.
 HM_DEV inline int s8_rdoq(Simt8A *A, Simt8B *B, const S8Par &p, int k, int scanType)
 {
   const int32_t *tab = A->tab;
   const int qBits = p.qBits, half = 1 << (qBits - 1);
   const double lambda = p.lambda, errScale = p.errScale;
-  const int firstCtx = first_sig_ctx(8, scanType, 0);
+  const int firstCtx = first_sig_ctx(8, scanType, p.chroma), lumaSets = p.chroma ? 0 : 2;      // luma: coefficient groups behind the first use context sets 2, 3
   double blockUncoded = 0, baseCost = 0;
   double cgSig0 = 0, cgSig1 = 0, cgSig2 = 0, cgSig3 = 0;          // cost of the coded-sub-block flag per group (scan order)
   int last = -1, cgLast = -1, ctxSet = 0, c1 = 1, c2 = 0, c1Idx = 0, c2Idx = 0, goRice = 0;
@@ -139,11 +146,11 @@ HM_DEV inline int s8_rdoq(Simt8A *A, Simt8B *B, const S8Par &p, int k, int scanT
       uint32_t mx = (uint32_t)((lvlD + half) >> qBits); if (mx > 32767u) mx = 32767u;
       const double err = (double)lvlD, c0 = err * err * errScale;
       blockUncoded += c0;
-      if (mx > 0 && last < 0) { last = sp; cgLast = cg; ctxSet = cg > 0 ? 2 : 0; cgSets = ctxSet << (2 * cg); }
+      if (mx > 0 && last < 0) { last = sp; cgLast = cg; ctxSet = cg > 0 ? lumaSets : 0; cgSets = ctxSet << (2 * cg); }
       uint32_t level = 0; double cSig = 0, cCoeff = c0;
       if (last >= 0) {
         const int isLast = (sp == last);
-        const int si = isLast ? 0 : sig_ctx_inc(pattern, firstCtx, B->scan[scanType][sp], 3, 0);
+        const int si = isLast ? 0 : sig_ctx_inc(pattern, firstCtx, B->scan[scanType][sp], 3, p.chroma);
         if (!isLast && mx < 3) { cSig = lambda * (double)tab[T8_SIG + si * 2]; cCoeff = c0 + cSig; }      // xGetCodedLevel :2660
         else cCoeff = HM_MAX_DOUBLE;
         if (mx > 0) {
@@ -165,7 +172,7 @@ HM_DEV inline int s8_rdoq(Simt8A *A, Simt8B *B, const S8Par &p, int k, int scanT
         if (level >= 1) c1Idx++;
         if (level > 1) { c1 = 0; c2 += (c2 < 2); c2Idx++; }
         else if (c1 < 3 && c1 > 0 && level) c1++;
-        if (q == 0 && cg > 0) { ctxSet = ((cg - 1) > 0 ? 2 : 0) + (c1 == 0 ? 1 : 0); c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0; }
+        if (q == 0 && cg > 0) { ctxSet = ((cg - 1) > 0 ? lumaSets : 0) + (c1 == 0 ? 1 : 0); c1 = 1; c2 = 0; c1Idx = 0; c2Idx = 0; goRice = 0; }
       } else baseCost += c0;
       sigCost += cSig;
       if (q == 0) sigCost0 = cSig;
@@ -215,7 +222,7 @@ HM_DEV inline int s8_rdoq(Simt8A *A, Simt8B *B, const S8Par &p, int k, int scanT
     const int wSet = (cgSets >> (2 * cg)) & 3; int wC1 = 1, wC1Idx = 0, wC2Idx = 0, wGoR = 0;
     for (int q = (cg == cgLast ? (last & 15) : 15); q >= 0; q--) {
       const int sp = cg * 16 + q, lev = B->dc[sp][k] & 0xffff;
-      const int si = sp == last ? 0 : s8_sig_idx(B, scanType, firstCtx, sp, cgMask);
+      const int si = sp == last ? 0 : s8_sig_idx(B, scanType, firstCtx, sp, cgMask, p.chroma);
       if (lev) {
         const int blkPos = B->scan[scanType][sp];
         int py = blkPos >> 3, px = blkPos & 7;
@@ -279,7 +286,7 @@ HM_DEV inline int s8_rdoq(Simt8A *A, Simt8B *B, const S8Par &p, int k, int scanT
             const int sc = A->cs[subPos + q][k];
             const int32_t lvlD = s8_level_double(sc, p);
             const int32_t deltaU = (int32_t)((lvlD - (int32_t)(dec << qBits)) >> (qBits - 8));
-            const int si = (subPos + q == last) ? 0 : s8_sig_idx(B, scanType, firstCtx, subPos + q, cgMask);
+            const int si = (subPos + q == last) ? 0 : s8_sig_idx(B, scanType, firstCtx, subPos + q, cgMask, p.chroma);
             const int sigRateDelta = (subPos + q == last) ? 0 : tab[T8_SIG + si * 2 + 1] - tab[T8_SIG + si * 2];
             int rateIncUp, rateIncDown = 0;
             if (dec > 0) {
@@ -314,12 +321,13 @@ HM_DEV inline int s8_rdoq(Simt8A *A, Simt8B *B, const S8Par &p, int k, int scanT
   return absSum;
 }
 
-// TEncSbac::codeCoeffNxN, TEncSbac.cpp:1172-1525, of candidate k's 8x8 luma block on its private contexts (bits only)
-HM_DEV inline void s8_code_coeff(const Shared *e, Simt8A *A, const Simt8B *B, int k, int scanType, uint32_t *frac)
+// TEncSbac::codeCoeffNxN, TEncSbac.cpp:1172-1525, of an 8x8 block on candidate k's private contexts (bits only); the levels are those of
+// candidate `src` (the lane that decided them)
+HM_DEV inline void s8_code_coeff(const Shared *e, Simt8A *A, const Simt8B *B, int k, int src, int chroma, int scanType, uint32_t *frac)
 {
   int last = -1, cgMask = 0;
   for (int sp = 0; sp < 64; sp++)
-    if ((B->dc[sp][k] >> 16) != 0) { last = sp; cgMask |= 1 << B->scanCG[scanType][sp >> 4]; }
+    if ((B->dc[sp][src] >> 16) != 0) { last = sp; cgMask |= 1 << B->scanCG[scanType][sp >> 4]; }
   { // codeLastSignificantXY :1106
     const int blkPos = B->scan[scanType][last];
     int py = blkPos >> 3, px = blkPos & 7;
@@ -333,7 +341,7 @@ HM_DEV inline void s8_code_coeff(const Shared *e, Simt8A *A, const Simt8B *B, in
     if (gx > 3) *frac += 32768u * (uint32_t)((gx - 2) >> 1);
     if (gy > 3) *frac += 32768u * (uint32_t)((gy - 2) >> 1);
   }
-  const int firstCtx = first_sig_ctx(8, scanType, 0), lastSet = last >> 4;
+  const int firstCtx = first_sig_ctx(8, scanType, chroma), lastSet = last >> 4;
   int c1 = 1;
   for (int subSet = lastSet; subSet >= 0; subSet--) {
     const int subPos = subSet << 4, isLastSet = subSet == lastSet;
@@ -346,17 +354,17 @@ HM_DEV inline void s8_code_coeff(const Shared *e, Simt8A *A, const Simt8B *B, in
     const int top = isLastSet ? (last & 15) : 15;
     int numNonZero = isLastSet ? 1 : 0, firstNZ = isLastSet ? top : 16, lastNZ = isLastSet ? top : -1;
     for (int q = isLastSet ? top - 1 : 15; q >= 0; q--) {           // significance flags; the last coefficient itself is implied
-      const int sig = (B->dc[subPos + q][k] >> 16) != 0;
-      if (q > 0 || subSet == 0 || numNonZero) s8_bin(e, A, k, frac, S8_SIG + sig_ctx_inc(pattern, firstCtx, B->scan[scanType][subPos + q], 3, 0), sig);
+      const int sig = (B->dc[subPos + q][src] >> 16) != 0;
+      if (q > 0 || subSet == 0 || numNonZero) s8_bin(e, A, k, frac, S8_SIG + sig_ctx_inc(pattern, firstCtx, B->scan[scanType][subPos + q], 3, chroma), sig);
       if (sig) { numNonZero++; firstNZ = q; if (lastNZ < 0) lastNZ = q; }
     }
     if (numNonZero > 0) {
       const int signHidden = (lastNZ - firstNZ >= 4);
-      const int ctxSet = (subSet > 0 ? 2 : 0) + (c1 == 0 ? 1 : 0);
+      const int ctxSet = ((subSet > 0 && !chroma) ? 2 : 0) + (c1 == 0 ? 1 : 0);
       c1 = 1;
       int firstC2 = -1, escape = 0, idx = 0;
       for (int q = lastNZ; q >= 0 && idx < 8; q--) {
-        const int a = hm_abs(B->dc[subPos + q][k] >> 16);
+        const int a = hm_abs(B->dc[subPos + q][src] >> 16);
         if (!a) continue;
         const int sym = a > 1;
         s8_bin(e, A, k, frac, S8_ONE + 4 * ctxSet + c1, sym);
@@ -364,13 +372,13 @@ HM_DEV inline void s8_code_coeff(const Shared *e, Simt8A *A, const Simt8B *B, in
         else if (c1 < 3 && c1 > 0) c1++;
         idx++;
       }
-      if (c1 == 0 && firstC2 != -1) { const int sym = hm_abs(B->dc[subPos + firstC2][k] >> 16) > 2; s8_bin(e, A, k, frac, S8_ABS + ctxSet, sym); if (sym) escape = 1; }
+      if (c1 == 0 && firstC2 != -1) { const int sym = hm_abs(B->dc[subPos + firstC2][src] >> 16) > 2; s8_bin(e, A, k, frac, S8_ABS + ctxSet, sym); if (sym) escape = 1; }
       escape = escape || (numNonZero > 8);
       *frac += 32768u * (uint32_t)(signHidden ? numNonZero - 1 : numNonZero);
       if (escape) {
         int firstCoeff2 = 1; uint32_t goRice = 0; idx = 0;
         for (int q = lastNZ; q >= 0; q--) {
-          const int a = hm_abs(B->dc[subPos + q][k] >> 16);
+          const int a = hm_abs(B->dc[subPos + q][src] >> 16);
           if (!a) continue;
           const int baseLevel = (idx < 8) ? (2 + firstCoeff2) : 1;
           if (a >= baseLevel) {                                     // xWriteCoefRemainExGolomb :337
@@ -407,8 +415,8 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
     enc_bin(e, &r, C_SUBDIV + 2, 0);                               // transform_split of the 8x8 root TU: not split in this pass
     commonFrac = (uint32_t)r.frac;
   }
-  s8_setup(e, &e->cur, numModes);
-  const S8Par p = s8_params(e);
+  s8_setup(e, &e->cur, numModes, 0, 1, 1, C_INTRA_LUMA);            // luma cbf at the CU's root TU: context 1
+  const S8Par p = s8_params(e, 0);
   const Pel *org = e->fb.org[0] + (e->ctuY * 64 + t->y) * ps + e->ctuX * 64 + t->x;
   int dcVal;
   { int s = 0; HM_PAR_FOR(i, 8) s += e->u.ref.refTop[0][i + 1] + e->u.ref.refLeft[0][i + 1]; dcVal = (hm_wave_sum_i(s) + 8) / 16; }
@@ -492,7 +500,7 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
       s8_bin(e, A, k, &frac, S8_MODE, predIdx != -1);
       frac += 32768u * (uint32_t)(predIdx == -1 ? 5 : (predIdx ? 2 : 1));
       s8_bin(e, A, k, &frac, S8_CBF, cbf);
-      if (cbf) s8_code_coeff(e, A, B, k, scanType, &frac);
+      if (cbf) s8_code_coeff(e, A, B, k, k, 0, scanType, &frac);
       A->outCost[k] = calc_rd_cost(e, frac >> 15, A->outDist[k]);
     }
   }
@@ -503,4 +511,153 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
   const int bestMode = e->rdModeList[best];
   HM_SYNC();
   return bestMode;
+}
+
+// ------------------------------------------------------------------------------------------------
+// chroma of a 16x16 CU whose luma transform is not split: one 8x8 block per component under the five chroma modes
+// (estIntraPredChromaQT :2698-2849), ten evaluations from the CU's entry snapshot: sample work job after job on the 64 lanes, the RDOQ
+// chains one job per lane (job = 2 * modeIndex + component - 1), then one lane per mode counts the mode's bits (chroma prediction mode,
+// both cbfs, Cb and Cr coefficients: xGetIntraBitsQT :1038) and the modes are compared in the reference's order.  An 8x8 chroma block
+// never tries transform skip and always scans diagonally.  Writes the winner (dirC / cbf / ts of the CU, coefficients, reconstruction
+// into ws->reco) and returns its distortion.
+// ------------------------------------------------------------------------------------------------
+HM_FINL int s8_pred_sample_chroma(const Shared *e, int rs, int mode, int x, int y, int dcVal)
+{ // TComPrediction::predIntraAng for an 8x8 chroma block (no edge filters, unfiltered reference lines of slot rs)
+  const Pel *top = e->u.ref.refTop[rs], *left = e->u.ref.refLeft[rs];
+  if (mode == PLANAR_IDX) {
+    const int hor = (left[y + 1] << 3) + 8 + (x + 1) * (top[9] - left[y + 1]);
+    const int ver = (top[x + 1] << 3) + (y + 1) * (left[9] - top[x + 1]);
+    return (hor + ver) >> 4;
+  }
+  if (mode == DC_IDX) return dcVal;
+  const int isVer = mode >= 18;
+  const int angMode = isVer ? mode - VER_IDX : -(mode - HOR_IDX);
+  const int absAng = HM_ANG_TABLE[hm_abs(angMode)], invAngle = HM_INV_ANG_TABLE[hm_abs(angMode)];
+  const int angle = angMode < 0 ? -absAng : absAng;
+  const Pel *mainR = isVer ? top : left, *sideR = isVer ? left : top;
+  const int xx = isVer ? x : y, yy = isVer ? y : x;
+  if (angle == 0) return mainR[xx + 1];
+  const int deltaPos = (yy + 1) * angle, di = deltaPos >> 5, df = deltaPos & 31;
+  const int i0 = xx + di + 1;
+  const int a = i0 >= 0 ? mainR[i0] : sideR[(128 - i0 * invAngle) >> 8];
+  if (!df) return a;
+  const int i1 = i0 + 1;
+  const int b = i1 >= 0 ? mainR[i1] : sideR[(128 - i1 * invAngle) >> 8];
+  return ((32 - df) * a + df * b + 16) >> 5;
+}
+HM_DEV HM_NOINLINE uint32_t simt8_chroma_cu16(Shared *e, int cuZ)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ);
+  CtuMeta *m = (&e->meta); WorkSpace *ws = e->ws;
+  const TU t = tu_root(e, cuZ, 2);
+  const int r = hm_z2r(cuZ), bitDepth = e->bitDepth;
+  const int x4 = e->ctuX * 16 + (r & 15), y4 = e->ctuY * 16 + (r >> 4), px = e->ctuX * 32 + t.cx, py = e->ctuY * 32 + t.cy;
+  init_adi_pattern(e, 2, px, py, 8, x4, y4, 4, 0);
+  HM_PAR_FOR(i, 17) { e->u.ref.refTop[1][i] = e->u.ref.refTop[0][i]; e->u.ref.refLeft[1][i] = e->u.ref.refLeft[0][i]; }
+  HM_SYNC();
+  init_adi_pattern(e, 1, px, py, 8, x4, y4, 4, 0);
+  int modeList[5] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX, DM_CHROMA_IDX};       // getAllowedChromaDir, TComDataCU.cpp:1486
+  const int lumaDir = m->dirL[cuZ];
+  for (int i = 0; i < 4; i++) if (lumaDir == modeList[i]) { modeList[i] = 34; break; }
+  Simt8A *A = s8_a(e); Simt8B *B = s8_b(e);
+  s8_setup(e, &e->cur, 10, 1, 5, 5, C_CHROMA_PRED);                  // chroma cbf at the CU's root TU: context 5 + transform depth 0
+  const S8Par p = s8_params(e, 1);
+  const uint32_t baseFrac = (uint32_t)(e->cur.frac & 32767);
+  int dcVal[2];
+  for (int c = 0; c < 2; c++) { int s = 0; HM_PAR_FOR(i, 8) s += e->u.ref.refTop[c][i + 1] + e->u.ref.refLeft[c][i + 1]; dcVal[c] = (hm_wave_sum_i(s) + 8) / 16; }
+  const int s1 = 3 + bitDepth + 6 - 15, a1 = 1 << (s1 - 1), s2 = 9, a2 = 256;
+  const int maxv = (1 << bitDepth) - 1, shiftSse = (bitDepth - 8) << 1, is2 = 20 - bitDepth;
+  // ---- residual + forward transform of every job
+  for (int job = 0; job < 10; job++) {
+    const int c = job & 1, dirC = modeList[job >> 1], mode = dirC == DM_CHROMA_IDX ? lumaDir : dirC, ps = e->stride[1 + c];
+    const Pel *org = e->fb.org[1 + c] + (size_t)py * ps + px;
+    HM_PAR_FOR(l, 64) { const int y = l >> 3, x = l & 7; A->tile[0][l] = org[y * ps + x] - s8_pred_sample_chroma(e, c, mode, x, y, dcVal[c]); }
+    HM_SYNC();
+    HM_PAR_FOR(l, 64) {
+      const int j = l >> 3, kk = l & 7; int32_t acc = 0;
+      for (int i = 0; i < 8; i++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][j * 8 + i];
+      A->tile[1][kk * 8 + j] = (acc + a1) >> s1;
+    }
+    HM_SYNC();
+    HM_PAR_FOR(l, 64) {
+      const int blkPos = B->scan[SCAN_DIAG][l], kk = blkPos >> 3, j = blkPos & 7; int32_t acc = 0;
+      for (int i = 0; i < 8; i++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][j * 8 + i];
+      A->cs[l][job] = (int16_t)((acc + a2) >> s2);
+    }
+    HM_SYNC();
+  }
+  HM_WAVE_FOR(k) { if (k < 10) A->outCbf[k] = (uint8_t)(s8_rdoq(A, B, p, k, SCAN_DIAG) > 0); }
+  HM_SYNC();
+  // ---- reconstruction + distortion of a job (also used for the winner's reconstruction afterwards)
+  for (int pass = 0; pass < 12; pass++) {
+    int job = pass;
+    if (pass == 10) {                                                // all costs are in: bits and decision, then the winner's two jobs once more
+      HM_WAVE_FOR(k) {
+        if (k < 10 && !(k & 1)) {
+          const int dirC = modeList[k >> 1];
+          uint32_t frac = baseFrac;
+          s8_bin(e, A, k, &frac, S8_MODE, dirC != DM_CHROMA_IDX);    // codeIntraDirChroma :692
+          if (dirC != DM_CHROMA_IDX) frac += 2u * 32768u;
+          const int cbfU = A->outCbf[k], cbfV = A->outCbf[k + 1];
+          s8_bin(e, A, k, &frac, S8_CBF, cbfU);                      // xEncSubdivCbfQT :856: both cbfs at the root TU
+          s8_bin(e, A, k, &frac, S8_CBF, cbfV);
+          if (cbfU) s8_code_coeff(e, A, B, k, k, 1, SCAN_DIAG, &frac);
+          if (cbfV) s8_code_coeff(e, A, B, k, k + 1, 1, SCAN_DIAG, &frac);
+          const uint32_t dist = A->outDist[k] + A->outDist[k + 1];
+          A->outCost[k] = calc_rd_cost(e, frac >> 15, dist);
+        }
+      }
+      HM_SYNC();
+      double bestCost = HM_MAX_DOUBLE; int best = 0;
+      for (int mi = 0; mi < 5; mi++) { const double v = A->outCost[2 * mi]; if (v < bestCost) { bestCost = v; best = mi; } }
+      best = HM_UNI(best);
+      if (hm_lane() == 0) A->pad[0] = (uint8_t)best;
+      HM_SYNC();
+    }
+    const int best = pass >= 10 ? A->pad[0] : 0;
+    if (pass >= 10) job = 2 * best + (pass - 10);
+    const int c = job & 1, dirC = modeList[job >> 1], mode = dirC == DM_CHROMA_IDX ? lumaDir : dirC, ps = e->stride[1 + c], cbf = A->outCbf[job];
+    const Pel *org = e->fb.org[1 + c] + (size_t)py * ps + px;
+    if (cbf) {
+      HM_PAR_FOR(l, 64) {
+        const int lvv = hm_clip3(p.dqMin, p.dqMax, B->dc[l][job] >> 16);
+        int v;
+        if (p.dqShift > 0) v = (lvv * p.dqScale + (1 << (p.dqShift - 1))) >> p.dqShift;
+        else v = (int)((unsigned)(lvv * p.dqScale) << (-p.dqShift));
+        A->tile[0][B->scan[SCAN_DIAG][l]] = hm_clip3(-32768, 32767, v);
+      }
+      HM_SYNC();
+      HM_PAR_FOR(l, 64) {
+        const int j = l >> 3, i = l & 7; int32_t acc = 0;
+        for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
+        A->tile[1][j * 8 + i] = hm_clip3(-32768, 32767, (acc + 64) >> 7);
+      }
+      HM_SYNC();
+    }
+    uint32_t sse = 0;
+    const int po = HM_PLANE_OFF(1 + c);
+    HM_PAR_FOR(l, 64) {
+      const int j = l >> 3, i = l & 7; int resi = 0;
+      if (cbf) {
+        int32_t acc = 0;
+        for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
+        resi = hm_clip3(-32768, 32767, (acc + (1 << (is2 - 1))) >> is2);
+      }
+      const int rr = hm_clip3(0, maxv, s8_pred_sample_chroma(e, c, mode, i, j, dcVal[c]) + resi);
+      const int d = org[j * ps + i] - rr; sse += (uint32_t)((d * d) >> shiftSse);
+      if (pass >= 10) {                                              // the winner: reconstruction and levels to where the CU's data lives
+        ws->reco[po + (t.cy + j) * 32 + t.cx + i] = (Pel)rr;
+        e->cc[po + t.cOff + B->scan[SCAN_DIAG][l]] = cbf ? (B->dc[l][job] >> 16) : 0;
+      }
+    }
+    const uint32_t dsum = hm_wave_sum(sse);
+    if (pass < 10 && hm_lane() == 0) A->outDist[job] = (uint32_t)(e->fb.chromaWeight * (double)dsum);   // getDistPart, TComRdCost.cpp:447-450
+    HM_SYNC();
+  }
+  const int best = A->pad[0], cbfU = A->outCbf[2 * best], cbfV = A->outCbf[2 * best + 1];
+  const uint32_t bestDist = A->outDist[2 * best] + A->outDist[2 * best + 1];
+  const int bm = modeList[best];
+  HM_PAR_FOR(i, 16) { m->cbf[1][cuZ + i] = (uint8_t)cbfU; m->cbf[2][cuZ + i] = (uint8_t)cbfV; m->ts[1][cuZ + i] = 0; m->ts[2][cuZ + i] = 0; m->dirC[cuZ + i] = (uint8_t)bm; }
+  HM_SYNC();
+  return bestDist;
 }
