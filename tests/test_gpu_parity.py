@@ -581,6 +581,25 @@ def test_full_size_1080p_main10_batch_equals_single(hm):
     enc.close()
 
 
+def test_row_bands_two_real_ranks_over_gloo():
+    """the band pipeline with REAL ranks: two processes (torch.distributed.run, gloo transport) share the GPU, each searches its band of the
+    same pictures through hm-16.2_amd/bands.py + TorchTransport, rank 0 gathers the bands and compares them with an unsplit run"""
+    import os
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", os.path.join(common.ROOT, "tools", "bands_two_ranks.py"), "416", "240", "3", "2"],
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    text = out.stdout.decode()
+    assert out.returncode == 0 and "bands equal the unsplit run: True" in text, text[-2000:]
+
+
+def test_create_reports_out_of_memory(hm):
+    """a batch that cannot fit the device is refused with HM355_ERR_NOMEM before anything large is allocated"""
+    with pytest.raises(RuntimeError, match="rc=-3"):
+        hm.Encoder(3840, 2160, 10, 1, max_batch=100000)
+
+
 def test_hip_primitive_kats(hm):
     """SAD/SSE/SATD and transform kernels vs the reference's known answers"""
     k = np.load(common.GOLD + "/kat_primitives.npz")
