@@ -344,6 +344,7 @@ struct Shared {
   double outCost; uint32_t outBits, outDist; double outRdCost; uint32_t outDistY;
   uint32_t satd[36];                   // SATD of the 35 intra modes of the PU under test
   int32_t mpmZ, mpmNum, mpmPreds[3];   // most-probable-mode list of the PU under test (same for all its candidates)
+  int32_t s8Winner, s8Reuse;           // hm355_simt8.h: the first pass's winning candidate; set while its evaluation can stand in for the closing pass's unsplit 8x8 TU
   // inter (P / B slice) state
   InterMeta *im;                       // motion arrays of the CTU under search (HBM)
   uint32_t mcost; MvD mvPredictor; int32_t costScale;   // TComRdCost motion-cost state
@@ -1832,6 +1833,7 @@ HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
 // ------------------------------------------------------------------------------------------------
 // returns distortion through *distY and adds the RD cost to *rdCost, exactly like the recursive reference
 HM_DEV HM_NOINLINE void simt4_luma_leaf(Shared *e, TU tv);      // hm355_simt4.h
+HM_DEV HM_NOINLINE void simt8_luma_winner_as_single_tu(Shared *e, TU tv);      // hm355_simt8.h
 HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirst)
 {
   HM_ENTRY(e); checkFirst = HM_UNI(checkFirst); rootv = hm_uni_struct(rootv);
@@ -1880,6 +1882,16 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
           simt4_luma_leaf(e, *t);
           HM_PROF_END(e, PR_S4LEAF);
           f->singleDist = e->outDistY;
+          f->singleCost = calc_rd_cost(e, e->outBits, f->singleDist);
+        } else if (sp == 0 && e->s8Reuse) {
+          // closing pass of an 8x8 PU: its unsplit 8x8 TU is the evaluation the candidates-in-lanes first pass already made for the winner
+          e->s8Reuse = 0;
+          cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+          par_set8(m->ts[0] + z, 0, t->parts);
+          par_set8(m->tr + z, t->trDepth, t->parts);
+          simt8_luma_winner_as_single_tu(e, *t);
+          f->singleDist = e->outDistY; f->singleCbf = e->outDist;
+          par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
           f->singleCost = calc_rd_cost(e, e->outBits, f->singleDist);
         } else {
           if (f->checkSplit) cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
@@ -2039,6 +2051,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       bestPUMode = HM_UCALL(simt8_luma_first_pass(e, t, numModesForFullRD));
       HM_PROF_END(e, PR_S8L);
       firstPass = numModesForFullRD;
+      e->s8Reuse = 1;
     }
     for (int pass = firstPass; pass <= numModesForFullRD; pass++) {
       const int last = (pass == numModesForFullRD);
@@ -2486,7 +2499,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
 {
   // uniform context (every lane writes the same values)
   e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab;
-  e->width = P->width; e->height = P->height; e->bitDepth = P->bitDepth; e->wCtu = P->wCtu; e->mpmZ = -1;
+  e->width = P->width; e->height = P->height; e->bitDepth = P->bitDepth; e->wCtu = P->wCtu; e->mpmZ = -1; e->s8Reuse = 0;
   for (int c = 0; c < 3; c++) e->stride[c] = P->stride[c];
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
   e->cc = e->fb.coef + (size_t)e->ctuAddr * HM_COEF_CTU;

@@ -16,7 +16,7 @@ struct Simt8A {                           // overlays Shared::bufA
   int32_t tile[2][64];                    // transform stages of the candidate under the lanes
   int32_t tab[T8_N];                      // bit costs of the start state
   double outCost[HM_S8];
-  uint32_t outDist[HM_S8];
+  uint32_t outDist[HM_S8], outFrac[HM_S8];
   int16_t cs[64][HM_S8];                  // coefficients in scan order
   uint8_t ctx[S8_NCTX][HM_S8];            // context states of each candidate
   uint8_t outCbf[HM_S8], pad[5];
@@ -501,6 +501,7 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
       frac += 32768u * (uint32_t)(predIdx == -1 ? 5 : (predIdx ? 2 : 1));
       s8_bin(e, A, k, &frac, S8_CBF, cbf);
       if (cbf) s8_code_coeff(e, A, B, k, k, 0, scanType, &frac);
+      A->outFrac[k] = frac;
       A->outCost[k] = calc_rd_cost(e, frac >> 15, A->outDist[k]);
     }
   }
@@ -509,6 +510,7 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
   for (int c = 0; c < numModes; c++) { const double v = A->outCost[c]; if (v < bestCost) { bestCost = v; best = c; } }
   best = HM_UNI(best);
   const int bestMode = e->rdModeList[best];
+  e->s8Winner = best;                                              // simt8_luma_winner_as_single_tu picks the winner's evaluation up from the overlays
   HM_SYNC();
   return bestMode;
 }
@@ -660,4 +662,74 @@ HM_DEV HM_NOINLINE uint32_t simt8_chroma_cu16(Shared *e, int cuZ)
   HM_PAR_FOR(i, 16) { m->cbf[1][cuZ + i] = (uint8_t)cbfU; m->cbf[2][cuZ + i] = (uint8_t)cbfV; m->ts[1][cuZ + i] = 0; m->ts[2][cuZ + i] = 0; m->dirC[cuZ + i] = (uint8_t)bm; }
   HM_SYNC();
   return bestDist;
+}
+
+// The closing pass of estIntraPredQT (:2566-2600) starts with the unsplit evaluation of the winner's 8x8 transform block -- the very
+// evaluation the first pass above made for it, from the same snapshot.  Instead of repeating it (xIntraCodingTUBlock + xGetIntraBitsQT), the
+// winner's results are put where the residual quadtree expects them: levels and reconstruction in the layer buffers of the 8x8 size, the
+// estimator (e->cur) advanced past the block's syntax (the bins every candidate codes alike, then the contexts and the bit count of the
+// winner's lane).  Must run right after simt8_luma_first_pass (the overlays and the reference lines are still in place), with e->cur
+// holding the CU's entry snapshot.  Distortion / bits / cbf in e->outDistY / e->outBits / e->outDist.
+HM_DEV HM_NOINLINE void simt8_luma_winner_as_single_tu(Shared *e, TU tv)
+{
+  HM_ENTRY(e); tv = hm_uni_struct(tv);
+  const TU *t = &tv; WorkSpace *ws = e->ws;
+  Simt8A *A = s8_a(e); Simt8B *B = s8_b(e);
+  const int best = HM_UNI(e->s8Winner), z = t->cuZ + t->relZ, ps = e->stride[0], bitDepth = e->bitDepth;
+  const int mode = e->rdModeList[best], cbf = A->outCbf[best];
+  int scanType = SCAN_DIAG;
+  if (hm_abs(mode - VER_IDX) <= 4) scanType = SCAN_HOR; else if (hm_abs(mode - HOR_IDX) <= 4) scanType = SCAN_VER;
+  const S8Par p = s8_params(e, 0);
+  int dcVal;
+  { int s = 0; HM_PAR_FOR(i, 8) s += e->u.ref.refTop[0][i + 1] + e->u.ref.refLeft[0][i + 1]; dcVal = (hm_wave_sum_i(s) + 8) / 16; }
+  const int maxv = (1 << bitDepth) - 1, is2 = 20 - bitDepth;
+  TCoeff *coef = ws->qtCoef[2] + z * 16; Pel *rq = ws->qtRec[2] + t->y * 64 + t->x;
+  Pel *recPic = e->fb.rec[0] + (e->ctuY * 64 + t->y) * ps + e->ctuX * 64 + t->x;
+  if (cbf) {
+    HM_PAR_FOR(l, 64) {
+      const int lv = B->dc[l][best] >> 16, blk = B->scan[scanType][l];
+      coef[blk] = lv;
+      const int lvv = hm_clip3(p.dqMin, p.dqMax, lv);
+      int v;
+      if (p.dqShift > 0) v = (lvv * p.dqScale + (1 << (p.dqShift - 1))) >> p.dqShift;
+      else v = (int)((unsigned)(lvv * p.dqScale) << (-p.dqShift));
+      A->tile[0][blk] = hm_clip3(-32768, 32767, v);
+    }
+    HM_SYNC();
+    HM_PAR_FOR(l, 64) {
+      const int j = l >> 3, i = l & 7; int32_t acc = 0;
+      for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
+      A->tile[1][j * 8 + i] = hm_clip3(-32768, 32767, (acc + 64) >> 7);
+    }
+    HM_SYNC();
+  } else { HM_PAR_FOR(l, 64) coef[l] = 0; }
+  HM_PAR_FOR(l, 64) {
+    const int j = l >> 3, i = l & 7; int resi = 0;
+    if (cbf) {
+      int32_t acc = 0;
+      for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
+      resi = hm_clip3(-32768, 32767, (acc + (1 << (is2 - 1))) >> is2);
+    }
+    const Pel rr = (Pel)hm_clip3(0, maxv, pred_sample(e, mode, 8, 3, i, j, dcVal, bitDepth) + resi);
+    rq[j * 64 + i] = rr; recPic[j * ps + i] = rr;
+  }
+  HM_SYNC();
+  { // the estimator: the bins in front of the lane's own (same as simt8_luma_first_pass counted), then the lane's contexts and bit count
+    CabacR r; cabr_load(r, &e->cur);
+    r.frac &= 32767;
+    if (e->im) { code_skip_flag(e, &r, t->cuZ); enc_bin(e, &r, C_PRED_MODE, 1); }
+    enc_bin(e, &r, C_PART, 1);
+    enc_bin(e, &r, C_SUBDIV + 2, 0);
+    cabr_store(r, &e->cur);
+  }
+  HM_PAR_FOR(j, S8_NCTX - 1) {
+    int c;
+    if (j < S8_ONE) c = C_SIG + j; else if (j < S8_ABS) c = C_ONE + (j - S8_ONE); else if (j < S8_LX) c = C_ABS + (j - S8_ABS);
+    else if (j < S8_LY) c = C_LASTX + 3 + (j - S8_LX); else if (j < S8_CG) c = C_LASTY + 3 + (j - S8_LY);
+    else if (j < S8_CBF) c = C_SIG_CG + (j - S8_CG); else if (j == S8_CBF) c = C_QT_CBF + 1; else c = C_INTRA_LUMA;
+    e->cur.s[c] = A->ctx[j][best];
+  }
+  e->cur.frac = (uint64_t)A->outFrac[best];
+  e->outDistY = A->outDist[best]; e->outBits = A->outFrac[best] >> 15; e->outDist = (uint32_t)cbf;
+  HM_SYNC();
 }
