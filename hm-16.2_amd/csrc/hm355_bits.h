@@ -119,8 +119,9 @@ HM_DEV inline void cabw_finish(CabacW *w)
 // registers as in CabacR (4 bytes per lane, read with v_readlane), low / range / bitsLeft / the bin count in scalars; only the byte output
 // (once per 8 bits) goes through the LDS copy.  A state needs 7 bits: bit 7 of its byte carries the "coded" flag while it is in registers.
 struct CabacWR { CabacW *w; HM_LV(int32_t, st); HM_LV(int32_t, lpsRow); HM_LV(int32_t, nlps); uint32_t low, range; int32_t bitsLeft; uint32_t bins; };
-HM_DEV inline void cabr_load(CabacWR &r, CabacW *c)
+HM_DEV inline void cabr_load(const Shared *e, CabacWR &r, CabacW *c)
 {
+  (void)e;
   r.w = c;
   HM_WAVE_FOR(k) {
     HM_LVK(r.st, k) = k < 46 ? (((const int32_t *)c->s)[k] | ((((const int32_t *)c->used)[k] & 0x01010101) << 7)) : 0;

@@ -324,6 +324,7 @@ struct RefLds {
 struct Shared {
   Cabac cur;                           // m_pcRDGoOnSbacCoder
   int8_t tmat[32 * HM_TSTRIDE];        // 32-point transform matrix, padded rows
+  int8_t dst4[16];                     // the 4-point DST of intra luma 4x4 blocks
   int32_t bufA[32 * HM_TSTRIDE];
   union {                              // phase-exclusive LDS: transform temp | RDOQ state | intra reference samples
     int32_t bufB[32 * HM_TSTRIDE];
@@ -456,7 +457,7 @@ HM_DEV inline int hm_next_state(int st, int bin) { return bin == (st & 1) ? (st 
 HM_DEV inline void enc_bin(const Shared *e, Cabac *c, int ctx, int bin)
 {
   const int st = c->s[ctx];
-  c->frac += (uint64_t)HM_ENTROPY_BITS[st ^ bin];
+  c->frac += (uint64_t)e->ebits[st ^ bin];
   c->s[ctx] = hm_next_state(st, bin);
 }
 HM_DEV inline void enc_ep(Cabac *c, int n) { c->frac += (uint64_t)32768 * (uint64_t)n; }
@@ -560,9 +561,10 @@ HM_DEV inline void load_tmat(Shared *e)
     if (m <= 32) v = HM_DCT_C[m]; else if (m <= 64) v = -HM_DCT_C[64 - m]; else if (m <= 96) v = -HM_DCT_C[m - 64]; else v = HM_DCT_C[128 - m];
     e->tmat[k * HM_TSTRIDE + n] = (int8_t)v;
   }
+  HM_PAR_FOR(i, 16) e->dst4[i] = HM_DST4[i];
   HM_SYNC();
 }
-HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst ? HM_DST4[k * 4 + j] : e->tmat[(k * (32 / n)) * HM_TSTRIDE + j]; }
+HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst ? e->dst4[k * 4 + j] : e->tmat[(k * (32 / n)) * HM_TSTRIDE + j]; }
 
 // forward: src (bufA, [row][col]) -> dst (bufA); xTrMxN, TComTrQuant.cpp:836-890
 HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth)
@@ -982,7 +984,7 @@ HM_DEV inline int sig_ctx_inc(int pattern, int firstCtx, int blkPos, int log2n, 
   const int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
   if (posX + posY == 0) return 0;
   int offset;
-  if (log2n == 2) offset = HM_CTX_IND_MAP_4x4[4 * posY + posX];
+  if (log2n == 2) offset = (int)((0x8877886654325410ull >> (4 * (4 * posY + posX))) & 15);      // ctxIndMap4x4 (HM_CTX_IND_MAP_4x4), 16 nibbles: no table read per lane
   else {
     int cnt; const int xs = posX & 3, ys = posY & 3;
     if (pattern == 0) cnt = (xs + ys >= 3) ? 0 : ((xs + ys >= 1) ? 1 : 2);
@@ -1110,10 +1112,10 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   HM_LV(double, vCGSig);                  // cost of the coded-sub-block flag per coefficient group (scan order)
   HM_WAVE_FOR(k) {
     const int bin = k & 1, c = k >> 1;
-    HM_LVK(tSig, k) = c < (chroma ? 16 : 28) ? HM_ENTROPY_BITS[cb->s[sigOff + c] ^ bin] : 0;
-    HM_LVK(tOne, k) = c < 30 ? HM_ENTROPY_BITS[cb->s[C_ONE + c] ^ bin] : 0;                   // C_ABS follows C_ONE
-    HM_LVK(tLast, k) = c < 30 ? HM_ENTROPY_BITS[cb->s[(c < 15 ? C_LASTX + c : C_LASTY + c - 15) + (chroma ? 15 : 0)] ^ bin] : 0;
-    HM_LVK(tMisc, k) = c < 15 ? HM_ENTROPY_BITS[cb->s[c < 4 ? C_SIG_CG + c : (c < 14 ? C_QT_CBF + c - 4 : C_ROOT_CBF)] ^ bin] : 0;   // cbfCtx 10 = root cbf
+    HM_LVK(tSig, k) = c < (chroma ? 16 : 28) ? e->ebits[cb->s[sigOff + c] ^ bin] : 0;
+    HM_LVK(tOne, k) = c < 30 ? e->ebits[cb->s[C_ONE + c] ^ bin] : 0;                   // C_ABS follows C_ONE
+    HM_LVK(tLast, k) = c < 30 ? e->ebits[cb->s[(c < 15 ? C_LASTX + c : C_LASTY + c - 15) + (chroma ? 15 : 0)] ^ bin] : 0;
+    HM_LVK(tMisc, k) = c < 15 ? e->ebits[cb->s[c < 4 ? C_SIG_CG + c : (c < 14 ? C_QT_CBF + c - 4 : C_ROOT_CBF)] ^ bin] : 0;   // cbfCtx 10 = root cbf
     HM_LVK(tLastCost, k) = 0;
     HM_LVK(vCGSig, k) = 0;
   }
@@ -1396,11 +1398,11 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
 // from its LDS home at entry and store it back at exit.
 // ------------------------------------------------------------------------------------------------
 struct CabacR { HM_LV(int32_t, st); HM_LV(int32_t, eb0); HM_LV(int32_t, eb1); HM_LV(int32_t, lps); uint64_t frac; };
-HM_DEV inline void cabr_load(CabacR &r, const Cabac *c)
+HM_DEV inline void cabr_load(const Shared *e, CabacR &r, const Cabac *c)
 {
   HM_WAVE_FOR(k) {
     HM_LVK(r.st, k) = k < (int)(sizeof(c->s) / 4) ? ((const int32_t *)c->s)[k] : 0;
-    HM_LVK(r.eb0, k) = HM_ENTROPY_BITS[k]; HM_LVK(r.eb1, k) = HM_ENTROPY_BITS[64 + k];
+    HM_LVK(r.eb0, k) = e->ebits[k]; HM_LVK(r.eb1, k) = e->ebits[64 + k];
     HM_LVK(r.lps, k) = ((const int32_t *)HM_NEXT_LPS)[k & 31];
   }
   r.frac = c->frac;
@@ -1445,7 +1447,7 @@ template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   const unsigned long long profT0 = __builtin_readcyclecounter();
 #endif
-  typename EngOf<C>::R r; cabr_load(r, c);
+  typename EngOf<C>::R r; cabr_load(e, r, c);
   if (n == 4) enc_bin(e, &r, C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
   int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->u.rq.cgFlag;
@@ -1705,7 +1707,7 @@ HM_DEV HM_NOINLINE uint32_t intra_bits_qt(Shared *e, TU tv, int bLuma, int bChro
   const TU *t = &tv;
   HM_PROF_BEGIN(e, PR_BITS);
   {
-    CabacR r; cabr_load(r, &e->cur);
+    CabacR r; cabr_load(e, r, &e->cur);
     r.frac &= 32767;                       // resetBits, TEncBinCoderCABAC.cpp:161
     enc_intra_header(e, &r, t, bLuma, bChroma);
     enc_subdiv_cbf_qt(e, &r, t, bLuma, bChroma);
@@ -2006,7 +2008,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
           if (k < 35) {
             int predIdx = -1;
             for (int i = 0; i < 3; i++) if (k == preds[i]) predIdx = i;
-            uint64_t fb = frac0 + (uint64_t)HM_ENTROPY_BITS[st0 ^ (predIdx != -1)];
+            uint64_t fb = frac0 + (uint64_t)e->ebits[st0 ^ (predIdx != -1)];
             fb += (uint64_t)32768 * (uint64_t)(predIdx == -1 ? 5 : (predIdx ? 2 : 1));
             const uint32_t modeBits = (uint32_t)(fb >> 15);
             cost = (double)e->satd[k] + (double)modeBits * e->fb.sqrtLambda;

@@ -83,14 +83,14 @@ HM_DEV inline void s4_setup(Shared *e, const Cabac *cb, int chroma, int cbfCtx, 
   const int lxOff = C_LASTX + (chroma ? 15 : 0), lyOff = C_LASTY + (chroma ? 15 : 0);
   HM_PAR_FOR(i, T4_N) {
     int v = 0;
-    if (i < T4_ONE) v = HM_ENTROPY_BITS[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
-    else if (i < T4_ABS) v = HM_ENTROPY_BITS[cb->s[oneOff + ((i - T4_ONE) >> 1)] ^ (i & 1)];
-    else if (i < T4_LASTX) v = HM_ENTROPY_BITS[cb->s[absOff] ^ (i & 1)];
+    if (i < T4_ONE) v = e->ebits[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
+    else if (i < T4_ABS) v = e->ebits[cb->s[oneOff + ((i - T4_ONE) >> 1)] ^ (i & 1)];
+    else if (i < T4_LASTX) v = e->ebits[cb->s[absOff] ^ (i & 1)];
     else if (i < T4_CBF) { // cost of the last-position group index g = 0..3: g ones, then a zero unless g is the maximum (xGetRateLast, TComTrQuant.cpp:2815)
       const int g = (i - T4_LASTX) & 3, off = i < T4_LASTY ? lxOff : lyOff;
-      for (int c = 0; c < g; c++) v += HM_ENTROPY_BITS[cb->s[off + c] ^ 1];
-      if (g < 3) v += HM_ENTROPY_BITS[cb->s[off + g] ^ 0];
-    } else if (i < T4_CBF + 2) v = HM_ENTROPY_BITS[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
+      for (int c = 0; c < g; c++) v += e->ebits[cb->s[off + c] ^ 1];
+      if (g < 3) v += e->ebits[cb->s[off + g] ^ 0];
+    } else if (i < T4_CBF + 2) v = e->ebits[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
     A->tab[i] = v;
   }
   HM_PAR_FOR(i, 128) A->lps[i] = HM_NEXT_LPS[i];
@@ -492,7 +492,7 @@ HM_DEV HM_NOINLINE void simt4_luma_pu(Shared *e, TU tv, int numModes)
   // values for all of them; none of those contexts is touched again inside the block
   uint32_t commonFrac;
   {
-    CabacR r; cabr_load(r, &e->cur);
+    CabacR r; cabr_load(e, r, &e->cur);
     r.frac &= 32767;
     if (t->relZ == 0) {
       if (e->im) { code_skip_flag(e, &r, t->cuZ); enc_bin(e, &r, C_PRED_MODE, 1); }
@@ -654,7 +654,7 @@ HM_DEV HM_NOINLINE void simt4_luma_leaf(Shared *e, TU tv)
   const int z = t->cuZ + t->relZ, ps = e->stride[0], r = hm_z2r(z), mode = m->dirL[z];
   init_adi_pattern(e, 0, e->ctuX * 64 + t->x, e->ctuY * 64 + t->y, 4, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), 1, 0);
   { // the bins in front of the block's own (xEncIntraHeader :965), on the estimator itself
-    CabacR cr; cabr_load(cr, &e->cur);
+    CabacR cr; cabr_load(e, cr, &e->cur);
     cr.frac &= 32767;
     enc_intra_header(e, &cr, t, 1, 0);
     cabr_store(cr, &e->cur);

@@ -58,16 +58,16 @@ HM_DEV inline void s8_setup(Shared *e, const Cabac *cb, int jobs, int chroma, in
   const int lxOff = chroma ? C_LASTX + 15 : C_LASTX + 3, lyOff = chroma ? C_LASTY + 15 : C_LASTY + 3, cgOff = C_SIG_CG + (chroma ? 2 : 0);
   HM_PAR_FOR(i, T8_N) {
     int v = 0;
-    if (i < T8_ONE) v = (chroma && (i >> 1) >= 16) ? 0 : HM_ENTROPY_BITS[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
-    else if (i < T8_ABS) v = (chroma && ((i - T8_ONE) >> 1) >= 8) ? 0 : HM_ENTROPY_BITS[cb->s[oneOff + ((i - T8_ONE) >> 1)] ^ (i & 1)];
-    else if (i < T8_LASTX) v = (chroma && ((i - T8_ABS) >> 1) >= 2) ? 0 : HM_ENTROPY_BITS[cb->s[absOff + ((i - T8_ABS) >> 1)] ^ (i & 1)];
+    if (i < T8_ONE) v = (chroma && (i >> 1) >= 16) ? 0 : e->ebits[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
+    else if (i < T8_ABS) v = (chroma && ((i - T8_ONE) >> 1) >= 8) ? 0 : e->ebits[cb->s[oneOff + ((i - T8_ONE) >> 1)] ^ (i & 1)];
+    else if (i < T8_LASTX) v = (chroma && ((i - T8_ABS) >> 1) >= 2) ? 0 : e->ebits[cb->s[absOff + ((i - T8_ABS) >> 1)] ^ (i & 1)];
     else if (i < T8_CG) { // last-position group index g = 0..5 of an 8x8 block: context (g >> 1) of the block's three; g > 3 adds one bypass bit (xGetRateLast :2815)
       const int g = (i - T8_LASTX) % 6, off = i < T8_LASTY ? lxOff : lyOff;
-      for (int c = 0; c < g; c++) v += HM_ENTROPY_BITS[cb->s[off + (c >> 1)] ^ 1];
-      if (g < 5) v += HM_ENTROPY_BITS[cb->s[off + (g >> 1)] ^ 0];
+      for (int c = 0; c < g; c++) v += e->ebits[cb->s[off + (c >> 1)] ^ 1];
+      if (g < 5) v += e->ebits[cb->s[off + (g >> 1)] ^ 0];
       if (g > 3) v += 32768 * ((g - 2) >> 1);
-    } else if (i < T8_CBF) v = HM_ENTROPY_BITS[cb->s[cgOff + ((i - T8_CG) >> 1)] ^ (i & 1)];
-    else v = HM_ENTROPY_BITS[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
+    } else if (i < T8_CBF) v = e->ebits[cb->s[cgOff + ((i - T8_CG) >> 1)] ^ (i & 1)];
+    else v = e->ebits[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
     A->tab[i] = v;
   }
   HM_PAR_FOR(i, 128) A->lps[i] = HM_NEXT_LPS[i];
@@ -408,7 +408,7 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
   Simt8A *A = s8_a(e); Simt8B *B = s8_b(e);
   uint32_t commonFrac;                                             // bins every candidate codes alike (xEncIntraHeader :965, xEncSubdivCbfQT :856)
   {
-    CabacR r; cabr_load(r, &e->cur);
+    CabacR r; cabr_load(e, r, &e->cur);
     r.frac &= 32767;
     if (e->im) { code_skip_flag(e, &r, t->cuZ); enc_bin(e, &r, C_PRED_MODE, 1); }
     enc_bin(e, &r, C_PART, 1);                                     // 2Nx2N at the smallest CU size
@@ -715,7 +715,7 @@ HM_DEV HM_NOINLINE void simt8_luma_winner_as_single_tu(Shared *e, TU tv)
   }
   HM_SYNC();
   { // the estimator: the bins in front of the lane's own (same as simt8_luma_first_pass counted), then the lane's contexts and bit count
-    CabacR r; cabr_load(r, &e->cur);
+    CabacR r; cabr_load(e, r, &e->cur);
     r.frac &= 32767;
     if (e->im) { code_skip_flag(e, &r, t->cuZ); enc_bin(e, &r, C_PRED_MODE, 1); }
     enc_bin(e, &r, C_PART, 1);
