@@ -1885,7 +1885,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
           HM_PROF_END(e, PR_S4LEAF);
           f->singleDist = e->outDistY;
           f->singleCost = calc_rd_cost(e, e->outBits, f->singleDist);
-        } else if (sp == 0 && e->s8Reuse) {
+        } else if (sp == 0 && e->s8Reuse == 1) {
           // closing pass of an 8x8 PU: its unsplit 8x8 TU is the evaluation the candidates-in-lanes first pass already made for the winner
           e->s8Reuse = 0;
           cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
@@ -1895,6 +1895,22 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
           f->singleDist = e->outDistY; f->singleCbf = e->outDist;
           par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
           f->singleCost = calc_rd_cost(e, e->outBits, f->singleDist);
+        } else if (sp == 0 && e->s8Reuse == 2) {
+          // closing pass of a 16x16 / 32x32 PU: its unsplit TU is the winner's first-pass evaluation (same snapshot, same mode), whose levels and
+          // reconstruction est_intra_pred_qt kept (xSetIntraResultQT) and whose estimator state it parked in this depth's CI_QT_TRAFO_TEST slot
+          e->s8Reuse = 0;
+          cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
+          par_set8(m->ts[0] + z, 0, t->parts);
+          par_set8(m->tr + z, t->trDepth, t->parts);
+          {
+            const int n = 1 << log2, layer = 5 - log2;
+            par_copy32(e->ws->qtCoef[layer] + z * 16, e->cc + z * 16, n * n);
+            par_copy_blk(e->ws->qtRec[layer] + t->y * 64 + t->x, 64, e->ws->reco + t->y * 64 + t->x, 64, n);
+          }
+          f->singleCbf = e->ws->tmpCbf[0][0] & 1;
+          par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
+          f->singleDist = e->outDistY; f->singleCost = e->outRdCost;
+          cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)]);
         } else {
           if (f->checkSplit) cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
           par_set8(m->ts[0] + z, 0, t->parts);
@@ -2060,6 +2076,8 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       const int orgMode = last ? bestPUMode : rdModeList[pass];
       par_set8(m->dirL + z, orgMode, puParts);
       cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+      // 16x16 / 32x32 PUs: the closing pass takes its unsplit TU from the winner's first-pass evaluation instead of repeating it
+      if (last && (n == 16 || n == 32) && numModesForFullRD > 0) { e->s8Reuse = 2; e->outDistY = bestPUDistY; e->outRdCost = bestPUCost; }
       recur_intra_coding_qt(e, t, !last);
       const uint32_t puDistY = e->outDistY; const double puCost = e->outRdCost;
       if (puCost < bestPUCost) {
@@ -2067,6 +2085,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
         set_intra_result_qt(e, &t);
         HM_PAR_FOR(i, puParts) { ws->tmpTr[i] = m->tr[z + i]; for (int c = 0; c < 3; c++) { ws->tmpCbf[c][i] = m->cbf[c][z + i]; ws->tmpTs[c][i] = m->ts[c][z + i]; } }
         HM_SYNC();
+        if (!last && (n == 16 || n == 32)) cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_QT_TRAFO_TEST)], &e->cur);
       }
     }
     overallDistY += bestPUDistY;
@@ -2457,7 +2476,25 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
       retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
     }
     if (f->phase == 2) { // a sub-CU returned
-      f->splitBits += retBits; f->splitDist += retDist; f->phase = 1; continue;
+      f->splitBits += retBits; f->splitDist += retDist; f->phase = 1;
+      // The split candidate's cost only grows from here (bits and distortion add up, calcRdCost is monotone in both) and it has to come in
+      // strictly below the unsplit best (TEncCu.cpp:1704): once the sub-CUs so far are no cheaper, the rest cannot change the decision.
+      // One thing of the skipped work does reach outside: the split flag of the parent's split candidate is priced on the estimator "as it
+      // stands" (TEncCu.cpp:1042-1047), i.e. as this CU's last sub-CU left it - so a CU only stops early when a later sibling (which reloads
+      // the estimator from its slot) follows it, or at the CTU root.
+      bool laterSibling = sp == 0;     // (I slices only: in P / B slices more than the estimator carries over from a CU's last sub-CU)
+      if (sp > 0) {
+        const int pq = parts, pz = fr[sp - 1].cuZ;
+        for (int s2 = fr[sp - 1].sub; s2 < 4; s2++) {
+          const int r2 = hm_z2r(pz + s2 * pq);
+          laterSibling |= (e->ctuX * 64 + (r2 & 15) * 4 < e->width) && (e->ctuY * 64 + (r2 >> 4) * 4 < e->height);
+        }
+      }
+      if (f->sub < 4 && !e->im && laterSibling && !f->boundary && !(calc_rd_cost(e, f->splitBits, f->splitDist) < f->bestCost)) {
+        restore_best(e, cuZ, cuDepth);
+        retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--;
+      }
+      continue;
     }
   }
   e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
