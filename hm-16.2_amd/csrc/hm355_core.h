@@ -280,7 +280,7 @@ struct TU {
 // explicit stacks of the tree walks (kept in LDS: no private-memory traffic, no device recursion)
 struct TuWalk { TU node[5]; int8_t next[5]; int sp; };
 struct RqtFrame {
-  TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf; double singleCost, splitCost;
+  TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf, singleBits; double singleCost, splitCost;
 };
 struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary, parentPart; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
 // inter (P / B slice) helpers kept in LDS
@@ -335,7 +335,7 @@ struct Shared {
   TCoeff tsCoef[3][16];
   uint8_t flags[72];
   TuWalk walkOuter, walkInner;         // tree-walk stacks
-  RqtFrame rqt[4]; uint32_t rqtRetDist[5]; double rqtRetCost[5];
+  RqtFrame rqt[4]; uint32_t rqtRetDist[5], rqtRetBits[5]; double rqtRetCost[5];
   CuFrame cuf[4];
   int32_t absCoeff[16];
   int32_t ebits[128];                  // HM_ENTROPY_BITS for per-lane lookups (hm355_simt4.h)
@@ -1841,8 +1841,8 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
   HM_ENTRY(e); checkFirst = HM_UNI(checkFirst); rootv = hm_uni_struct(rootv);
   CtuMeta *m = (&e->meta);
   RqtFrame *fr = e->rqt; int sp = 0;
-  uint32_t *retDist = e->rqtRetDist; double *retCost = e->rqtRetCost;     // accumulators handed to each level by its parent
-  fr[0].t = rootv; fr[0].phase = 0; retDist[0] = 0; retCost[0] = 0.0;
+  uint32_t *retDist = e->rqtRetDist, *retBits = e->rqtRetBits; double *retCost = e->rqtRetCost;     // accumulators handed to each level by its parent
+  fr[0].t = rootv; fr[0].phase = 0; retDist[0] = 0; retBits[0] = 0; retCost[0] = 0.0;
   while (sp >= 0) {
     RqtFrame *f = &fr[sp]; const TU *t = &f->t;
     const int z = t->cuZ + t->relZ, fullDepth = t->cuDepth + t->trDepth, log2 = t->log2;
@@ -1851,7 +1851,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
       f->checkFull = log2 <= 5;
       f->checkSplit = log2 > tr_min_size_in_cu(6 - t->cuDepth, nxn);
       if (checkFirst && f->checkFull) f->checkSplit = 0;              // HHI_RQT_INTRA_SPEEDUP
-      f->singleCost = HM_MAX_DOUBLE; f->singleDist = 0; f->singleCbf = 0; f->bestModeId = 0;
+      f->singleCost = HM_MAX_DOUBLE; f->singleDist = 0; f->singleCbf = 0; f->bestModeId = 0; f->singleBits = 0;
       const int checkTS = (log2 == 2) && (m->part[z] == SIZE_NxN);    // TransformSkip + TransformSkipFast
       if (f->checkFull) {
         if (checkTS) {
@@ -1883,7 +1883,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
           HM_PROF_BEGIN(e, PR_S4LEAF);
           simt4_luma_leaf(e, *t);
           HM_PROF_END(e, PR_S4LEAF);
-          f->singleDist = e->outDistY;
+          f->singleDist = e->outDistY; f->singleBits = e->outBits;
           f->singleCost = calc_rd_cost(e, e->outBits, f->singleDist);
         } else if (sp == 0 && e->s8Reuse == 1) {
           // closing pass of an 8x8 PU: its unsplit 8x8 TU is the evaluation the candidates-in-lanes first pass already made for the winner
@@ -1917,30 +1917,42 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
           f->singleDist = HM_UCALL(intra_coding_tu_block(e, *t, 0, 0));
           if (f->checkSplit) f->singleCbf = (m->cbf[0][z] >> t->trDepth) & 1;
           const uint32_t bits = HM_UCALL(intra_bits_qt(e, *t, 1, 0));
-          f->singleCost = calc_rd_cost(e, bits, f->singleDist);
+          f->singleCost = calc_rd_cost(e, bits, f->singleDist); f->singleBits = bits;
         }
       }
-      if (!f->checkSplit) { retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue; }
+      if (!f->checkSplit) { retDist[sp] += f->singleDist; retBits[sp] += f->singleBits; retCost[sp] += f->singleCost; sp--; continue; }
       if (f->checkFull) { cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)], &e->cur); cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]); }
       else cabac_copy(&e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)], &e->cur);
       f->splitCost = 0.0; f->splitDist = 0; f->splitCbf = 0; f->child = 0; f->phase = 1;
-      retDist[sp + 1] = 0; retCost[sp + 1] = 0.0;
+      retDist[sp + 1] = 0; retBits[sp + 1] = 0; retCost[sp + 1] = 0.0;
     }
     if (f->phase == 1) {
+      int splitLost = 0;
       if (f->child > 0) { // a child just returned
         const TU ch = tu_child(t, f->child - 1, 0);
         f->splitCbf |= (m->cbf[0][ch.cuZ + ch.relZ] >> ch.trDepth) & 1;
+        // The split candidate is priced by coding the whole subtree again from this TU's snapshot (xGetIntraBitsQT, TEncSearch.cpp:1670).  A bin's price
+        // depends only on the state of its own context, and each context sees the same bins in the same order in that recount as it did
+        // while the children were searched one after the other (flags and coefficients use different contexts; bypass bins cost one bit
+        // anywhere), so the recount is at least the sum of the children's prices - each known to within the fraction of a bit carried into
+        // it.  Once that lower bound on the split cost is no cheaper than the unsplit TU, the remaining children and the recount are moot.
+        if (f->checkFull) {
+          const uint32_t lbBits = retBits[sp + 1] > (uint32_t)f->child ? retBits[sp + 1] - (uint32_t)f->child : 0;
+          splitLost = !(calc_rd_cost(e, lbBits, retDist[sp + 1]) < f->singleCost);
+        }
       }
-      if (f->child < 4) {
-        fr[sp + 1].t = tu_child(t, f->child, 0); fr[sp + 1].phase = 0; f->child++;
-        sp++; continue;
+      if (!splitLost) {
+        if (f->child < 4) {
+          fr[sp + 1].t = tu_child(t, f->child, 0); fr[sp + 1].phase = 0; f->child++;
+          sp++; continue;
+        }
+        f->splitDist = retDist[sp + 1];
+        if (f->splitCbf) { HM_PAR_FOR(o, t->parts) m->cbf[0][z + o] |= (uint8_t)(1 << t->trDepth); HM_SYNC(); }
+        cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
+        const uint32_t splitBits = HM_UCALL(intra_bits_qt(e, *t, 1, 0));
+        f->splitCost = calc_rd_cost(e, splitBits, f->splitDist);
+        if (f->splitCost < f->singleCost) { retDist[sp] += f->splitDist; retBits[sp] += splitBits; retCost[sp] += f->splitCost; sp--; continue; }
       }
-      f->splitDist = retDist[sp + 1];
-      if (f->splitCbf) { HM_PAR_FOR(o, t->parts) m->cbf[0][z + o] |= (uint8_t)(1 << t->trDepth); HM_SYNC(); }
-      cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_ROOT)]);
-      const uint32_t splitBits = HM_UCALL(intra_bits_qt(e, *t, 1, 0));
-      f->splitCost = calc_rd_cost(e, splitBits, f->splitDist);
-      if (f->splitCost < f->singleCost) { retDist[sp] += f->splitDist; retCost[sp] += f->splitCost; sp--; continue; }
       cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(fullDepth, CI_QT_TRAFO_TEST)]);
       par_set8(m->tr + z, t->trDepth, t->parts);
       par_set8(m->cbf[0] + z, (int)(f->singleCbf << t->trDepth), t->parts);
@@ -1949,7 +1961,7 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
         const int n = 1 << log2, layer = 5 - log2, ps = e->stride[0];
         par_copy_blk(e->fb.rec[0] + (e->ctuY * 64 + t->y) * ps + e->ctuX * 64 + t->x, ps, e->ws->qtRec[layer] + t->y * 64 + t->x, 64, n);
       }
-      retDist[sp] += f->singleDist; retCost[sp] += f->singleCost; sp--; continue;
+      retDist[sp] += f->singleDist; retBits[sp] += f->singleBits; retCost[sp] += f->singleCost; sp--; continue;
     }
   }
   e->outDistY = retDist[0]; e->outRdCost = retCost[0];
