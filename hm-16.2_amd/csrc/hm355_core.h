@@ -2494,7 +2494,9 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
       // One thing of the skipped work does reach outside: the split flag of the parent's split candidate is priced on the estimator "as it
       // stands" (TEncCu.cpp:1042-1047), i.e. as this CU's last sub-CU left it - so a CU only stops early when a later sibling (which reloads
       // the estimator from its slot) follows it, or at the CTU root.
-      bool laterSibling = sp == 0;     // (I slices only: in P / B slices more than the estimator carries over from a CU's last sub-CU)
+      // I slices only: in P / B slices the integer vector of the last 2Nx2N motion search seeds the next CU's search whatever CU that was
+      // (m_integerMv2Nx2N, TEncSearch.cpp:3880-3888), so a skipped sub-CU would change its successors.
+      bool laterSibling = sp == 0;
       if (sp > 0) {
         const int pq = parts, pz = fr[sp - 1].cuZ;
         for (int s2 = fr[sp - 1].sub; s2 < 4; s2++) {
