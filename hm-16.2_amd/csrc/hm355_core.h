@@ -1936,9 +1936,12 @@ HM_DEV HM_NOINLINE void recur_intra_coding_qt(Shared *e, TU rootv, int checkFirs
         // while the children were searched one after the other (flags and coefficients use different contexts; bypass bins cost one bit
         // anywhere), so the recount is at least the sum of the children's prices - each known to within the fraction of a bit carried into
         // it.  Once that lower bound on the split cost is no cheaper than the unsplit TU, the remaining children and the recount are moot.
-        if (f->checkFull) {
-          const uint32_t lbBits = retBits[sp + 1] > (uint32_t)f->child ? retBits[sp + 1] - (uint32_t)f->child : 0;
-          splitLost = !(calc_rd_cost(e, lbBits, retDist[sp + 1]) < f->singleCost);
+        const uint32_t lbBits = retBits[sp + 1] > (uint32_t)f->child ? retBits[sp + 1] - (uint32_t)f->child : 0;
+        if (f->checkFull) splitLost = !(calc_rd_cost(e, lbBits, retDist[sp + 1]) < f->singleCost);
+        else if (sp == 0 && !(calc_rd_cost(e, lbBits, retDist[1]) < e->outCost)) {
+          // a 64x64 PU (four 32x32 TUs, no unsplit form): the same bound against the best candidate so far, which this one has to beat
+          // (estIntraPredQT, TEncSearch.cpp:2490 / :2570) - it cannot, and nothing of it is kept
+          e->outDistY = 0; e->outRdCost = HM_MAX_DOUBLE; return;
         }
       }
       if (!splitLost) {
@@ -2089,6 +2092,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
       par_set8(m->dirL + z, orgMode, puParts);
       cabac_copy(&e->cur, &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
       // 16x16 / 32x32 PUs: the closing pass takes its unsplit TU from the winner's first-pass evaluation instead of repeating it
+      e->outCost = bestPUCost;               // what this candidate has to beat (recur_intra_coding_qt gives up on a 64x64 PU that cannot)
       if (last && (n == 16 || n == 32) && numModesForFullRD > 0) { e->s8Reuse = 2; e->outDistY = bestPUDistY; e->outRdCost = bestPUCost; }
       recur_intra_coding_qt(e, t, !last);
       const uint32_t puDistY = e->outDistY; const double puCost = e->outRdCost;
