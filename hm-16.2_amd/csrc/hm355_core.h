@@ -1083,11 +1083,18 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   const int sigOff = C_SIG + (chroma ? 28 : 0);
   const int32_t *src = e->bufA;
   WorkSpace *ws = e->ws;
-  double *costCoeff = (n == 32) ? ws->costCoeff : (double *)(e->bufA + 16 * HM_TSTRIDE);   // blocks up to 16x16 leave rows 16..31 of bufA free
-  int32_t *rqLvl = (n == 32) ? ws->rqLvl : e->u.rq.lvl;
-  uint16_t *rqPos = (n == 32) ? ws->rqPos : e->u.rq.pos, *rqDec = (n == 32) ? ws->rqDec : e->u.rq.dec;
-  int16_t *rqCur = (n == 32) ? ws->rqCur : e->u.rq.cur;
-  uint8_t *rqCtxSig = (n == 32) ? ws->rqCtxSig : e->u.rq.ctxSig, *rqCode = (n == 32) ? ws->rqCode : e->u.rq.code;
+  // Per-position state, indexed by scan position.  Blocks up to 16x16: the RqLds arrays + rows 16..31 of bufA for the costs.  32x32 blocks
+  // (`big`) keep it in LDS too, in 8 bytes per position: |c|*scale in the transform temp (u.bufB), raster position | sign | significance code
+  // and the decided level in bufA once the pre-pass has read the coefficients out of it; the working level (decision, or 0 in a zeroed
+  // group, cut at the chosen last position, signed) and the significance context are derived where they are needed, and only the cost of
+  // the non-zero levels goes through the HBM workspace (fetched one group ahead).
+  const bool big = n == 32;
+  double *costCoeff = big ? ws->costCoeff : (double *)(e->bufA + 16 * HM_TSTRIDE);
+  int32_t *rqLvl = big ? (int32_t *)e->u.bufB : e->u.rq.lvl;
+  uint16_t *rqPos = big ? (uint16_t *)e->bufA : e->u.rq.pos, *rqDec = big ? (uint16_t *)e->bufA + 1024 : e->u.rq.dec;
+  int16_t *rqCur = e->u.rq.cur;                              // not used by 32x32 blocks
+  uint8_t *rqCtxSig = e->u.rq.ctxSig, *rqCode = e->u.rq.code;   // not used by 32x32 blocks
+  uint8_t *cgCtxSet = big ? (uint8_t *)e->u.bufB + 4096 : e->u.rq.cgCtxSet;
   // ---- 1. pre-pass
   int lastLocal = -1;
   {
@@ -1097,14 +1104,23 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       const int32_t sc = src[(blkPos >> log2n) * HM_TSTRIDE + (blkPos & (n - 1))];
       const int64_t tmpLevel = (int64_t)hm_abs(sc) * quantCoef;
       const int32_t lvl = (int32_t)(tmpLevel < cap ? tmpLevel : cap);
-      rqLvl[sp] = lvl;
-      rqPos[sp] = (uint16_t)(blkPos | (sc < 0 ? 0x8000 : 0));
+      rqLvl[sp] = (big && sc < 0) ? ~lvl : lvl;               // 32x32: the sign rides along until the positions can go where the coefficients are
+      if (!big) rqPos[sp] = (uint16_t)(blkPos | (sc < 0 ? 0x8000 : 0));
       if (((lvl + (1 << (qBits - 1))) >> qBits) > 0 && sp > lastLocal) lastLocal = sp;
       dst[sp] = 0;
     }
   }
   const int lastScanPos = hm_wave_max_i(lastLocal);
   HM_SYNC();
+  if (big && lastScanPos >= 0) {
+    HM_PAR_FOR(sp, numCoef) {
+      const int32_t v = rqLvl[sp]; const int neg = v < 0;
+      rqLvl[sp] = neg ? ~v : v;
+      rqPos[sp] = (uint16_t)(scan[sp] | (neg ? 0x8000 : 0));
+      rqDec[sp] = 0;
+    }
+    HM_SYNC();
+  }
   if (lastScanPos < 0) return 0;
   // ---- 2. bit-cost tables of the current estimator state (TEncSbac::estBit, TEncSbac.cpp:1717-1956)
   int lastOff, lastShift; last_ctx_params(chroma, n, &lastOff, &lastShift);
@@ -1253,22 +1269,29 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     HM_WAVE_FOR(k) {
       if (k < 16) {
         const int scanPos = cgScanPos * 16 + k, dec = HM_LVK(vDec, k);
-        rqDec[scanPos] = (uint16_t)dec; rqCur[scanPos] = (int16_t)(zeroed ? 0 : dec);
-        rqCode[scanPos] = (uint8_t)((zeroed && dec) ? 0 : HM_LVK(vCode, k));
-        rqCtxSig[scanPos] = (uint8_t)HM_LVK(vSigIdx, k);
+        const int code = (zeroed && dec) ? 0 : HM_LVK(vCode, k);
+        rqDec[scanPos] = (uint16_t)dec;
+        if (big) rqPos[scanPos] = (uint16_t)(rqPos[scanPos] | (code << 12));
+        else { rqCur[scanPos] = (int16_t)(zeroed ? 0 : dec); rqCode[scanPos] = (uint8_t)code; rqCtxSig[scanPos] = (uint8_t)HM_LVK(vSigIdx, k); }
         costCoeff[scanPos] = HM_LVK(vCC, k);
       }
     }
-    e->u.rq.cgCtxSet[cgScanPos] = (uint8_t)wSet;
+    cgCtxSet[cgScanPos] = (uint8_t)wSet;
   }
   HM_SYNC();
   double bestCost = blockUncodedCost + lambda * (double)HM_LV_GET(tMisc, 8 + cbfCtx * 2);   // TComTrQuant.cpp:2310-2316
   baseCost += lambda * (double)HM_LV_GET(tMisc, 8 + cbfCtx * 2 + 1);
   int bestLastIdxP1 = 0, foundLast = 0;
+  HM_LV(double, ccNext);                 // the group's non-zero level costs, fetched one group ahead (HBM for 32x32 blocks)
+  HM_WAVE_FOR(k) { HM_LVK(ccNext, k) = costCoeff[cgLastScanPos * 16 + (k & 15)]; }
   for (int cgScanPos = cgLastScanPos; cgScanPos >= 0 && !foundLast; cgScanPos--) {
     const int cgBlkPos = scanCG[cgScanPos];
+    HM_LV(double, ccCur);
+    HM_WAVE_FOR(k) { HM_LVK(ccCur, k) = HM_LVK(ccNext, k); if (cgScanPos > 0) HM_LVK(ccNext, k) = costCoeff[(cgScanPos - 1) * 16 + (k & 15)]; }
     baseCost -= HM_LV_GETD(vCGSig, cgScanPos);
     if (!((cgMask >> cgBlkPos) & 1)) continue;
+    const int cgyB = cgBlkPos >> (log2n - 2), cgxB = cgBlkPos & (wg - 1);
+    const int patternB = wg <= 1 ? 0 : ((cgxB < wg - 1) ? (int)((cgMask >> (cgBlkPos + 1)) & 1) : 0) + (((cgyB < wg - 1) ? (int)((cgMask >> (cgBlkPos + wg)) & 1) : 0) << 1);
     // per position: baseCost = (baseCost - A) + B with A = cost of the coded level (or of the significance flag of a
     // zero), B = distortion of the uncoded level (or +0.0); a coded position first offers itself as the last one
     HM_LV(double, dSig); HM_LV(double, dLast); HM_LV(double, dA); HM_LV(double, dB); HM_LV(double, dPre);
@@ -1276,17 +1299,20 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
     HM_WAVE_FOR(k) {
       const int scanPos = cgScanPos * 16 + (k & 15);
       const int inRange = scanPos <= lastScanPos;
-      const int cur = rqCur[scanPos], code = rqCode[scanPos], sigIdx = rqCtxSig[scanPos];
+      const int posv = rqPos[scanPos], blkPos = posv & 0x3ff;
+      // 32x32: a group that gets here kept its decisions; its significance contexts follow from the final group flags (the right and lower
+      // neighbours were settled before this group's decisions were taken)
+      const int cur = big ? (int)rqDec[scanPos] : (int)rqCur[scanPos], code = big ? ((posv >> 12) & 3) : (int)rqCode[scanPos];
+      const int sigIdx = big ? ((scanPos == lastScanPos) ? 0 : sig_ctx_inc(patternB, firstCtx, blkPos, log2n, chroma)) : (int)rqCtxSig[scanPos];
       const int sb = HM_LV_GATHER(tSig, sigIdx * 2 + (code ? code - 1 : 0));
       const double cSig = lambda * (double)(code ? sb : 0);
       HM_LVK(dSig, k) = cSig;
-      const int blkPos = rqPos[scanPos] & 0x3ff;
       int posY = blkPos >> log2n, posX = blkPos - (posY << log2n);
       if (scanType == SCAN_VER) { const int t = posX; posX = posY; posY = t; }
       const int lb = HM_LV_GATHER(tLastCost, hm_group_idx(posX)) + HM_LV_GATHER(tLastCost, 16 + hm_group_idx(posY));
       HM_LVK(dLast, k) = lambda * (double)lb;
       const double err = (double)rqLvl[scanPos];
-      HM_LVK(dA, k) = !inRange ? 0.0 : (cur ? costCoeff[scanPos] : cSig);
+      HM_LVK(dA, k) = !inRange ? 0.0 : (cur ? HM_LVK(ccCur, k) : cSig);
       HM_LVK(dB, k) = (inRange && cur) ? err * err * errScale : 0.0;
       HM_LVK(dPre, k) = 0;
       HM_BALLOT(curMask, k, cur != 0 && k < 16);
@@ -1304,9 +1330,10 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   // ---- levels with signs, truncated at the chosen last position (lane-parallel)
   int absPart = 0;
   HM_PAR_FOR(sp, lastScanPos + 1) {
-    int lv = sp < bestLastIdxP1 ? rqCur[sp] : 0;
+    int lv = 0;
+    if (sp < bestLastIdxP1) lv = big ? (((cgMask >> scanCG[sp >> 4]) & 1) ? (int)rqDec[sp] : 0) : (int)rqCur[sp];
     absPart += lv;
-    rqCur[sp] = (int16_t)((rqPos[sp] & 0x8000) ? -lv : lv);
+    if (!big) rqCur[sp] = (int16_t)((rqPos[sp] & 0x8000) ? -lv : lv);
   }
   const int absSum = hm_wave_sum_i(absPart);
   HM_SYNC();
@@ -1319,10 +1346,19 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
       const int top = (subPos + 15 <= lastScanPos) ? 15 : (lastScanPos - subPos);
       HM_LV(int32_t, sCur); HM_LV(int32_t, sDec); HM_LV(int32_t, sLvl); HM_LV(int32_t, sNeg); HM_LV(int32_t, sDelta);
       uint64_t nzM = 0, oddM = 0;
+      const int cgBlkPosS = scanCG[subSet], cgKept = (int)((cgMask >> cgBlkPosS) & 1);
+      const int cgyS = cgBlkPosS >> (log2n - 2), cgxS = cgBlkPosS & (wg - 1);
+      const int patternS = wg <= 1 ? 0 : ((cgxS < wg - 1) ? (int)((cgMask >> (cgBlkPosS + 1)) & 1) : 0) + (((cgyS < wg - 1) ? (int)((cgMask >> (cgBlkPosS + wg)) & 1) : 0) << 1);
       HM_WAVE_FOR(k) {
         const int kk = k & 15, sp = subPos + kk;
-        const int cur = (kk <= top) ? rqCur[sp] : 0, sigIdx = rqCtxSig[sp];
-        HM_LVK(sCur, k) = cur; HM_LVK(sDec, k) = rqDec[sp]; HM_LVK(sLvl, k) = rqLvl[sp]; HM_LVK(sNeg, k) = (rqPos[sp] >> 15) & 1;
+        const int posv = rqPos[sp], dec = rqDec[sp];
+        int cur, sigIdx;
+        if (big) {
+          const int lv = (cgKept && sp < bestLastIdxP1) ? dec : 0;
+          cur = (kk <= top) ? ((posv & 0x8000) ? -lv : lv) : 0;
+          sigIdx = (sp == lastScanPos) ? 0 : sig_ctx_inc(patternS, firstCtx, posv & 0x3ff, log2n, chroma);
+        } else { cur = (kk <= top) ? rqCur[sp] : 0; sigIdx = rqCtxSig[sp]; }
+        HM_LVK(sCur, k) = cur; HM_LVK(sDec, k) = dec; HM_LVK(sLvl, k) = rqLvl[sp]; HM_LVK(sNeg, k) = (posv >> 15) & 1;
         const int d = HM_LV_GATHER(tSig, sigIdx * 2 + 1) - HM_LV_GATHER(tSig, sigIdx * 2);
         HM_LVK(sDelta, k) = (sp == lastScanPos) ? 0 : d;
         HM_BALLOT(nzM, k, cur != 0 && k < 16);
@@ -1336,7 +1372,7 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
           const int64_t I64MAX = 0x7fffffffffffffffLL;
           int64_t minCostInc = I64MAX, curCost = I64MAX; int minK = -1, finalChange = 0, curChange = 0;
           // re-walk the group's decision-time state (contexts, Rice parameter, flag counters)
-          int wC1 = 1, wC1Idx = 0, wC2Idx = 0, wGoR = 0; const int wSet = e->u.rq.cgCtxSet[subSet];
+          int wC1 = 1, wC1Idx = 0, wC2Idx = 0, wGoR = 0; const int wSet = cgCtxSet[subSet];
           const int kStart = (lastCG == 1 ? lastNZ : 15);
           for (int k = top; k >= 0; --k) {
             const uint32_t dec = (uint32_t)HM_LV_GET(sDec, k);
@@ -1375,15 +1411,23 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
           if (minK >= 0) {
             const int mv = HM_LV_GET(sCur, minK);
             if (mv == 32767 || mv == -32768) finalChange = -1;
-            rqCur[subPos + minK] = (int16_t)(HM_LV_GET(sNeg, minK) ? mv - finalChange : mv + finalChange);
+            const int nv = HM_LV_GET(sNeg, minK) ? mv - finalChange : mv + finalChange;
+            if (big) HM_LV_SET(sCur, minK, nv); else rqCur[subPos + minK] = (int16_t)nv;
           }
         }
       }
+      if (big) { HM_WAVE_FOR(k) { if (k < 16) rqDec[subPos + k] = (uint16_t)(int16_t)HM_LVK(sCur, k); } }   // this group's final levels take its decisions' place
       if (lastCG == 1) lastCG = 0;
     }
   }
   HM_SYNC();
-  HM_PAR_FOR(sp, lastScanPos + 1) dst[rqPos[sp] & 0x3ff] = rqCur[sp];
+  HM_PAR_FOR(sp, lastScanPos + 1) {
+    int v;
+    if (!big) v = rqCur[sp];
+    else if (absSum >= 2) v = (int16_t)rqDec[sp];
+    else { const int lv = (sp < bestLastIdxP1 && ((cgMask >> scanCG[sp >> 4]) & 1)) ? (int)rqDec[sp] : 0; v = (rqPos[sp] & 0x8000) ? -lv : lv; }
+    dst[rqPos[sp] & 0x3ff] = v;
+  }
   HM_SYNC();
   return absSum;
 }
@@ -1450,8 +1494,9 @@ template <class C> HM_DEV HM_NOINLINE void code_coeff_nxn(Shared *e, C *c, const
   typename EngOf<C>::R r; cabr_load(e, r, c);
   if (n == 4) enc_bin(e, &r, C_TSKIP + chroma, tskipFlag);              // codeTransformSkipFlags, TEncSbac.cpp:988
   const uint16_t *scan = e->tab->scan[scanType][log2n - 2], *scanCG = e->tab->scanCG[scanType][log2n - 2];
-  int16_t *lv = (n == 32) ? e->ws->rqCur : e->u.rq.cur; uint8_t *cgFlag = e->u.rq.cgFlag;
-  uint16_t *sposArr = (n == 32) ? e->ws->rqPos : e->u.rq.pos;
+  // levels and raster positions in scan order: 32x32 blocks stage them in the idle transform buffer (2 x 2 KB of bufA's 4.1 KB)
+  int16_t *lv = (n == 32) ? (int16_t *)e->bufA : e->u.rq.cur; uint8_t *cgFlag = e->u.rq.cgFlag;
+  uint16_t *sposArr = (n == 32) ? (uint16_t *)e->bufA + 1024 : e->u.rq.pos;
   HM_PAR_FOR(i, 64) cgFlag[i] = 0;
   HM_SYNC();
   int lastLocal = -1;
@@ -1765,7 +1810,7 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, TU tv, int comp, in
   const int absSum = HM_UCALL(rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx));
   HM_PROF_END(e, PR_RDOQ);
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
-  { const int pid = l2 == 2 ? (absSum ? 13 : 7) : (l2 == 3 ? 14 : 15); e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }
+  { const int pid = l2 == 2 ? (absSum ? 13 : 7) : (l2 == 3 ? 14 : (l2 == 4 ? 15 : 43)); e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }
 #endif
   par_set8(m->cbf[comp] + z, (absSum > 0 ? 1 : 0) << t->trDepth, parts);   // setCbfPartRange, TComTrQuant.cpp:1419
   HM_PROF_BEGIN(e, PR_INV);

@@ -72,9 +72,7 @@ struct WorkSpace {
   Pel pred[HM_COEF_CTU], resi[HM_COEF_CTU], reco[HM_COEF_CTU];
   Pel qtRec[4][HM_COEF_CTU];         // m_pcQTTempTComYuv[layer]
   TCoeff qtCoef[4][HM_COEF_CTU];     // m_ppcQTTempCoeff[comp][layer]
-  double costCoeff[1024];            // RDOQ: cost of the positions that keep a non-zero level
-  int32_t rqLvl[1024];               // RDOQ per-position state of 32x32 blocks (smaller blocks keep it in LDS)
-  uint16_t rqPos[1024], rqDec[1024]; int16_t rqCur[1024]; uint8_t rqCtxSig[1024], rqCode[1024];
+  double costCoeff[1024];            // RDOQ of 32x32 blocks: cost of the positions that keep a non-zero level (everything else of its per-position state is in LDS)
   Cabac slot[4 * CI_NUM + 3];        // m_pppcRDSbacCoder[depth][CI_*] snapshots (the live coder stays in LDS); depth 4 only holds TEMP_BEST/QT_TRAFO_*
   Pel tmpPred[HM_COEF_CTU];          // m_tmpYuvPred (merge / ME prediction error)
   Pel resiBest[HM_COEF_CTU];         // m_ppcResiYuvBest[depth]

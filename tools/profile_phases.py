@@ -12,10 +12,10 @@ NP = 44
 out = (C.c_ulonglong * (2 * NP))()
 lib.hm355_read_profile.argtypes = [C.c_void_p, C.c_void_p]
 lib.hm355_read_profile(enc.h_, out)
-names = ["RDOQ", "BITS", "ADI", "PRED", "FWD", "INV", "SATD35", "RDOQ4z", "SAVE", "CHROMA", "LUMA", "ENCCU", "TOTAL", "RDOQ4nz", "RDOQ8", "RDOQ16+"]   # ids 16.. are the inter phases (tools/inter_timing.py)
+names = ["RDOQ", "BITS", "ADI", "PRED", "FWD", "INV", "SATD35", "RDOQ4z", "SAVE", "CHROMA", "LUMA", "ENCCU", "TOTAL", "RDOQ4nz", "RDOQ8", "RDOQ16"]   # ids 16.. are the inter phases (tools/inter_timing.py)
 tot = out[12]
 print(f"{w}x{h} F={F}: {dt:.2f}s, {enc.num_ctus*F/dt:.1f} CTU/s, per-step {ms/l:.1f} ms")
-names += [None] * 16 + ["S4LUMA", "S4CHROMA", "CU64", "CU32", "CU16", "CU8_2Nx2N", "CU8_NxN", "S8LUMA", "S4LEAF", "S4CLEAF", "S8CHROMA"]
+names += [None] * 16 + ["S4LUMA", "S4CHROMA", "CU64", "CU32", "CU16", "CU8_2Nx2N", "CU8_NxN", "S8LUMA", "S4LEAF", "S4CLEAF", "S8CHROMA", "RDOQ32"]
 for i, n in enumerate(names):
     if n is None: continue
     print(f"{n:8s} {100.0*out[i]/tot:6.2f}%  calls {out[NP+i]:9d}  cyc/call {out[i]/max(1,out[NP+i]):10.0f}")
