@@ -507,7 +507,7 @@ def main():
                          "of the SAME pictures, boundary rows handed down over RCCL send / recv (hm-16.2_amd/bands.py; strong scaling)")
     ap.add_argument("--group", type=int, default=0, help="--shard rows: pictures per pipeline stage (default: frames / (4 * ranks))")
     ap.add_argument("--budget-s", type=float, default=280.0, help="wall-time bound of warm-up + timed steps (intra4k); fewer steps run when the request does not fit")
-    ap.add_argument("--frames", type=int, default=512, help="independent pictures per GPU per step")
+    ap.add_argument("--frames", type=int, default=768, help="independent pictures per GPU per step")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=32)
