@@ -29,7 +29,9 @@ def test_hip_matches_reference_fixture(hm, name):
     enc.close()
 
 
-@pytest.mark.parametrize("w,h,bd,qp,wpp,seed", [(192, 128, 8, 30, 1, 11), (128, 72, 10, 34, 0, 12), (64, 64, 8, 25, 0, 13)])
+@pytest.mark.parametrize("w,h,bd,qp,wpp,seed", [(192, 128, 8, 30, 1, 11), (128, 72, 10, 34, 0, 12), (64, 64, 8, 25, 0, 13),
+                                                   # dense and nearly empty 32x32 blocks: RDOQ state of 32x32 blocks, early terminations of the CU / residual quadtrees
+                                                   (448, 256, 10, 12, 1, 21), (320, 192, 8, 47, 0, 22), (384, 192, 10, 22, 1, 23), (200, 192, 8, 3, 0, 24)])
 def test_hip_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, qp, wpp, seed):
     import oracle
     planes = synth.frame(w, h, bd, 0, seed)

@@ -100,6 +100,24 @@ def test_hostsim_of_kernel_source_matches_reference_fixture(tmp_path):
             assert np.array_equal(got[i][1], rec)
 
 
+def test_hostsim_of_kernel_source_matches_oracle_at_extreme_qps(tmp_path):
+    """Dense 32x32 blocks (low QP: RDOQ with every coefficient group coded, sign-bit hiding everywhere), nearly empty ones (high QP),
+    with and without WPP: the code paths behind the early terminations of the CU / residual quadtrees and the LDS-resident RDOQ state
+    of 32x32 blocks, against the oracle on fresh inputs."""
+    import synth, gen_golden, oracle
+    out = tmp_path / "hostsim"
+    subprocess.run(["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-w", "-o", str(out), os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")], check=True)
+    for (w, h, bd, qp, wpp, seed) in [(320, 192, 10, 12, 1, 21), (256, 136, 8, 47, 0, 22), (384, 192, 10, 22, 1, 23), (200, 192, 8, 3, 0, 24)]:
+        yuv = tmp_path / f"in{seed}.yuv"
+        synth.write_yuv(str(yuv), w, h, bd, 1, seed)
+        want_rec, want_ctus = oracle.compress(synth.frame(w, h, bd, 0, seed), bd, qp, wpp)
+        dump = tmp_path / f"out{seed}.bin"
+        subprocess.run([str(out), str(yuv), str(w), str(h), str(bd), "1", str(qp), str(wpp), str(dump)], check=True)
+        got = gen_golden.parse_dump(str(dump))
+        common.assert_ctus_equal(got[0][0], want_ctus, f"{w}x{h} qp{qp}", (w, h))
+        common.assert_rec_equal(want_rec, got[0][1], w, h, f"{w}x{h} qp{qp}")
+
+
 @pytest.mark.parametrize("name", common.LDP_CASES[1:] + common.B_CASES + common.LDP_LONG_CASES)
 def test_hostsim_of_kernel_source_matches_reference_p_slices(tmp_path, name):
     """The P-slice part of the kernel source (hm355_inter.h / hm355_inter_cu.h) compiled for the host with one lane, forwards and
