@@ -53,7 +53,7 @@ __device__ __attribute__((noinline)) int hm355_wait_flag(const unsigned int *fla
   return __shfl(bad, 0, 64);
 }
 
-extern "C" __global__ void __launch_bounds__(64, 4) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
+extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
 {
   __shared__ WorkItem curItem;
   for (;;) {
