@@ -273,10 +273,12 @@ HM_CONST int16_t HM_INV_ANG_TABLE[9] = {0, 4096, 1638, 910, 630, 482, 390, 315, 
 // LDS-resident state of one CTU search
 // ------------------------------------------------------------------------------------------------
 // TU descriptor: the subset of TComTU (TComTU.h/.cpp) that 4:2:0 intra coding needs
-struct TU {
-  int16_t cuZ, cuDepth, cuParts, relZ, trDepth, log2, parts, section, x, y;
-  int16_t cW, cCodeAll, cTrDepth, cRelZ, cParts, cOff, cx, cy;
+struct TU {                            // 24 bytes: it sits in every frame of the LDS tree-walk stacks and travels by value (6 dwords)
+  int16_t cuParts, parts, cParts, cOff;
+  uint8_t cuZ, cuDepth, relZ, trDepth, log2, section, x, y;
+  uint8_t cW, cCodeAll, cTrDepth, cRelZ, cx, cy, pad_[2];
 };
+static_assert(sizeof(TU) == 24, "TU layout");
 // explicit stacks of the tree walks (kept in LDS: no private-memory traffic, no device recursion)
 struct TuWalk { TU node[5]; int8_t next[5]; int sp; };
 struct RqtFrame {
@@ -331,27 +333,34 @@ struct Shared {
     RqLds rq;
     RefLds ref;
   } u;
-  Pel tsPred[3][16], tsRec[3][16];     // transform-skip trial of a 4x4 block
-  TCoeff tsCoef[3][16];
-  uint8_t flags[72];
   TuWalk walkOuter, walkInner;         // tree-walk stacks
-  RqtFrame rqt[4]; uint32_t rqtRetDist[5], rqtRetBits[5]; double rqtRetCost[5];
   CuFrame cuf[4];
-  int32_t absCoeff[16];
   int32_t ebits[128];                  // HM_ENTROPY_BITS for per-lane lookups (hm355_simt4.h)
-  int32_t rdModeList[12]; double candCost[12];
-  uint8_t splitCbf[5][2];
   // results handed back by the big non-inlined stages (instead of pointers to private memory)
-  double outCost; uint32_t outBits, outDist; double outRdCost; uint32_t outDistY;
-  uint32_t satd[36];                   // SATD of the 35 intra modes of the PU under test
-  int32_t mpmZ, mpmNum, mpmPreds[3];   // most-probable-mode list of the PU under test (same for all its candidates)
+  double outCost; uint32_t outBits, outDist; double outRdCost;
+  int32_t mpmZ;                        // the PU whose most-probable-mode list is tabulated below (-1: none)
   int32_t s8Winner, s8Reuse;           // hm355_simt8.h: the first pass's winning candidate; set while its evaluation can stand in for the closing pass's unsplit 8x8 TU
-  // inter (P / B slice) state
+  // inter (P / B slice) state that outlives a stage
   InterMeta *im;                       // motion arrays of the CTU under search (HBM)
   uint32_t mcost; MvD mvPredictor; int32_t costScale;   // TComRdCost motion-cost state
-  MvD intMv[2][16];                    // TEncSearch::m_integerMv2Nx2N[list][refIdx]
-  TZ tz; MvD outMv; MergeList ml; AmvpInfo amvp; MvFieldD mrgField[2]; int32_t mrgDir, mrgIdx; uint32_t mrgCost, irqZeroDist;
-  IrqFrame irq[4];
+  // Scratch state of the intra stages and of the inter stages share their LDS: nothing of the one is live while the other runs (an intra
+  // trial of a P / B slice runs between inter trials, never inside one; the host twin runs the same layout against the P / B fixtures)
+  union {
+    struct {                           // est_intra_pred_qt / recur_intra_coding_qt / chroma / init_adi_pattern
+      uint8_t flags[72];
+      RqtFrame rqt[4]; uint32_t rqtRetDist[5], rqtRetBits[5]; double rqtRetCost[5];
+      int32_t rdModeList[12];
+      uint8_t splitCbf[5][2];
+      uint32_t outDistY;
+      uint32_t satd[36];               // SATD of the 35 intra modes of the PU under test
+      int32_t mpmNum, mpmPreds[3];     // most-probable-mode list of the PU under test (same for all its candidates)
+    };
+    struct {                           // motion search, merge / AMVP lists, inter residual quadtree
+      int32_t absCoeff[10];            // the 9 costs of a fractional refinement step
+      TZ tz; MvD outMv; MergeList ml; AmvpInfo amvp; MvFieldD mrgField[2]; int32_t mrgDir, mrgIdx; uint32_t mrgCost, irqZeroDist;
+      IrqFrame irq[4];
+    };
+  };
   // uniform per-CTU context
   int32_t width, height, bitDepth, wCtu, stride[3];
   const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
@@ -386,7 +395,7 @@ __device__ inline void hm_trace(Shared *e, int tag, uint32_t a, uint32_t b, doub
 __shared__ Shared g_sh;                // the one CTU search of this workgroup (HM_ENTRY)
 #endif
 #if !defined(HM355_PROFILE)
-static_assert(sizeof(Shared) + 16 <= 16384, "Shared (+ the kernel's work item) must stay within 1/10 of a CU's 160 KB LDS (10 CTU searches per CU)");
+static_assert(sizeof(Shared) + 16 <= 14848, "Shared (+ the kernel's work item) must stay within 1/11 of a CU's 160 KB LDS in 512-byte granules (11 CTU searches per CU)");
 #endif
 static_assert(offsetof(Shared, bufA) % 8 == 0 && (16 * HM_TSTRIDE * 4) % 8 == 0, "the RDOQ cost array aliases the lower half of bufA as doubles");
 
@@ -1792,8 +1801,8 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, TU tv, int comp, in
     const int r = hm_z2r(z);
     { HM_PROF_BEGIN(e, PR_ADI); init_adi_pattern(e, comp, e->ctuX * st + bx, e->ctuY * st + by, n, e->ctuX * 16 + (r & 15), e->ctuY * 16 + (r >> 4), comp ? n / 2 : n / 4, filt); HM_PROF_END(e, PR_ADI); }
     { HM_PROF_BEGIN(e, PR_PRED); pred_intra(e, comp, mode, n, filt, pred, st); HM_PROF_END(e, PR_PRED); }
-    if (save1load2 == 1) { HM_PAR_FOR(i, 16) e->tsPred[comp][i] = pred[(i >> 2) * st + (i & 3)]; HM_SYNC(); }
-  } else { HM_PAR_FOR(i, 16) pred[(i >> 2) * st + (i & 3)] = e->tsPred[comp][i]; HM_SYNC(); }
+    if (save1load2 == 1) { HM_PAR_FOR(i, 16) e->ws->tsPred[comp][i] = pred[(i >> 2) * st + (i & 3)]; HM_SYNC(); }
+  } else { HM_PAR_FOR(i, 16) pred[(i >> 2) * st + (i & 3)] = e->ws->tsPred[comp][i]; HM_SYNC(); }
   if (comp == 0) par_set8(m->tr + z, t->trDepth, parts);             // setTrIdxSubParts, TEncSearch.cpp:1229
   // residual straight into the LDS transform buffer (and the scratch plane, as the reference keeps it)
   const int tshift = 15 - bitDepth - l2;
@@ -1861,7 +1870,7 @@ HM_DEV inline void store_intra_result_qt(Shared *e, const TU *t, int comp)
   const int bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
   const TCoeff *coef = e->ws->qtCoef[layer] + po + (comp ? t->cOff : (t->cuZ + t->relZ) * 16);
   const Pel *rq = e->ws->qtRec[layer] + po + by * st + bx;
-  HM_PAR_FOR(i, 16) { e->tsCoef[comp][i] = coef[i]; e->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; }
+  HM_PAR_FOR(i, 16) { e->ws->tsCoef[comp][i] = coef[i]; e->ws->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; }
   HM_SYNC();
 }
 HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
@@ -1871,7 +1880,7 @@ HM_DEV inline void load_intra_result_qt(Shared *e, const TU *t, int comp)
   TCoeff *coef = e->ws->qtCoef[layer] + po + (comp ? t->cOff : (t->cuZ + t->relZ) * 16);
   Pel *rq = e->ws->qtRec[layer] + po + by * st + bx;
   Pel *recPic = e->fb.rec[comp] + (e->ctuY * st + by) * ps + e->ctuX * st + bx;
-  HM_PAR_FOR(i, 16) { coef[i] = e->tsCoef[comp][i]; const Pel v = e->tsRec[comp][i]; rq[(i >> 2) * st + (i & 3)] = v; recPic[(i >> 2) * ps + (i & 3)] = v; }
+  HM_PAR_FOR(i, 16) { coef[i] = e->ws->tsCoef[comp][i]; const Pel v = e->ws->tsRec[comp][i]; rq[(i >> 2) * st + (i & 3)] = v; recPic[(i >> 2) * ps + (i & 3)] = v; }
   HM_SYNC();
 }
 
@@ -2613,7 +2622,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     // CTUs take the state of their predecessor -- which is what lets inter slices run as a WPP wavefront.
     const int bnd = it->ctuX * 64 + 63 >= P->width || it->ctuY * 64 + 63 >= P->height;
     const MvD *src = e->ctuAddr == 0 ? e->fb.ip->integerMv2Nx2N[0] : e->fb.intMv + (size_t)(e->ctuAddr - 1) * 32;
-    HM_PAR_FOR(i, 32) { MvD v; v.x = v.y = 0; if (bnd) v = src[i]; e->intMv[i >> 4][i & 15] = v; }
+    HM_PAR_FOR(i, 32) { MvD v; v.x = v.y = 0; if (bnd) v = src[i]; e->ws->intMv[i >> 4][i & 15] = v; }
     HM_SYNC();
   }
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
@@ -2653,7 +2662,7 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   reset_bits(&e->cur);
   encode_ctu(e, &e->cur, a == numCtus - 1);
   cabac_copy(e->fb.endState + a, &e->cur);
-  if (e->im) { HM_PAR_FOR(i, 32) e->fb.intMv[(size_t)a * 32 + i] = e->intMv[i >> 4][i & 15]; HM_SYNC(); }   // carried to the next CTU in coding order
+  if (e->im) { HM_PAR_FOR(i, 32) e->fb.intMv[(size_t)a * 32 + i] = e->ws->intMv[i >> 4][i & 15]; HM_SYNC(); }   // carried to the next CTU in coding order
   { // decision arrays back to HBM (TComDataCU::copyToPic of the whole CTU)
     const uint32_t *src = (const uint32_t *)&e->meta; uint32_t *dst = (uint32_t *)(e->fb.meta + a);
     HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];

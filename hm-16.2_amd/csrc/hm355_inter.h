@@ -691,9 +691,9 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   if (bi) c = pattern_search(e, &z, &mv, lt, rb);
   else {
     const int useInt = (partSize != SIZE_2Nx2N || cuDepth != 0);
-    MvD im = e->intMv[list][refIdx];
+    MvD im = e->ws->intMv[list][refIdx];
     c = tz_search(e, &z, &mv, cuX, cuY, lt, rb, useInt, im);
-    if (partSize == SIZE_2Nx2N) e->intMv[list][refIdx] = mv;
+    if (partSize == SIZE_2Nx2N) e->ws->intMv[list][refIdx] = mv;
   }
   HM_PROF_END(e, PR_ME_INT);
   HM_PROF_BEGIN(e, PR_ME_FRAC);
@@ -1231,7 +1231,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
       cabac_put(&e->cur, root);
       reset_bits(&e->cur);
       uint32_t currBits = 0, currDist = 0, nonCoeffBits = 0, nonCoeffDist = 0; double currCost = 0, nonCoeffCost = 0;
-      if (!isOne && !isFirst) { HM_PAR_FOR(i, 16) { e->tsCoef[comp][i] = coef[i]; e->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; } HM_SYNC(); }
+      if (!isOne && !isFirst) { HM_PAR_FOR(i, 16) { e->ws->tsCoef[comp][i] = coef[i]; e->ws->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; } HM_SYNC(); }
       HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int r = resi[y * st + x]; e->bufA[y * HM_TSTRIDE + x] = tsMode ? (r << tshift) : r; }
       HM_SYNC();
       { HM_PROF_BEGIN(e, PR_IQ_FWD); if (!tsMode) fwd_transform(e, n, 0, bd); HM_PROF_END(e, PR_IQ_FWD); }
@@ -1288,7 +1288,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
         if (absSum == 0) { HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); rq[y * st + x] = 0; } }
         HM_SYNC();
       } else {
-        HM_PAR_FOR(i, 16) { coef[i] = e->tsCoef[comp][i]; rq[(i >> 2) * st + (i & 3)] = e->tsRec[comp][i]; }
+        HM_PAR_FOR(i, 16) { coef[i] = e->ws->tsCoef[comp][i]; rq[(i >> 2) * st + (i & 3)] = e->ws->tsRec[comp][i]; }
         HM_SYNC();
       }
       (void)currBits;

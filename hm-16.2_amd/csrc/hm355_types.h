@@ -72,6 +72,8 @@ struct WorkSpace {
   Pel pred[HM_COEF_CTU], resi[HM_COEF_CTU], reco[HM_COEF_CTU];
   Pel qtRec[4][HM_COEF_CTU];         // m_pcQTTempTComYuv[layer]
   TCoeff qtCoef[4][HM_COEF_CTU];     // m_ppcQTTempCoeff[comp][layer]
+  MvD intMv[2][16];                  // TEncSearch::m_integerMv2Nx2N[list][refIdx] of the search in progress (read and written once per motion search)
+  Pel tsPred[3][16], tsRec[3][16]; TCoeff tsCoef[3][16];   // the parked first trial of a 4x4 transform-skip decision (wave-uniform path; rare since the candidates-in-lanes paths)
   double costCoeff[1024];            // RDOQ of 32x32 blocks: cost of the positions that keep a non-zero level (everything else of its per-position state is in LDS)
   Cabac slot[4 * CI_NUM + 3];        // m_pppcRDSbacCoder[depth][CI_*] snapshots (the live coder stays in LDS); depth 4 only holds TEMP_BEST/QT_TRAFO_*
   Pel tmpPred[HM_COEF_CTU];          // m_tmpYuvPred (merge / ME prediction error)
