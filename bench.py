@@ -7,8 +7,13 @@
 A "step" = one pass of the hot path (the TEncSlice::compressSlice replacement) over one batch of
 independent all-intra pictures that are already resident in HBM: synthetic 3840x2160 10-bit frames,
 encoder_intra_main10 parameters, QP 32, WaveFrontSynchro=1 (BASELINE.json configs[3], the configuration
-the metric is quoted on; it fits one GPU).  Every rank owns one GPU and its own batch (weak scaling: the
-path shards by picture with no data-path collective); RCCL is used only for the barrier / max-time.
+the metric is quoted on; it fits one GPU).  Consecutive steps are pipelined over `--lanes` HIP streams
+(hm355_run_begin / hm355_run_wait): each step has its own picture slots and its own launch, step k + lanes
+is issued once step k has finished, so the wavefront drain of one step overlaps the fill of the next ones
+and the device stays full with far fewer pictures per step.  The timed region holds exactly K steps between
+two barrier + synchronize pairs: the pipeline is empty when it starts and when it ends.
+Every rank owns one GPU and its own batches (weak scaling: the path shards by picture with no data-path
+collective); RCCL is used only for the barrier / max-time.
 """
 import argparse
 import json
@@ -67,13 +72,13 @@ def rank_frame_numbers(rank, count=DISTINCT_FRAMES):
     return [DISTINCT_FRAMES * rank + f for f in range(count)]
 
 
-def plan_steps(step_s, warmup, steps, budget_s):
-    """(warm-up, timed) steps that fit `budget_s` seconds of wall time when one step takes `step_s`; one warm-up step (the one that
-    was just timed) has already run.  The requested counts are kept whenever they fit."""
-    warmup = max(1, warmup)
+def plan_steps(step_s, warmup, steps, budget_s, first=1):
+    """(warm-up, timed) steps that fit `budget_s` seconds of wall time when one step takes `step_s`; `first` warm-up steps (the ones
+    that were just timed) have already run.  The requested counts are kept whenever they fit."""
+    warmup = max(first, warmup)
     if step_s * (warmup + steps) <= budget_s:
         return warmup, steps
-    return 1, max(1, min(steps, int((budget_s - step_s) / max(step_s, 1e-9))))
+    return first, max(1, min(steps, int((budget_s - step_s * first) / max(step_s, 1e-9))))
 
 
 def agree_over_ranks(dist, torch, v, op, device):
@@ -90,12 +95,23 @@ def _frame_job(a):
     return synth.frame(*a)
 
 
+def gpu_runtime_loaded():
+    """True when the HIP / HSA runtime is already mapped into this process (or that cannot be told): no fork then"""
+    try:
+        with open("/proc/self/maps") as fh:
+            maps = fh.read()
+    except OSError:
+        return True
+    return any(lib in maps for lib in ("libamdhip64", "libhsa-runtime64", "librocprofiler", "libroctracer"))
+
+
 def distinct_frames(width, height, bit_depth, numbers, seed):
     """the synthetic frames `numbers`, generated on a few host cores (call before the process touches the GPU: the pool forks)"""
     import synth
     jobs = [(width, height, bit_depth, f, seed) for f in numbers]
-    # under rocprofv3 the profiler's preloaded library has initialised the GPU before main(): no fork then
-    if len(jobs) < 4 or "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("HM355_NO_FORK"):
+    # A tool preloaded into this process (rocprofv3, any other injected library) may have initialised the GPU before main(): a forked
+    # child would then hold the device.  The pool is only used when neither the HIP nor the HSA runtime is mapped into the process yet.
+    if len(jobs) < 4 or os.environ.get("HM355_NO_FORK") or gpu_runtime_loaded():
         return [synth.frame(*j) for j in jobs]
     import multiprocessing as mp
     with mp.get_context("fork").Pool(min(8, len(jobs), os.cpu_count() or 1)) as pool:
@@ -164,7 +180,7 @@ Frame8:  B    7   4        0.68     0            0              1           2   
 }
 
 
-def cpu_baseline_inter(kind, qp, width):
+def cpu_baseline_inter(kind, qp, width, height):
     """The reference's own encoder (oracle/_ref/hm_encoder) on one host core for the same configuration, on a bounded sample of the
     benched picture size: the top 4 CTU rows (width x 256) of the same synthetic clip, encoded with 1 picture and with 1 + n inter
     pictures; the difference is the time of the n inter pictures (whole encoder: the search dominates)."""
@@ -183,7 +199,7 @@ def cpu_baseline_inter(kind, qp, width):
         yuv = os.path.join(td, "in.yuv")
         with open(yuv, "wb") as fh:
             for f in range(1 + n_inter):
-                y, u, v = synth.frame(w, 1080 if w == 1920 else 2160, bd, f, 1234)
+                y, u, v = synth.frame(w, height, bd, f, 1234)
                 for p in (y[:h], u[:h // 2], v[:h // 2]):
                     fh.write(np.ascontiguousarray(p).astype(np.uint8 if bd == 8 else "<u2").tobytes())
         cfg = os.path.join(td, "inter.cfg")
@@ -275,7 +291,7 @@ def run_inter(args, torch):
         "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "traffic": None, "note": f"algorithmic bytes {alg} B/CTU (SURVEY 8d)"}}
     if not args.no_cpu_baseline:
-        cb = cpu_baseline_inter(kind, qp, w)
+        cb = cpu_baseline_inter(kind, qp, w, h)
         if cb:
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_1core"] = line["value"] / cb["value"]
@@ -462,19 +478,23 @@ def run_bits(args, torch):
     enc.close()
 
 
-def intra_line(args, world, rows_mode, group, steps, warmup, dt, kernel_ms, launches, total_ctus, ctus_per_rank):
+def intra_line(args, world, rows_mode, group, steps, warmup, dt, kernel_ms, launches, total_ctus, ctus_per_rank, build_id="unknown"):
     """the JSON line of the intra4k workload (rank 0), without the CPU baseline"""
-    # HBM bytes per launch from the committed PMC passes of this workload, if they match its size
-    traffic = None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if (tj["width"], tj["height"], tj["frames"]) == (args.width, args.height, args.frames):
-                traffic = tj["hbm_bytes_per_launch"]
-                break
-        except (OSError, KeyError, ValueError):
-            pass
-    ach = ALG_BYTES_PER_CTU * ctus_per_rank / (kernel_ms * 1e-3) / 1e9    # GB/s of the CTU-search kernel on this rank
+    # HBM bytes per launch from the PMC passes committed under profiles/ -- quoted only when they were taken on this very build of
+    # the library (hm355_build_id) with this launch shape; otherwise null: counters of another build say nothing about this run
+    traffic, traffic_note = None, "no PMC passes of this build and launch shape under profiles/"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        if (tj["width"], tj["height"], tj["frames"], tj.get("lanes", 1)) == (args.width, args.height, args.frames, args.lanes) and tj.get("build_id") == build_id:
+            traffic, traffic_note = tj["hbm_bytes_per_launch"], "PMC FETCH_SIZE + WRITE_SIZE (separate passes) on this build: profiles/r03_traffic.json"
+        else:
+            traffic_note = f"profiles/r03_traffic.json is from build {tj.get('build_id')} / another launch shape, this run is build {build_id}"
+    except (OSError, KeyError, ValueError):
+        pass
+    # algorithmic bytes per launch / average launch duration (HIP events on the launch's stream), times the launches in flight on average
+    # (= sum of the launch durations / timed region): the GB/s of the CTU-search kernel on this rank over the timed region
+    in_flight = (kernel_ms * 1e-3) / dt if not rows_mode else 1.0
+    ach = ALG_BYTES_PER_CTU * ctus_per_rank / (kernel_ms * 1e-3) / 1e9 * in_flight
     return {
         "metric": "CTUs/sec (enc) at 4K main10; bit-exact CU partition vs HM",
         "value": total_ctus / dt, "unit": "CTU/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -482,17 +502,19 @@ def intra_line(args, world, rows_mode, group, steps, warmup, dt, kernel_ms, laun
         "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "strong" if rows_mode else "weak", "vs_baseline": None,
         "dtype": "int32+f64", "data": "synthetic",
         "config": {"workload": f"encoder_intra_main10, synthetic {args.width}x{args.height} 10-bit, QP {args.qp}, WaveFrontSynchro=1, " +
-                               (f"{args.frames} independent I pictures per step shared by the ranks" if rows_mode else f"{args.frames} independent I pictures per GPU per step") +
+                               (f"{args.frames} independent I pictures per step shared by the ranks" if rows_mode else
+                                f"{args.frames} independent I pictures per GPU per step, steps pipelined {args.lanes} deep") +
                                f" ({min(DISTINCT_FRAMES, args.frames)} distinct frames), inputs resident in HBM",
-                   "frames_per_gpu": args.frames, "ctus_per_step": total_ctus // steps,
+                   "frames_per_gpu": args.frames, "ctus_per_step": total_ctus // steps, "lanes": 1 if rows_mode else args.lanes, "build_id": build_id,
                    "parallelism": (f"CTU rows of every picture sharded over {world} GPUs in bands, boundary rows handed down over RCCL send / recv, {group} pictures per pipeline stage"
                                    if rows_mode else f"pictures sharded over {world} GPU(s), 2-CTU-lag wavefront inside a picture"),
                    "step_budget": f"warm-up + timed steps bounded to {args.budget_s:.0f} s of wall time: {warmup}+{steps} of the requested {args.warmup}+{args.steps} steps run"},
         "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                     "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches,
-                     "note": "algorithmic bytes 54,278 B/CTU (SURVEY 8d) x CTUs / HIP-event kernel time; the path is bound by the latency of its own "
-                             "dependent LDS / L2 round trips (profiles/r02_pmc_sq_summary.json), not by HBM"},
+                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                     "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches, "launches_in_flight": in_flight,
+                     "note": "achieved = 54,278 B/CTU (SURVEY 8d) x CTUs per launch / average launch duration (HIP events on the launch's stream) x "
+                             "launches in flight on average; the path is bound by the latency of its own dependent LDS / L2 round trips "
+                             "(profiles/r02_pmc_sq_summary.json), not by HBM"},
     }
 
 
@@ -508,6 +530,7 @@ def main():
     ap.add_argument("--group", type=int, default=0, help="--shard rows: pictures per pipeline stage (default: frames / (4 * ranks))")
     ap.add_argument("--budget-s", type=float, default=280.0, help="wall-time bound of warm-up + timed steps (intra4k); fewer steps run when the request does not fit")
     ap.add_argument("--frames", type=int, default=768, help="independent pictures per GPU per step")
+    ap.add_argument("--lanes", type=int, default=1, help="steps in flight at a time (hm355_run_begin / hm355_run_wait; 1..4)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=32)
@@ -548,10 +571,13 @@ def main():
 
     import hm355
     bd, seed = 10, 1234
-    enc = hm355.Encoder(args.width, args.height, bd, 1, args.frames)
-    # synthetic clip: 16 distinct frames per rank (rank r takes frames 16r .. 16r+15), cycled over the batch slots; resident in HBM before timing
+    lanes = 1 if rows_mode else max(1, min(4, args.lanes))
+    args.lanes = lanes
+    enc = hm355.Encoder(args.width, args.height, bd, 1, args.frames * lanes)
+    build_id = enc.lib.hm355_build_id().decode()
+    # synthetic clip: 16 distinct frames per rank (rank r takes frames 16r .. 16r+15), cycled over the picture slots; resident in HBM before timing
     distinct = pre_frames
-    for i in range(args.frames):
+    for i in range(args.frames * lanes):
         enc.upload(i, distinct[i % len(distinct)])
     del distinct
 
@@ -564,9 +590,6 @@ def main():
     def agree(v, op):
         return agree_over_ranks(dist, torch, v, op, "cuda")
 
-    # Warm-up.  The first step is timed: when the requested warm-up + timed steps would not fit the wall budget (the driver's
-    # 600 s limit covers start-up, the steps and the CPU baseline), the warm-up stops after that step and as many timed steps
-    # run as fit (at least one); the line reports the steps actually run next to the ones requested.
     if rows_mode:
         # every rank holds the same pictures and searches its band of CTU rows; the last row of a band goes down to the next rank (RCCL send / recv)
         import bands
@@ -574,25 +597,42 @@ def main():
         transport = bands.TorchTransport(dist, torch, torch.device("cuda", local_rank))
         group = args.group or max(1, args.frames // (4 * world))
 
-        def one_step():
-            return bands.run_banded(enc, args.frames, group, h_ctu, rank, world, transport.send, transport.recv, args.qp), len(bands.picture_groups(args.frames, group))
+        def run_steps(count):
+            ms_sum, launches = 0.0, 0
+            for _ in range(count):
+                ms_sum += bands.run_banded(enc, args.frames, group, h_ctu, rank, world, transport.send, transport.recv, args.qp, transport.buffer)
+                launches += len(bands.picture_groups(args.frames, group))
+            return ms_sum, launches
     else:
-        def one_step():
-            return enc.run(args.frames, args.qp)   # blocking: returns after the last kernel of the step finished
+        def run_steps(count):
+            """`count` steps, pipelined `lanes` deep: step k runs on lane k % lanes over that lane's own slots; returns when the last
+            step has finished (the pipeline is empty again), with the summed per-launch kernel times (HIP events) and the launch count"""
+            ms_sum, busy = 0.0, [False] * lanes
+            for k in range(count):
+                lane = k % lanes
+                if busy[lane]:
+                    ms_sum += enc.run_wait(lane)
+                enc.run_begin(lane, lane * args.frames, args.frames, args.qp)
+                busy[lane] = True
+            for lane in range(lanes):          # oldest launch first
+                l2 = (count + lane) % lanes
+                if busy[l2]:
+                    ms_sum += enc.run_wait(l2)
+            return ms_sum, count
+    # Warm-up.  Its first `lanes` steps are timed: when the requested warm-up + timed steps would not fit the wall budget (the driver's
+    # 600 s limit covers start-up, the steps and the CPU baseline), the warm-up stops there and as many timed steps run as fit (at least
+    # one pipeline depth); the line reports the steps actually run next to the ones requested.
+    first = min(max(1, args.warmup), lanes)
     t0 = time.perf_counter()
-    one_step()
+    run_steps(first)
     barrier()
-    step_s = agree(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
-    warmup, steps = plan_steps(step_s, args.warmup, args.steps, args.budget_s)
-    for _ in range(warmup - 1):
-        one_step()
+    step_s = agree((time.perf_counter() - t0) / first, dist.ReduceOp.MAX if dist else None)
+    warmup, steps = plan_steps(step_s, args.warmup, args.steps, args.budget_s, first)
+    if warmup > first:
+        run_steps(warmup - first)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, launches = 0.0, 0
-    for _ in range(steps):
-        ms, l = one_step()
-        kernel_ms += ms
-        launches += l
+    kernel_ms, launches = run_steps(steps)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -605,7 +645,7 @@ def main():
         ctus_per_rank = enc.num_ctus * args.frames * steps
         total_ctus = ctus_per_rank * world
     if rank == 0:
-        line = intra_line(args, world, rows_mode, group if rows_mode else 0, steps, warmup, dt, kernel_ms, launches, total_ctus, ctus_per_rank)
+        line = intra_line(args, world, rows_mode, group if rows_mode else 0, steps, warmup, dt, kernel_ms, launches, total_ctus, ctus_per_rank, build_id)
         if not args.no_cpu_baseline and world >= 1:
             line["cpu_baseline"] = cpu_baseline(args.width, bd, args.qp, seed)
             line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]

@@ -28,9 +28,12 @@ def picture_groups(num_pictures, group):
     return [(s, min(group, num_pictures - s)) for s in range(0, num_pictures, group)]
 
 
-def run_banded(engine, num_pictures, group, h_ctu, rank, world, send, recv, qp):
+def run_banded(engine, num_pictures, group, h_ctu, rank, world, send, recv, qp, buffer=None):
     """Search this rank's band of `num_pictures` pictures resident in the engine's slots, `group` pictures per launch.
-    Returns the kernel milliseconds this rank spent.  Ranks without rows only forward nothing and return 0."""
+    Returns the kernel milliseconds this rank spent.  Ranks without rows only forward nothing and return 0.
+    `buffer(nbytes)` (optional) allocates a device-resident byte buffer (an object with data_ptr()): the boundary rows then go from the
+    slots into it and from it into the slots on the device (hm355_export_boundary / hm355_import_boundary accept device pointers), and
+    the transport is handed the device buffer -- no host hop.  Without it the rows travel as numpy arrays."""
     first, last = band_rows(h_ctu, world, rank)
     if last < first:
         return 0.0
@@ -43,11 +46,19 @@ def run_banded(engine, num_pictures, group, h_ctu, rank, world, send, recv, qp):
         if has_above:
             data = recv(n * nbytes, rank - 1)
             for i in range(n):
-                engine.import_boundary(slot0 + i, first - 1, data[i * nbytes:(i + 1) * nbytes])
+                if hasattr(data, "data_ptr"):
+                    engine.import_boundary_ptr(slot0 + i, first - 1, data.data_ptr() + i * nbytes)
+                else:
+                    engine.import_boundary(slot0 + i, first - 1, data[i * nbytes:(i + 1) * nbytes])
         ms, _ = engine.run_rows(slot0, n, qp, first, last)
         kernel_ms += ms
         if has_below:
-            out = np.concatenate([engine.export_boundary(slot0 + i, last) for i in range(n)])
+            if buffer is not None:
+                out = buffer(n * nbytes)
+                for i in range(n):
+                    engine.export_boundary_ptr(slot0 + i, last, out.data_ptr() + i * nbytes)
+            else:
+                out = np.concatenate([engine.export_boundary(slot0 + i, last) for i in range(n)])
             pending.append(send(out, rank + 1))
     for h in pending:
         if h is not None:
@@ -55,21 +66,34 @@ def run_banded(engine, num_pictures, group, h_ctu, rank, world, send, recv, qp):
     return kernel_ms
 
 
+class _Sent:
+    """an asynchronous send in flight: owns the tensor until the send has completed"""
+
+    def __init__(self, work, tensor):
+        self.work, self.tensor = work, tensor
+
+    def wait(self):
+        self.work.wait()
+        self.tensor = None
+
+
 class TorchTransport:
-    """send / recv of byte arrays over torch.distributed point-to-point (backend "nccl" = RCCL between GPUs: device tensors; "gloo": host tensors)"""
+    """send / recv of byte buffers over torch.distributed point-to-point.  Backend "nccl" = RCCL between GPUs: the buffers are device
+    tensors from `buffer()`, filled and consumed on the device (no host hop); "gloo" (device None): numpy arrays through host tensors."""
 
     def __init__(self, dist, torch, device=None):
         self.dist, self.torch, self.device = dist, torch, device
-        self._keep = []
 
-    def send(self, array, dst):
-        t = self.torch.from_numpy(np.ascontiguousarray(array, np.uint8))
-        if self.device is not None:
+    def buffer(self, nbytes):
+        return self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device)
+
+    def send(self, data, dst):
+        t = data if hasattr(data, "data_ptr") else self.torch.from_numpy(np.ascontiguousarray(data, np.uint8))
+        if self.device is not None and t.device != self.device:
             t = t.to(self.device)
-        self._keep.append(t)                     # the tensor must outlive the asynchronous send
-        return self.dist.isend(t, dst)
+        return _Sent(self.dist.isend(t, dst), t)      # the tensor lives until wait()
 
     def recv(self, nbytes, src):
         t = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.device if self.device is not None else "cpu")
         self.dist.recv(t, src)
-        return t.cpu().numpy()
+        return t if self.device is not None else t.numpy()

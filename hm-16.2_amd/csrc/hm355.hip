@@ -87,6 +87,53 @@ extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Param
   }
 }
 
+// The same scheduler with a TEAM of wavefronts per CTU (hm355_team.h): wave 0 takes the tickets, waits for the dependencies and runs the
+// reference's recursion; waves 1.. evaluate the unsplit candidates it hands them.  Used for launches that cannot fill the device with
+// one-wavefront searches (a few pictures, or pictures whose CABAC state chains through every CTU), where the time of ONE CTU search is
+// what the launch takes.  I slices.
+__shared__ Team g_team;
+extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
+{
+  Team *T = &g_team;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (threadIdx.x < HM_TEAM_HELPERS) { T->box[threadIdx.x].reqSeq = 0; T->box[threadIdx.x].doneSeq = 0; }
+  if (threadIdx.x == 0) { T->quit = 0; T->dead = 0; T->abortWord = sched + 1; }
+  __syncthreads();
+  if (wave != 0) {
+    team_helper(T, wave - 1, P->teamWin + ((size_t)blockIdx.x * HM_TEAM_HELPERS + (size_t)(wave - 1)) * P->teamWinStride);
+    return;
+  }
+  for (;;) {
+    int idx = 0;
+    if (threadIdx.x == 0) idx = (int)atomicAdd(&sched[0], 1u);
+    idx = __shfl(idx, 0, 64);
+    if (idx >= total) break;
+    if (threadIdx.x == 0) T->item = items[idx];
+    HM_SYNC();
+    const int cx = T->item.ctuX, cy = T->item.ctuY, wCtu = P->wCtu;
+    const unsigned int *done = P->frames[T->item.frame].done;
+    const int a = cy * wCtu + cx;
+    int dep0 = -1, dep1 = -1;
+    if (P->wpp) {
+      if (cx > 0) dep0 = a - 1;
+      if (cy > 0) dep1 = (cy - 1) * wCtu + (cx + 1 < wCtu ? cx + 1 : cx);
+    } else if (a > 0) dep0 = a - 1;
+    int bad = 0;
+    if (dep0 >= 0) bad = hm355_wait_flag(done + dep0, sched + 1, epoch);
+    if (!bad && dep1 >= 0) bad = hm355_wait_flag(done + dep1, sched + 1, epoch);
+    if (bad) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    process_ctu(&T->sh[0], P, &T->item, (int)blockIdx.x * HM_TEAM, T);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    HM_SYNC();
+    if (team_ld(&T->dead)) break;
+  }
+  HM_TEAM_RELEASE();
+  team_st(&T->quit, 1u);
+}
+
 // batched distortion primitives: one wavefront per n x n block pair
 extern "C" __global__ void __launch_bounds__(64) hm355_dist_kernel(int kind, int n, int bitDepth, int count, const Pel *org, const Pel *cur, uint32_t *out)
 {
@@ -131,6 +178,18 @@ struct Slot {           // one picture resident in HBM
   uint8_t *bitsRaw, *bitsPacked; uint32_t *bitsSizes; CabacW *bitsSync; uint32_t *bitsFlag; InterPic *bitsIp;   // bitstream pass (allocated on first use)
 };
 #define HM_BITS_CAP_PER_CTU 16384u   /* bytes reserved per CTU in the raw substream buffers: above the raw size of a 10-bit 4:2:0 CTU (7.7 KB) */
+#define HM_MAX_LANES 4
+struct Lane {           // one launch of the search in flight: its own stream, scratch areas, work list and scheduler words
+  hipStream_t stream; hipEvent_t ev0, ev1;
+  Params *dP;           // device copy of the kernel parameters with this lane's scratch areas
+  WorkSpace *dWs; size_t wsCount;
+  WorkItem *dItems; size_t itemsCap;
+  unsigned int *dSched; // [0] ticket, [1] abort
+  std::vector<WorkItem> items; std::vector<int> stepStart; std::vector<FrameBuf> fbs;
+  long long key[5]; int keyValid, fewWaves;
+  int busy, grid;
+  Pel *dTeamWin; size_t teamCap;   // team launches (hm355_team.h): the helpers' reconstruction windows, for teamCap teams
+};
 struct hm355_ctx {
   hm355_seq_cfg cfg;
   Params hp;            // host copy of the kernel parameters
@@ -139,10 +198,9 @@ struct hm355_ctx {
   FrameBuf *dFrames;
   WorkSpace *dWs; size_t wsCount;
   uint8_t *arena;       // the pictures' planes, decision arrays, coefficients, statistics, CABAC states, done words: one allocation
-  WorkItem *dItems; size_t itemsCap;
   unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort of the search launch; [8] ticket, [9] abort of the bitstream launch
   std::vector<Slot> slots;
-  std::vector<WorkItem> items; std::vector<int> stepStart; long long schedKey;
+  Lane lane[HM_MAX_LANES];   // lane 0 is the context's own stream / scratch (every blocking entry point); 1.. are created on first use
   hipStream_t stream; hipEvent_t ev0, ev1;
   double lastKernelMs; int lastLaunches;
   std::string err;
@@ -158,6 +216,10 @@ struct hm355_ctx {
 
 static int fail(hm355_ctx *c, int code, const char *msg) { if (c) c->err = msg; return code; }
 
+#ifndef HM355_BUILD_ID
+#define HM355_BUILD_ID "unknown"
+#endif
+extern "C" const char *hm355_build_id(void) { return HM355_BUILD_ID; }
 extern "C" const char *hm355_last_error(const hm355_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
 static int maxItemsPerStep(int wCtu, int hCtu, int wpp, int frames)
@@ -179,8 +241,9 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
-  c->cfg = *cfg; c->schedKey = -1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
-  c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->dItems = NULL; c->itemsCap = 0; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
+  c->cfg = *cfg; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
+  c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
+  for (int l = 0; l < HM_MAX_LANES; l++) { Lane &L = c->lane[l]; L.stream = NULL; L.ev0 = L.ev1 = NULL; L.dP = NULL; L.dWs = NULL; L.wsCount = 0; L.dItems = NULL; L.itemsCap = 0; L.dSched = NULL; L.keyValid = 0; L.fewWaves = -1; L.busy = 0; L.grid = 0; L.dTeamWin = NULL; L.teamCap = 0; }
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
   P.wCtu = (cfg->width + 63) / 64; P.hCtu = (cfg->height + 63) / 64;
@@ -195,7 +258,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   delete ht;
   HM_CHECK(c, e);
   // one scratch area per resident workgroup of the persistent grid: 256 CUs x 8 single-wave workgroups, or fewer when the batch is small
-  c->wsCount = (size_t)c->numCtus * (size_t)cfg->max_batch; if (c->wsCount > 3072) c->wsCount = 3072;   // 12 searches per CU x 256 CUs is the most that can be resident
+  c->wsCount = (size_t)c->numCtus * (size_t)cfg->max_batch * HM_TEAM; if (c->wsCount > 3072) c->wsCount = 3072;   // 12 searches per CU x 256 CUs is the most that can be resident; a small batch runs as teams of HM_TEAM wavefronts per CTU
   HM_CHECK(c, hipMalloc((void **)&c->dSched, 64)); HM_CHECK(c, hipMemset(c->dSched, 0, 64));
   HM_CHECK(c, hipMalloc((void **)&c->dWs, c->wsCount * sizeof(WorkSpace)));
   HM_CHECK(c, hipMalloc((void **)&c->dFrames, sizeof(FrameBuf) * cfg->max_batch));
@@ -245,8 +308,17 @@ extern "C" void hm355_destroy(hm355_ctx *c)
       if (sl.bitsSync) hipFree(sl.bitsSync); if (sl.bitsFlag) hipFree(sl.bitsFlag); if (sl.bitsIp) hipFree(sl.bitsIp); }
     if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCand) hipFree(c->slots[s].saoCand); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
   }
+  for (int l = 0; l < HM_MAX_LANES; l++) {
+    Lane &L = c->lane[l];
+    if (L.busy && L.stream) hipStreamSynchronize(L.stream);
+    if (L.dItems) hipFree(L.dItems);
+    if (L.dTeamWin) hipFree(L.dTeamWin);
+    if (l == 0) continue;           // lane 0 wraps the context's own objects, released below
+    if (L.dWs) hipFree(L.dWs); if (L.dSched) hipFree(L.dSched); if (L.dP) hipFree(L.dP);
+    if (L.ev0) hipEventDestroy(L.ev0); if (L.ev1) hipEventDestroy(L.ev1); if (L.stream) hipStreamDestroy(L.stream);
+  }
   if (c->arena) hipFree(c->arena);
-  if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dItems) hipFree(c->dItems); if (c->dSched) hipFree(c->dSched);
+  if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dSched) hipFree(c->dSched);
   if (c->staging) hipHostFree(c->staging);
   if (c->dDbk) hipFree(c->dDbk);
   if (c->dSao) hipFree(c->dSao);
@@ -269,55 +341,138 @@ extern "C" int hm355_upload(hm355_ctx *c, int slot, const hm355_planes *org)
   return HM355_OK;
 }
 
-// the search over CTU rows [row0, row1] of the pictures in slots [slot0, slot0 + n); rows above row0 hold finished (or imported) CTUs
-static int run_rows_impl(hm355_ctx *c, int slot0, int n, const hm355_slice_desc *slices, int row0, int row1)
+// Lane l of the context: lane 0 wraps the context's own stream, scratch areas and scheduler words; further lanes get theirs on first use.
+static int lane_prepare(hm355_ctx *c, int l)
+{
+  Lane &L = c->lane[l];
+  if (L.stream) return HM355_OK;
+  if (l == 0) { L.stream = c->stream; L.ev0 = c->ev0; L.ev1 = c->ev1; L.dP = c->dP; L.dWs = c->dWs; L.wsCount = c->wsCount; L.dSched = c->dSched; L.fewWaves = c->hp.fewWaves; return HM355_OK; }
+  HM_CHECK(c, hipStreamCreate(&L.stream));
+  HM_CHECK(c, hipEventCreate(&L.ev0)); HM_CHECK(c, hipEventCreate(&L.ev1));
+  L.wsCount = c->wsCount;
+  HM_CHECK(c, hipMalloc((void **)&L.dWs, L.wsCount * sizeof(WorkSpace)));
+  HM_CHECK(c, hipMalloc((void **)&L.dSched, 64)); HM_CHECK(c, hipMemset(L.dSched, 0, 64));
+  HM_CHECK(c, hipMalloc((void **)&L.dP, sizeof(Params)));
+  L.fewWaves = -1;
+  return HM355_OK;
+}
+
+// Enqueues the search over CTU rows [row0, row1] of the pictures in slots [slot0, slot0 + n) on lane l and returns; rows above row0 hold
+// finished (or imported) CTUs.  Launches of different lanes run concurrently (each on its own stream with its own scratch areas), so the
+// drain of one step overlaps the fill of the next; their slot ranges must not overlap.
+static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_desc *slices, int row0, int row1)
 {
   const Params &P = c->hp;
-  std::vector<FrameBuf> fbs(n);
+  int rc = lane_prepare(c, l);
+  if (rc != HM355_OK) return rc;
+  Lane &L = c->lane[l];
+  if (L.busy) return fail(c, HM355_ERR_ARG, "hm355_run_begin: the lane still has a launch in flight (hm355_run_wait first)");
+  L.fbs.resize(n);
   for (int f = 0; f < n; f++) {
     if (slices[f].slice_type != 2) return fail(c, HM355_ERR_ARG, "only I slices are supported");
     if (slices[f].qp < 0 || slices[f].qp > 51 || !(slices[f].lambda > 0) || !(slices[f].chroma_weight > 0)) return fail(c, HM355_ERR_ARG, "bad slice parameters");
     hm355_fill_slice_params(&c->slots[slot0 + f].fb, P.bitDepth, slices[f].qp, slices[f].lambda, slices[f].chroma_weight);
-    fbs[f] = c->slots[slot0 + f].fb;
+    L.fbs[f] = c->slots[slot0 + f].fb;
   }
-  HM_CHECK(c, hipMemcpyAsync(c->dFrames + slot0, fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, c->stream));
+  HM_CHECK(c, hipMemcpyAsync(c->dFrames + slot0, L.fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, L.stream));
   int carry = 0;
   for (int f = 0; f < n; f++) carry |= c->slots[slot0 + f].fb.imeta != NULL && (P.height & 63) != 0;
-  const long long schedKey = ((((long long)slot0 * 4096 + n) * 2 + carry) * 1024 + row0) * 1024 + row1;
-  if (c->schedKey != schedKey) {
-    hm355_build_schedule(P.wCtu, P.hCtu, P.wpp, n, c->items, c->stepStart, carry, slot0, row0, row1);
-    if (c->items.size() > c->itemsCap) {
-      if (c->dItems) hipFree(c->dItems);
-      c->dItems = NULL; c->itemsCap = 0;
-      HM_CHECK(c, hipMalloc((void **)&c->dItems, sizeof(WorkItem) * c->items.size()));
-      c->itemsCap = c->items.size();
+  const long long key[5] = {slot0, n, carry, row0, row1};      // the cached work list is reused only for the very same launch shape
+  if (!L.keyValid || memcmp(key, L.key, sizeof(key)) != 0) {
+    L.keyValid = 0;
+    hm355_build_schedule(P.wCtu, P.hCtu, P.wpp, n, L.items, L.stepStart, carry, slot0, row0, row1);
+    if (L.items.size() > L.itemsCap) {
+      if (L.dItems) hipFree(L.dItems);
+      L.dItems = NULL; L.itemsCap = 0;
+      HM_CHECK(c, hipMalloc((void **)&L.dItems, sizeof(WorkItem) * L.items.size()));
+      L.itemsCap = L.items.size();
     }
-    HM_CHECK(c, hipMemcpyAsync(c->dItems, c->items.data(), sizeof(WorkItem) * c->items.size(), hipMemcpyHostToDevice, c->stream));
-    c->schedKey = schedKey;
+    HM_CHECK(c, hipMemcpyAsync(L.dItems, L.items.data(), sizeof(WorkItem) * L.items.size(), hipMemcpyHostToDevice, L.stream));
+    memcpy(L.key, key, sizeof(key)); L.keyValid = 1;
   }
-  { // a WPP picture offers about 16 CTUs at a time (one when the CABAC state chains through all of them): can this launch keep ~5 searches per CU busy?
-    const int fewWaves = (long long)n * (P.wpp ? 16 : 1) < 1280 ? 1 : 0;
-    if (fewWaves != c->hp.fewWaves) { c->hp.fewWaves = fewWaves; HM_CHECK(c, hipMemcpyAsync(c->dP, &c->hp, sizeof(Params), hipMemcpyHostToDevice, c->stream)); }
+  // A WPP picture offers about 16 CTUs at a time (one when the CABAC state chains through all of them).  A launch that cannot keep ~5
+  // one-wavefront searches per CU busy prefers the shortest dependency chain over the fewest instructions (fewWaves); one that cannot
+  // even give every CU two searches runs as teams of HM_TEAM wavefronts per CTU (I slices; HM355_TEAM=0 / 1 overrides for A/B runs).
+  const long long parallel = (long long)n * (P.wpp ? 16 : 1);
+  const int fewWaves = parallel < 1280 ? 1 : 0;
+  int useTeam = parallel <= 512 && L.wsCount >= HM_TEAM;
+  for (int f = 0; f < n; f++) if (c->slots[slot0 + f].fb.imeta) useTeam = 0;
+  { const char *ev = getenv("HM355_TEAM"); if (ev && ev[0] == '0') useTeam = 0; if (ev && ev[0] == '1' && L.wsCount >= HM_TEAM && !carry) { useTeam = 1; for (int f = 0; f < n; f++) if (c->slots[slot0 + f].fb.imeta) useTeam = 0; } }
+  const size_t winSamples = (size_t)65 * P.stride[0] + (size_t)33 * (P.stride[1] + P.stride[2]);
+  int teams = 0;
+  if (useTeam) {
+    const size_t total = L.items.size();
+    // as many teams as CTUs can ever be ready at once (the wavefront's widest step), a few more so that a finished team finds the next ticket taken
+    size_t want = (size_t)maxItemsPerStep(P.wCtu, row1 - row0 + 1 < P.hCtu ? row1 - row0 + 1 : P.hCtu, P.wpp, n) + 2;
+    if (want > total) want = total; if (want > 512) want = 512; if (want > L.wsCount / HM_TEAM) want = L.wsCount / HM_TEAM;
+    if (want > L.teamCap) {
+      HM_CHECK(c, hipStreamSynchronize(L.stream));
+      if (L.dTeamWin) hipFree(L.dTeamWin);
+      L.dTeamWin = NULL; L.teamCap = 0; L.fewWaves = -1;
+      if (hipMalloc((void **)&L.dTeamWin, want * HM_TEAM_HELPERS * winSamples * sizeof(Pel)) != hipSuccess) { (void)hipGetLastError(); useTeam = 0; }
+      else L.teamCap = want;
+    }
+    teams = (int)(want < L.teamCap ? want : L.teamCap);
+  }
+  if (fewWaves != L.fewWaves) {
+    Params lp = c->hp; lp.ws = L.dWs; lp.fewWaves = fewWaves; lp.teamWin = L.dTeamWin; lp.teamWinStride = winSamples;
+    if (l == 0) { c->hp.fewWaves = fewWaves; c->hp.teamWin = L.dTeamWin; c->hp.teamWinStride = winSamples; }
+    HM_CHECK(c, hipMemcpyAsync(L.dP, &lp, sizeof(Params), hipMemcpyHostToDevice, L.stream));
+    HM_CHECK(c, hipStreamSynchronize(L.stream));      // lp is a local
+    L.fewWaves = fewWaves;
   }
   c->epoch++; if (c->epoch == 0) c->epoch = 1;
-  HM_CHECK(c, hipMemsetAsync(c->dSched, 0, 64, c->stream));        // ticket = 0, abort = 0
+  HM_CHECK(c, hipMemsetAsync(L.dSched, 0, 8, L.stream));        // ticket = 0, abort = 0
   if (row0 > 0)    // the row above the band is complete: its CTUs count as published in this run
-    for (int f = 0; f < n; f++) HM_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(c->slots[slot0 + f].fb.done + (size_t)(row0 - 1) * P.wCtu), (int)c->epoch, P.wCtu, c->stream));
-  HM_CHECK(c, hipStreamSynchronize(c->stream));   // fbs / items must stay valid until copied
-  HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
-  const int total = (int)c->items.size();
-  const int grid = total < (int)c->wsCount ? total : (int)c->wsCount;
-  int launches = 1;
-  hipLaunchKernelGGL(hm355_ctu_kernel, dim3(grid), dim3(64), 0, c->stream, (const Params *)c->dP, (const WorkItem *)c->dItems, total, c->dSched, c->epoch);
+    for (int f = 0; f < n; f++) HM_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(c->slots[slot0 + f].fb.done + (size_t)(row0 - 1) * P.wCtu), (int)c->epoch, P.wCtu, L.stream));
+  HM_CHECK(c, hipEventRecord(L.ev0, L.stream));
+  const int total = (int)L.items.size();
+  if (useTeam && teams > 0) {
+    L.grid = teams;
+    hipLaunchKernelGGL(hm355_ctu_team_kernel, dim3(L.grid), dim3(64 * HM_TEAM), 0, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
+  } else {
+    L.grid = total < (int)L.wsCount ? total : (int)L.wsCount;
+    hipLaunchKernelGGL(hm355_ctu_kernel, dim3(L.grid), dim3(64), 0, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
+  }
   HM_CHECK(c, hipGetLastError());
-  HM_CHECK(c, hipEventRecord(c->ev1, c->stream));
-  HM_CHECK(c, hipStreamSynchronize(c->stream));
-  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  unsigned int sched[2] = {0, 0};
-  HM_CHECK(c, hipMemcpy(sched, c->dSched, sizeof(sched), hipMemcpyDeviceToHost));
-  if (sched[1] != 0) return fail(c, HM355_ERR_DEVICE, "scheduler aborted: a dependency wait timed out");
-  c->lastKernelMs = ms; c->lastLaunches = launches;
+  HM_CHECK(c, hipEventRecord(L.ev1, L.stream));
+  L.busy = 1;
   return HM355_OK;
+}
+static int run_wait(hm355_ctx *c, int l, double *kernelMs)
+{
+  Lane &L = c->lane[l];
+  if (!L.busy) return fail(c, HM355_ERR_ARG, "hm355_run_wait: no launch in flight on this lane");
+  L.busy = 0;
+  HM_CHECK(c, hipStreamSynchronize(L.stream));
+  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, L.ev0, L.ev1));
+  unsigned int sched[2] = {0, 0};
+  HM_CHECK(c, hipMemcpy(sched, L.dSched, sizeof(sched), hipMemcpyDeviceToHost));
+  if (sched[1] != 0) return fail(c, HM355_ERR_DEVICE, "scheduler aborted: a dependency wait timed out");
+  c->lastKernelMs = ms; c->lastLaunches = 1;
+  if (kernelMs) *kernelMs = ms;
+  return HM355_OK;
+}
+static int run_rows_impl(hm355_ctx *c, int slot0, int n, const hm355_slice_desc *slices, int row0, int row1)
+{
+  const int rc = run_begin(c, 0, slot0, n, slices, row0, row1);
+  return rc != HM355_OK ? rc : run_wait(c, 0, NULL);
+}
+
+// Pipelined steps: up to HM355_MAX_LANES launches in flight, each over its own slots (declared in include/hm355.h)
+extern "C" int hm355_run_begin(hm355_ctx *c, int lane, int first_slot, int n, const hm355_slice_desc *slices)
+{
+  if (!c || !slices || lane < 0 || lane >= HM_MAX_LANES || n < 1 || first_slot < 0 || first_slot + n > (int)c->slots.size()) return HM355_ERR_ARG;
+  for (int f = 0; f < n; f++) if (c->slots[first_slot + f].fb.imeta) return fail(c, HM355_ERR_ARG, "hm355_run_begin: I slices only");
+  for (int l = 0; l < HM_MAX_LANES; l++)
+    if (l != lane && c->lane[l].busy && c->lane[l].keyValid && first_slot < (int)(c->lane[l].key[0] + c->lane[l].key[1]) && (int)c->lane[l].key[0] < first_slot + n)
+      return fail(c, HM355_ERR_ARG, "hm355_run_begin: the slots overlap a launch in flight on another lane");
+  return run_begin(c, lane, first_slot, n, slices, 0, c->hp.hCtu - 1);
+}
+extern "C" int hm355_run_wait(hm355_ctx *c, int lane, double *kernel_ms)
+{
+  if (!c || lane < 0 || lane >= HM_MAX_LANES) return HM355_ERR_ARG;
+  return run_wait(c, lane, kernel_ms);
 }
 
 extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)
@@ -350,7 +505,7 @@ static int boundary_copy(hm355_ctx *c, int slot, int row, void *buf, int toHost)
   if (!c || !buf || slot < 0 || slot >= (int)c->slots.size() || row < 0 || row >= c->hp.hCtu) return HM355_ERR_ARG;
   const Params &P = c->hp; FrameBuf &fb = c->slots[slot].fb;
   uint8_t *p = (uint8_t *)buf;
-  const hipMemcpyKind kind = toHost ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice;
+  const hipMemcpyKind kind = hipMemcpyDefault;       // buf may be host or device memory (a device buffer goes straight to RCCL)
   for (int k = 0; k < 3; k++) {         // the line right above the next CTU row: all that intra prediction reads across the boundary (TComPattern.cpp:107-165)
     Pel *line = fb.rec[k] + ((size_t)(row + 1) * (k ? 32 : 64) - 1) * P.stride[k];
     const size_t bytes = (size_t)P.stride[k] * sizeof(Pel);

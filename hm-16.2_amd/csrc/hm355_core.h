@@ -77,7 +77,7 @@ static inline int hm_wave_max_i(int v) { return v; }
 #define HM_ASSUME_GLB(p) ((void)0)
 #endif
 #define HM_NT 64
-__device__ __forceinline__ int hm_lane() { return (int)threadIdx.x; }
+__device__ __forceinline__ int hm_lane() { return (int)(threadIdx.x & 63u); }   // a workgroup is one wavefront, or a team of wavefronts (hm355_team.h)
 // one wavefront per CTU: lanes run in lockstep, so a phase boundary only has to order this wave's own LDS /
 // global accesses (wavefront-scope fence) -- no s_barrier and no drain of outstanding stores
 #define HM_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -105,8 +105,8 @@ __device__ __forceinline__ int hm_wave_max_i(int v)
 #define HM_UNI(x) __builtin_amdgcn_readfirstlane((int)(x))
 // Arguments and results of non-inlined device functions travel in VGPRs and count as divergent for the compiler.
 // Every such function re-states at its entry that they are wave-uniform (one v_readfirstlane per dword), so that
-// the decision logic compiles to scalar (SALU / s_cbranch) code; HM_ENTRY re-derives the LDS state pointer from the
-// workgroup's one static instance for the same reason.
+// the decision logic compiles to scalar (SALU / s_cbranch) code; HM_ENTRY does the same for the pointer to the wavefront's LDS state
+// (a workgroup holds one such state, or one per wavefront of a team: hm355_team.h).
 template <class T> __device__ __forceinline__ T *hm_uni_ptr(T *p)
 {
   const unsigned long long v = (unsigned long long)p;
@@ -123,7 +123,7 @@ template <class T> __device__ __forceinline__ T hm_uni_struct(T v)
   __builtin_memcpy(&v, w, sizeof(T));
   return v;
 }
-#define HM_ENTRY(e) ((e) = &g_sh)
+#define HM_ENTRY(e) do { (e) = hm_uni_ptr(e); HM_ASSUME_LDS(e); } while (0)
 #define HM_UCALL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #define HM_PAR_FOR(i, n) for (int i = hm_lane(); i < (n); i += HM_NT)
 // lane-parallel loop over the first n samples of a rectangle of width w in raster order, with the (x, y) of a lane's sample kept
@@ -323,6 +323,7 @@ struct RefLds {
 // slot index: CI_CURR_BEST / CI_NEXT_BEST are never addressed at depth 4
 #define HM_SLOT(d, ci) ((d) * CI_NUM + (ci) - ((d) == 4 ? 2 : 0))
 #define HM_NUM_SLOTS (4 * CI_NUM + 3)
+struct Team;                           // hm355_team.h: the wavefronts of one workgroup searching one CTU together (latency mode)
 struct Shared {
   Cabac cur;                           // m_pcRDGoOnSbacCoder
   int8_t tmat[32 * HM_TSTRIDE];        // 32-point transform matrix, padded rows
@@ -365,6 +366,7 @@ struct Shared {
   int32_t width, height, bitDepth, wCtu, stride[3];
   const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
   CtuMeta meta;                        // decision arrays of the CTU under search (written back to HBM at the end)
+  Team *team;                          // the team this wavefront belongs to (0: it searches its CTU alone)
   TCoeff *cc;
   int32_t ctuX, ctuY, ctuAddr;
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
@@ -395,7 +397,7 @@ __device__ inline void hm_trace(Shared *e, int tag, uint32_t a, uint32_t b, doub
 __shared__ Shared g_sh;                // the one CTU search of this workgroup (HM_ENTRY)
 #endif
 #if !defined(HM355_PROFILE)
-static_assert(sizeof(Shared) + 16 <= 14848, "Shared (+ the kernel's work item) must stay within 1/11 of a CU's 160 KB LDS in 512-byte granules (11 CTU searches per CU)");
+static_assert(sizeof(Shared) + 16 <= 14848 && sizeof(Shared) % 8 == 0, "Shared (+ the kernel's work item) must stay within 1/11 of a CU's 160 KB LDS in 512-byte granules (11 CTU searches per CU)");
 #endif
 static_assert(offsetof(Shared, bufA) % 8 == 0 && (16 * HM_TSTRIDE * 4) % 8 == 0, "the RDOQ cost array aliases the lower half of bufA as doubles");
 
@@ -2421,10 +2423,10 @@ HM_DEV HM_NOINLINE void save_best(Shared *e, int cuZ, int cuDepth)
   HM_SYNC();
   HM_PROF_END(e, PR_SAVE);
 }
-HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
+HM_DEV HM_NOINLINE void restore_best_from(Shared *e, const Best *b, int cuZ, int cuDepth)
 {
-  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
-  const Best *b = &e->ws->best[cuDepth]; const int parts = 256 >> (2 * cuDepth);
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); b = hm_uni_ptr(b); HM_ASSUME_GLB(b); // TComDataCU::copyToPic + TEncCu::xCopyYuv2Pic of the unsplit winner
+  const int parts = 256 >> (2 * cuDepth);
   meta_copy_range((&e->meta), &b->m, cuZ, parts);
   if (e->im) imeta_copy_range(e->im, &b->im, cuZ, parts);
   HM_PAR_FOR(i, parts * 16) e->cc[cuZ * 16 + i] = b->coef[cuZ * 16 + i];
@@ -2440,6 +2442,7 @@ HM_DEV HM_NOINLINE void restore_best(Shared *e, int cuZ, int cuDepth)
   }
   HM_SYNC();
 }
+HM_DEV inline void restore_best(Shared *e, int cuZ, int cuDepth) { restore_best_from(e, &e->ws->best[cuDepth], cuZ, cuDepth); }
 
 // xCheckRDCostIntra, TEncCu.cpp:1574-1646; leaves the trial in place
 HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int partSize)
@@ -2606,10 +2609,13 @@ template <class C> HM_DEV HM_NOINLINE void encode_ctu(Shared *e, C *c, int lastC
 // ------------------------------------------------------------------------------------------------
 // one CTU of TEncSlice::compressSlice (TEncSlice.cpp:724-892)
 // ------------------------------------------------------------------------------------------------
-HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, int wsIndex)
+#if !defined(HM355_HOSTSIM)
+#include "hm355_team.h"
+#endif
+HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, int wsIndex, Team *team = 0)
 {
   // uniform context (every lane writes the same values)
-  e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab;
+  e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab; e->team = team;
   e->width = P->width; e->height = P->height; e->bitDepth = P->bitDepth; e->wCtu = P->wCtu; e->mpmZ = -1; e->s8Reuse = 0;
   for (int c = 0; c < 3; c++) e->stride[c] = P->stride[c];
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
@@ -2654,6 +2660,9 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     }
   } else cabac_copy(cb0, e->fb.endState + (a - 1));
   cabac_copy(&e->cur, cb0);
+#if !defined(HM355_HOSTSIM)
+  if (team) compress_ctu_team(e); else
+#endif
   compress_ctu(e);
   e->fb.stat[a].cost = e->outCost; e->fb.stat[a].bits = e->outBits; e->fb.stat[a].dist = e->outDist;
   // TEncCu::encodeCtu on m_pppcRDSbacCoder[0][CI_CURR_BEST] (the search never writes that snapshot), TEncSlice.cpp:818-825:

@@ -1,0 +1,261 @@
+// hm355 -- a team of wavefronts searching ONE CTU (latency mode of the CTU search).
+//
+// TEncCu::xCompressCU evaluates the unsplit CU at depth d and then the four sub-CUs at depth d + 1; both start from the same CABAC
+// snapshot ([d][CI_CURR_BEST], TEncCu.cpp:1007-1014 vs :636-798) and read nothing the other one writes: inside the CU each reads only
+// what it has reconstructed itself, outside the CU both read the finished neighbours.  The same holds for the two part sizes of the
+// smallest CU (2Nx2N and NxN, TEncCu.cpp:706-735).  A workgroup of HM_TEAM wavefronts uses that:
+//   * the MAIN wavefront (wave 0) runs the reference's recursion, but hands the unsplit candidate of every depth to a HELPER
+//     wavefront (wave 1 + d: the 2Nx2N CU of depth d = 0, 1, 2; wave 4: the 2Nx2N candidate of an 8x8 CU) and goes straight on into
+//     the sub-CUs (the NxN candidate at depth 3); it collects the helper's result where the reference compares the two
+//     (xCheckBestMode, TEncCu.cpp:1702) -- same operands, same strict "<", same order, so the decision is the reference's;
+//   * a helper works on private copies of everything the candidate writes: its own LDS state (Shared), HBM workspace, coefficient
+//     area and a window of the reconstruction (the CTU plus the sample row above and the column left of it, same addressing as the
+//     picture), filled from the picture when the request arrives.  The main wavefront only writes inside the CU while the helper
+//     is busy, the helper only reads outside it before it has written there itself: no hand-shake beyond request / done;
+//   * the winner's decision arrays, coefficients, reconstruction and CABAC state are taken from the helper's workspace where the
+//     reference copies them from its "best" buffers (TComDataCU::copyToPic, TEncCu::xCopyYuv2Pic, TEncCu.cpp:1087-1110).
+// The exact work skipping of the one-wavefront search (hm355_core.h, compress_ctu) needs the unsplit cost before the sub-CUs
+// start; here it is applied whenever the helper happens to have answered already -- it never changes a result, so the answer's
+// timing does not matter.
+// I slices.  The wavefronts of a team share one CU, so the request / done words live in LDS and workgroup-scope fences order the
+// HBM traffic between them.
+#pragma once
+
+#define HM_TEAM 5
+#define HM_TEAM_HELPERS (HM_TEAM - 1)
+#define HM_TEAM_TIMEOUT_TICKS (20ull * 100000000ull)   /* 20 s of the 100 MHz wall clock: a team member that never answers abandons the launch */
+
+struct TeamBox {                       // mailbox of one helper
+  uint32_t reqSeq, doneSeq;            // main: arguments, release, reqSeq + 1;  helper: results, release, doneSeq = reqSeq
+  int32_t cuZ, depth, part, pad;
+  uint32_t bits, dist; double cost;    // the candidate as xCheckBestMode sees it (split flag of the unsplit CU included)
+};
+struct Team {
+  Shared sh[HM_TEAM];                  // [0] the main wavefront, [1 + h] helper h
+  TeamBox box[HM_TEAM_HELPERS];
+  uint32_t quit, dead;                 // quit: the launch is over; dead: a wait timed out, results are void (the host sees the abort word)
+  unsigned int *abortWord;
+  WorkItem item;
+};
+
+__device__ __forceinline__ uint32_t team_ld(const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
+__device__ __forceinline__ void team_st(uint32_t *p, uint32_t v) { if (hm_lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define HM_TEAM_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define HM_TEAM_ACQUIRE() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
+// ---- main wavefront ----
+HM_DEV inline void team_post(Shared *e, int h, int cuZ, int depth, int part)
+{
+  TeamBox *b = &e->team->box[h];
+  if (hm_lane() == 0) { b->cuZ = cuZ; b->depth = depth; b->part = part; }
+  const uint32_t seq = team_ld(&b->reqSeq) + 1u;
+  HM_TEAM_RELEASE();
+  team_st(&b->reqSeq, seq);
+}
+HM_DEV inline int team_ready(Shared *e, int h)
+{
+  TeamBox *b = &e->team->box[h];
+  if (team_ld(&b->doneSeq) != team_ld(&b->reqSeq)) return 0;
+  HM_TEAM_ACQUIRE();
+  return 1;
+}
+HM_DEV HM_NOINLINE void team_wait(Shared *e, int h)
+{
+  HM_ENTRY(e); h = HM_UNI(h);
+  Team *T = e->team; TeamBox *b = &T->box[h];
+  const uint32_t want = team_ld(&b->reqSeq);
+  const unsigned long long t0 = wall_clock64();
+  while (team_ld(&b->doneSeq) != want) {
+    __builtin_amdgcn_s_sleep(2);
+    if (team_ld(&T->dead)) break;
+    if (wall_clock64() - t0 > HM_TEAM_TIMEOUT_TICKS) {
+      team_st(&T->dead, 1u);
+      if (hm_lane() == 0) __hip_atomic_store((__attribute__((address_space(1))) unsigned int *)T->abortWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+  HM_TEAM_ACQUIRE();
+}
+HM_DEV inline WorkSpace *team_helper_ws(Shared *e, int h) { return e->ws + 1 + h; }      // the workspaces of a team lie side by side, the main wavefront's first
+
+// what the reference's xCheckBestMode does when the unsplit candidate is the best mode: results of the helper become the CU's
+HM_DEV inline void team_take_unsplit(Shared *e, int h, int cuZ, int cuDepth)
+{
+  WorkSpace *hw = team_helper_ws(e, h);
+  restore_best_from(e, &hw->best[cuDepth], cuZ, cuDepth);
+  cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &hw->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)]);
+}
+
+// TEncCu::compressCtu -> xCompressCU for an I slice, the unsplit candidates evaluated by the helpers (see the head of this file)
+HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
+{
+  HM_ENTRY(e);
+  CtuMeta *m = (&e->meta);
+  CuFrame *fr = e->cuf; int sp = 0;
+  fr[0].cuZ = 0; fr[0].phase = 0; fr[0].parentPart = SIZE_NONE;
+  double retCost = 0; uint32_t retBits = 0, retDist = 0;
+  int pending[4] = {0, 0, 0, 0};       // the unsplit candidate of this depth is with its helper
+  while (sp >= 0) {
+    CuFrame *f = &fr[sp]; const int cuDepth = sp, cuZ = f->cuZ;
+    const int size = 64 >> cuDepth, parts = 256 >> (2 * cuDepth), q = parts >> 2;
+    if (f->phase == 0) {
+      const int r = hm_z2r(cuZ);
+      const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
+      f->boundary = !((lx + size - 1 < e->width) && (ty + size - 1 < e->height));
+      f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
+      pending[cuDepth] = 0;
+      if (!f->boundary) {
+        team_post(e, cuDepth, cuZ, cuDepth, SIZE_2Nx2N);
+        pending[cuDepth] = 1;
+        if (cuDepth == 3) {
+          // the helper has the 2Nx2N candidate; the NxN one runs here.  xCheckBestMode sees 2Nx2N first, NxN has to be strictly cheaper.
+          check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN);
+          const double cN = e->outCost; const uint32_t bN = e->outBits, dN = e->outDist;
+          team_wait(e, 3); pending[3] = 0;
+          const TeamBox *b = &e->team->box[3];
+          f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
+          if (cN < f->bestCost) {
+            f->bestCost = cN; f->bestBits = bN; f->bestDist = dN;
+            save_best(e, cuZ, cuDepth);
+            cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]);
+            restore_best(e, cuZ, cuDepth);
+          } else team_take_unsplit(e, 3, cuZ, cuDepth);
+          reset_bits(&e->cur);           // TEncCu.cpp:859-863 at the smallest CU size: no split flag, the bit counter is reset all the same
+          f->bestCost = calc_rd_cost(e, f->bestBits, f->bestDist);
+          retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
+        }
+      }
+      init_est_data(e, cuZ, cuDepth);
+      f->splitBits = 0; f->splitDist = 0; f->sub = 0; f->phase = 1;
+    }
+    if (f->phase == 1) {
+      if (f->sub < 4) {
+        const int s = f->sub++;
+        const int subZ = cuZ + s * q, r = hm_z2r(subZ);
+        const int sx = e->ctuX * 64 + (r & 15) * 4, sy = e->ctuY * 64 + (r >> 4) * 4;
+        HM_PAR_FOR(i, q) { m->depth[subZ + i] = (uint8_t)(cuDepth + 1); m->part[subZ + i] = SIZE_NONE; m->pred[subZ + i] = MODE_NONE; }
+        HM_SYNC();
+        if (sx < e->width && sy < e->height) {
+          if (s == 0) cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+          else cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
+          fr[sp + 1].cuZ = (int16_t)subZ; fr[sp + 1].phase = 0; fr[sp + 1].parentPart = SIZE_NONE;
+          f->phase = 2; sp++; continue;
+        }
+        continue;
+      }
+      if (!f->boundary) {
+        reset_bits(&e->cur);
+        enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), m->depth[cuZ] > cuDepth);
+        f->splitBits += num_bits(&e->cur);
+      }
+      f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
+      cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
+      if (pending[cuDepth]) {
+        team_wait(e, cuDepth); pending[cuDepth] = 0;
+        const TeamBox *b = &e->team->box[cuDepth];
+        f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
+      }
+      if (f->splitCost < f->bestCost) {
+        f->bestCost = f->splitCost; f->bestBits = f->splitBits; f->bestDist = f->splitDist;
+        cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]);
+      } else team_take_unsplit(e, cuDepth, cuZ, cuDepth);
+      retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
+    }
+    if (f->phase == 2) { // a sub-CU returned
+      f->splitBits += retBits; f->splitDist += retDist; f->phase = 1;
+      // the exact early stop of compress_ctu (same conditions), applied when the unsplit result is already there
+      if (pending[cuDepth] && team_ready(e, cuDepth)) {
+        pending[cuDepth] = 0;
+        const TeamBox *b = &e->team->box[cuDepth];
+        f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
+      }
+      bool laterSibling = sp == 0;
+      if (sp > 0) {
+        const int pq = parts, pz = fr[sp - 1].cuZ;
+        for (int s2 = fr[sp - 1].sub; s2 < 4; s2++) {
+          const int r2 = hm_z2r(pz + s2 * pq);
+          laterSibling |= (e->ctuX * 64 + (r2 & 15) * 4 < e->width) && (e->ctuY * 64 + (r2 >> 4) * 4 < e->height);
+        }
+      }
+      if (!pending[cuDepth] && f->sub < 4 && laterSibling && !f->boundary && !(calc_rd_cost(e, f->splitBits, f->splitDist) < f->bestCost)) {
+        team_take_unsplit(e, cuDepth, cuZ, cuDepth);
+        retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--;
+      }
+      continue;
+    }
+  }
+  e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
+}
+
+// ---- helper wavefront h (1-based wave index h + 1) ----
+// the uniform per-CTU context of the main wavefront, with private places for everything a candidate writes
+HM_DEV inline void team_adopt(Shared *e, const Shared *mainSh, int h, Pel *win)
+{
+  e->P = mainSh->P; e->fb = mainSh->fb; e->tab = mainSh->tab; e->team = mainSh->team;
+  e->width = mainSh->width; e->height = mainSh->height; e->bitDepth = mainSh->bitDepth; e->wCtu = mainSh->wCtu;
+  for (int c = 0; c < 3; c++) e->stride[c] = mainSh->stride[c];
+  e->ctuX = mainSh->ctuX; e->ctuY = mainSh->ctuY; e->ctuAddr = mainSh->ctuAddr;
+  e->ws = mainSh->ws + 1 + h; e->cc = e->ws->teamCoef; e->im = (InterMeta *)0; e->mpmZ = -1; e->s8Reuse = 0;
+  // the window: rows [ctuY * S - 1, ctuY * S + S) of a plane with the picture's stride, addressed like the picture
+  Pel *w = win;
+  for (int c = 0; c < 3; c++) {
+    const int S = c ? 32 : 64;
+    e->fb.rec[c] = w - ((long long)e->ctuY * S - 1) * e->stride[c];
+    w += (size_t)(S + 1) * e->stride[c];
+  }
+  HM_SYNC();
+}
+HM_DEV inline void team_fill_window(Shared *e, const Shared *mainSh)
+{ // everything a CU of this CTU can read outside itself (TComPattern.cpp:107-165): the row above up to 2 CTU widths, the column to the left, the CTU
+  for (int c = 0; c < 3; c++) {
+    const int S = c ? 32 : 64, ps = e->stride[c];
+    const int x0 = e->ctuX * S > 0 ? e->ctuX * S - 1 : 0, x1 = (e->ctuX + 2) * S < ps ? (e->ctuX + 2) * S : ps;
+    const int y0 = e->ctuY > 0 ? e->ctuY * S - 1 : 0, y1 = (e->ctuY + 1) * S, w = x1 - x0;
+    const Pel *src = mainSh->fb.rec[c]; Pel *dst = e->fb.rec[c];
+    HM_PAR_FOR_XY(x, y, w, w * (y1 - y0)) dst[(size_t)(y0 + y) * ps + x0 + x] = src[(size_t)(y0 + y) * ps + x0 + x];
+  }
+  HM_SYNC();
+}
+HM_DEV inline void team_helper(Team *T, int h, Pel *win)
+{
+  Shared *e = &T->sh[1 + h]; const Shared *mainSh = &T->sh[0];
+  TeamBox *b = &T->box[h];
+  load_tmat(e);
+  HM_PAR_FOR(i, 128) e->ebits[i] = HM_ENTROPY_BITS[i];
+  HM_SYNC();
+  uint32_t seen = 0;
+  for (;;) {
+    uint32_t s;
+    for (;;) {
+      s = team_ld(&b->reqSeq);
+      if (s != seen) break;
+      if (team_ld(&T->quit)) return;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    HM_TEAM_ACQUIRE();
+    seen = s;
+    const int cuZ = HM_UNI(b->cuZ), cuDepth = HM_UNI(b->depth), part = HM_UNI(b->part);
+    team_adopt(e, mainSh, h, win);
+    { // the decision arrays as the main wavefront holds them: everything outside the CU is final (inside, init_est_data starts afresh)
+      const uint32_t *src = (const uint32_t *)&mainSh->meta; uint32_t *dst = (uint32_t *)&e->meta;
+      HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];
+      HM_SYNC();
+    }
+    team_fill_window(e, mainSh);
+    cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)], &mainSh->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+    // xCheckRDCostIntra + xCheckBestMode against an empty best (TEncCu.cpp:706-735, :1574, :1702)
+    check_rd_cost_intra(e, cuZ, cuDepth, part);
+    double c = e->outCost; uint32_t bits = e->outBits; const uint32_t dist = e->outDist;
+    save_best(e, cuZ, cuDepth);
+    cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]);
+    if (cuDepth != 3) { // split flag of the unsplit candidate, TEncCu.cpp:859-863 (coded on the go-on coder as the candidate left it)
+      reset_bits(&e->cur);
+      enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
+      bits += num_bits(&e->cur);
+      c = calc_rd_cost(e, bits, dist);
+    }
+    if (hm_lane() == 0) { b->cost = c; b->bits = bits; b->dist = dist; }
+    HM_TEAM_RELEASE();
+    team_st(&b->doneSeq, s);
+  }
+}

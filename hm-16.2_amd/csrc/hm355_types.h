@@ -90,6 +90,7 @@ struct WorkSpace {
   } ps;
   struct { MvD mv[5][2]; int32_t ref[5][2]; uint8_t dir[5]; int32_t num; } mrg2N;   // merge list of xCheckRDCostMerge2Nx2N (outlives the per-PU list in LDS)
   uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
+  TCoeff teamCoef[HM_COEF_CTU];      // a team helper's private coefficient area (the team's main wavefront works in the picture's own, hm355_team.h)
 };
 
 // lookup tables generated on the host at create time (scan orders: TComRom.cpp:52-225)
@@ -125,6 +126,8 @@ struct Params {
   FrameBuf *frames;
   unsigned long long *prof;          // diagnostic builds only (HM355_PROFILE), else NULL
   int32_t fewWaves;                  // the launch cannot fill the device: prefer the shortest dependency chain over the fewest instructions
+  Pel *teamWin;                      // team launches: the helpers' private reconstruction windows, HM_TEAM_HELPERS per team (hm355_team.h)
+  uint64_t teamWinStride;            // samples per helper window
 };
 
 struct WorkItem { int32_t frame, ctuX, ctuY, pad; };

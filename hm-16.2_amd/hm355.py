@@ -76,11 +76,11 @@ class BitsDesc(C.Structure):
                 ("next_cabac_init_type", C.c_int32), ("num_bins", C.c_uint32)]
 
 
-EXPORTS = ["hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
+EXPORTS = ["hm355_build_id", "hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
            "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_sao_run",
            "hm355_num_substreams", "hm355_encode_slices_run", "hm355_encode_slice",
            "hm355_upload_file_frames", "hm355_download_file_frames", "hm355_download_org",
-           "hm355_upload", "hm355_run", "hm355_run_rows", "hm355_boundary_bytes", "hm355_export_boundary", "hm355_import_boundary", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
+           "hm355_upload", "hm355_run", "hm355_run_begin", "hm355_run_wait", "hm355_run_rows", "hm355_boundary_bytes", "hm355_export_boundary", "hm355_import_boundary", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
            "hm355_transform_batch"]
 
 
@@ -91,12 +91,15 @@ def load_library(path=LIB_PATH):
     lib = C.CDLL(path)
     for name in EXPORTS:
         getattr(lib, name)
+    lib.hm355_build_id.restype = C.c_char_p
     lib.hm355_create.argtypes = [C.POINTER(SeqCfg), C.POINTER(C.c_void_p)]
     lib.hm355_destroy.argtypes = [C.c_void_p]
     lib.hm355_last_error.argtypes = [C.c_void_p]
     lib.hm355_last_error.restype = C.c_char_p
     lib.hm355_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes)]
     lib.hm355_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SliceDesc)]
+    lib.hm355_run_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SliceDesc)]
+    lib.hm355_run_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     lib.hm355_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes), C.c_void_p, C.POINTER(SliceStats)]
     lib.hm355_run_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(SliceDesc), C.c_int, C.c_int]
     lib.hm355_boundary_bytes.argtypes = [C.c_void_p]
@@ -189,6 +192,18 @@ class Encoder:
         self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
         return ms.value, launches.value
 
+    def run_begin(self, lane, first_slot, n, qp):
+        """enqueue the search over slots [first_slot, first_slot + n) on pipeline lane `lane`; returns at once (hm355_run_begin)"""
+        lam, cw = intra_lambda(qp)
+        sl = (SliceDesc * n)(*[SliceDesc(2, qp, lam, cw) for _ in range(n)])
+        self._check(self.lib.hm355_run_begin(self.h_, lane, first_slot, n, sl), "hm355_run_begin")
+
+    def run_wait(self, lane):
+        """wait for the launch of `lane`; returns its kernel time in ms (hm355_run_wait)"""
+        ms = C.c_double()
+        self._check(self.lib.hm355_run_wait(self.h_, lane, C.byref(ms)), "hm355_run_wait")
+        return ms.value
+
     def run_rows(self, first_slot, n, qp, first_row, last_row):
         """the search over CTU rows [first_row, last_row] of the pictures in slots [first_slot, first_slot + n) (a band; see hm355_run_rows)"""
         lam, cw = intra_lambda(qp)
@@ -211,6 +226,13 @@ class Encoder:
         buf = np.ascontiguousarray(data, np.uint8)
         assert buf.size == self.boundary_bytes()
         self._check(self.lib.hm355_import_boundary(self.h_, slot, row, buf.ctypes.data), "hm355_import_boundary")
+
+    def export_boundary_ptr(self, slot, row, ptr):
+        """the same into boundary_bytes() bytes at address `ptr` -- host or device memory"""
+        self._check(self.lib.hm355_export_boundary(self.h_, slot, row, C.c_void_p(ptr)), "hm355_export_boundary")
+
+    def import_boundary_ptr(self, slot, row, ptr):
+        self._check(self.lib.hm355_import_boundary(self.h_, slot, row, C.c_void_p(ptr)), "hm355_import_boundary")
 
     def download(self, slot, want_ctus=True):
         rec = [np.zeros((self.h, self.w), np.uint16), np.zeros((self.h // 2, self.w // 2), np.uint16),

@@ -25,9 +25,10 @@ extern "C" {
 #define HM355_ERR_NOMEM       -3
 #define HM355_ERR_DEVICE      -4   /* a HIP call or a kernel failed */
 
-/* Sequence-level parameters: the SPS/PPS/TEncCfg getters compressSlice reads
- * (TEncCfg.h; cfg/encoder_intra_main.cfg, cfg/encoder_intra_main10.cfg).  Values other than the
- * ones of those cfg files are rejected with HM355_ERR_ARG rather than silently ignored. */
+/* Sequence-level parameters: the SPS/PPS/TEncCfg getters compressSlice reads (TEncCfg.h).  The block structure is the one every cfg
+ * file of the reference uses (cfg/encoder_intra_main*.cfg, encoder_lowdelay_P_main.cfg, encoder_lowdelay_main.cfg,
+ * encoder_randomaccess_main*.cfg: CTU 64, depth 4, TU 4..32, RQT depth 3); other values are rejected with HM355_ERR_ARG rather than
+ * silently ignored.  I, P and B slices are all accepted (the slice type is a per-call parameter). */
 typedef struct {
   int32_t width, height;          /* SourceWidth/Height, multiples of 8 (min CU) */
   int32_t bit_depth;              /* InternalBitDepth 8 or 10 (luma == chroma) */
@@ -78,6 +79,8 @@ typedef struct hm355_ctx hm355_ctx;
 int  hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out);
 void hm355_destroy(hm355_ctx *ctx);
 const char *hm355_last_error(const hm355_ctx *ctx);
+/* identifies the kernel source this library was built from (hash of hm-16.2_amd/csrc + this header): measurement records carry it */
+const char *hm355_build_id(void);
 
 /* Replacement of TEncSlice::compressSlice for one picture (host buffers in, host buffers out).
  *   org  : TComPic::getPicYuvOrg()          rec : TComPic::getPicYuvRec() (pre-deblocking)
@@ -203,6 +206,13 @@ int hm355_download_org(hm355_ctx *ctx, int slot, hm355_planes *org);
 int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */
 int hm355_run(hm355_ctx *ctx, int n, const hm355_slice_desc *slices);         /* slots [0,n) -> results in HBM; blocking */
 int hm355_download(hm355_ctx *ctx, int slot, hm355_planes *rec, hm355_ctu_out *ctus, hm355_slice_stats *stats);
+/* Pipelined steps (the calling pattern of TEncGOP::compressGOP -> compressSlice, TEncGOP.cpp:1138, for a caller that keeps several groups
+ * of independent pictures in flight): hm355_run_begin enqueues the search over slots [first_slot, first_slot + n) on pipeline lane
+ * `lane` (0..3) and returns; hm355_run_wait blocks until that lane's launch has finished and reports its kernel time (HIP events on the
+ * lane's stream) and errors.  Launches of different lanes run concurrently, each with its own stream and scratch areas, so the
+ * wavefront drain of one group overlaps the fill of the next; slot ranges of launches in flight must not overlap.  I slices. */
+int hm355_run_begin(hm355_ctx *ctx, int lane, int first_slot, int n, const hm355_slice_desc *slices);
+int hm355_run_wait(hm355_ctx *ctx, int lane, double *kernel_ms);
 
 /* CTU-row bands (TEncSlice.cpp:740-755,855-858 are the WPP hand-off points a band boundary cuts through): a picture is
  * searched by several devices, each owning a band of whole CTU rows [first_row, last_row] of the pictures in slots
@@ -211,7 +221,8 @@ int hm355_download(hm355_ctx *ctx, int slot, hm355_planes *rec, hm355_ctu_out *c
  * hm355_export_boundary copies out what the band below reads from CTU row `row`: the bottom sample line of the three planes (intra
  * reference samples, TComPattern.cpp:107-165), the CTUs' decision arrays (split-flag contexts, TComDataCU.cpp:1587) and the CABAC
  * state after each CTU (the WPP synchronisation source, TEncSlice.cpp:855-858); hm355_boundary_bytes() bytes per picture.  The buffers
- * are host memory: the transport between devices (RCCL send / recv in bench.py and hm-16.2_amd/bands.py) is the caller's. */
+ * may be host or device memory (the copies are address-space agnostic): a device buffer is handed to RCCL send / recv as it is, so a
+ * boundary row never touches the host (bench.py --shard rows, hm-16.2_amd/bands.py).  The transport between devices is the caller's. */
 int hm355_run_rows(hm355_ctx *ctx, int first_slot, int n, const hm355_slice_desc *slices, int first_row, int last_row);
 size_t hm355_boundary_bytes(const hm355_ctx *ctx);
 int hm355_export_boundary(hm355_ctx *ctx, int slot, int row, void *buf);

@@ -210,3 +210,47 @@ def load_yuvio_case(name):
         c["planes"].append([p[:w * h].reshape(h, w), p[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), p[w * h * 5 // 4:].reshape(h // 2, w // 2)])
     c["width"], c["height"] = w, h
     return c
+
+
+# ---- full-size pins (tests/gen_golden_full.py): digests of what the reference left, compared CTU by CTU ----
+FULL_CASES = ["full_c4_3840x2160_10b_wpp_qp32", "full_c2_1920x1080_10b_qp32", "full_c3_ldp_1920x1080_8b_wpp_qp32", "full_c5_ra_3840x2160_10b_wpp_qp32"]
+_DIGEST_CTU = ("total_cost", "total_bits", "total_dist", "depth", "part_size", "pred_mode", "intra_dir_luma", "intra_dir_chroma", "tr_idx", "cbf", "tskip",
+               "coeff_y", "coeff_cb", "coeff_cr")
+_DIGEST_INTER = ("skip", "merge_flag", "merge_idx", "inter_dir", "mv", "mvd", "ref_idx", "mvp_idx", "mvp_num")
+
+
+def ctu_digests(ctus, ictus=None):
+    """(n, 20) uint8: SHA-1 per CTU over its decision arrays, costs and coefficients (C-ABI layout, fixed field order), and its motion
+    data when `ictus` is given"""
+    import hashlib
+    out = np.zeros((len(ctus), 20), np.uint8)
+    for a in range(len(ctus)):
+        h = hashlib.sha1()
+        for f in _DIGEST_CTU:
+            h.update(np.ascontiguousarray(ctus[f][a]).tobytes())
+        if ictus is not None:
+            for f in _DIGEST_INTER:
+                h.update(np.ascontiguousarray(ictus[f][a]).tobytes())
+        out[a] = np.frombuffer(h.digest(), np.uint8)
+    return out
+
+
+def md5_of(arr):
+    import hashlib
+    return np.frombuffer(hashlib.md5(np.ascontiguousarray(arr).tobytes()).digest(), np.uint8).copy()
+
+
+def load_full_case(name):
+    """-> (cfg, [picture dict in coding order]) of a full-size pin; every picture: the slice parameters compressSlice saw, per-CTU digests,
+    MD5s of the pre-deblocking and the finished planes, SAO flags + digest, per-substream MD5s"""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = {k: int(g[k]) for k in ("width", "height", "bit_depth", "frames", "seed", "wpp", "pictures")}
+    pics = []
+    for i in range(cfg["pictures"]):
+        p = {k: g[f"p{i}_{k}"][()] for k in _S_KEYS}
+        for k in ("num_ref_idx", "ref_poc", "ref_long_term", "ctu_sha1", "rec_md5", "final_md5", "sao_enabled", "sao_md5", "sao_depth", "sub_sizes", "sub_md5",
+                  "next_cabac_init_type", "num_bins"):
+            p[k] = g[f"p{i}_{k}"]
+        p["num_ref_idx"] = tuple(int(v) for v in p["num_ref_idx"])
+        pics.append(p)
+    return cfg, pics

@@ -404,6 +404,55 @@ def test_hip_batch_equals_single(hm):
     enc.close()
 
 
+def test_hip_pipelined_lanes_equal_blocking_run(hm):
+    """hm355_run_begin / hm355_run_wait: four groups of pictures searched by four launches in flight at once (each lane its own stream,
+    scratch areas, work list and scheduler words) equal the same pictures through the blocking hm355_run; a lane can be reused after
+    its wait, a busy lane and overlapping slots are refused."""
+    w, h, bd, qp, per = 192, 128, 10, 30, 3
+    planes = [synth.frame(w, h, bd, i % 5, 31) for i in range(4 * per)]
+    enc = hm.Encoder(w, h, bd, 1, max_batch=4 * per)
+    want = enc.compress(planes, qp)
+    for rep in range(2):                                    # the second round reuses every lane's cached work list
+        for i, p in enumerate(planes):
+            enc.upload(i, planes[(i + rep) % len(planes)])
+        for lane in range(4):
+            enc.run_begin(lane, lane * per, per, qp)
+        with pytest.raises(RuntimeError):
+            enc.run_begin(1, per, per, qp)                  # lane 1 is busy
+        assert all(enc.run_wait(lane) > 0 for lane in (2, 0, 3, 1))
+        with pytest.raises(RuntimeError):
+            enc.run_wait(0)                                 # nothing in flight
+        for i in range(4 * per):
+            rec, ctus, _ = enc.download(i)
+            common.assert_ctus_equal(ctus, want[(i + rep) % len(planes)][1], f"round {rep} slot {i}")
+            for k in range(3):
+                assert np.array_equal(rec[k], want[(i + rep) % len(planes)][0][k])
+    enc.run_begin(0, 0, 2 * per, qp)
+    with pytest.raises(RuntimeError):
+        enc.run_begin(1, per, per, qp)                      # slots overlap the launch in flight on lane 0
+    enc.run_wait(0)
+    enc.close()
+
+
+@pytest.mark.parametrize("w,h,bd,qp,wpp,seed", [(256, 192, 10, 32, 1, 41), (200, 136, 8, 26, 0, 42), (448, 256, 8, 38, 1, 43)])
+def test_hip_team_search_equals_single_wavefront_search(hm, monkeypatch, w, h, bd, qp, wpp, seed):
+    """hm355_team.h: a CTU searched by a team of wavefronts (the unsplit candidate of every CU depth and the 2Nx2N candidate of the 8x8 CUs
+    on helper wavefronts) gives what one wavefront gives -- decisions, coefficients, costs, reconstruction, CABAC hand-off (several
+    pictures, partial CTUs at the right / bottom edge, with and without WaveFrontSynchro)."""
+    planes = [synth.frame(w, h, bd, i, seed) for i in range(3)]
+    enc = hm.Encoder(w, h, bd, wpp, max_batch=3)
+    monkeypatch.setenv("HM355_TEAM", "0")
+    one = enc.compress(planes, qp)
+    monkeypatch.setenv("HM355_TEAM", "1")
+    team = enc.compress(planes, qp)
+    for i in range(3):
+        common.assert_ctus_equal(team[i][1], one[i][1], f"picture {i}")
+        for k in range(3):
+            assert np.array_equal(team[i][0][k], one[i][0][k])
+        assert team[i][2] == one[i][2]
+    enc.close()
+
+
 def test_hip_large_batch_code_path_equals_small_batch(hm):
     """A launch that can fill the device takes the fewest-instructions code path (Params::fewWaves == 0), a small one the shortest
     dependency chain; both must give the same result: 96 pictures in one batch == the same pictures in batches of 3."""
@@ -485,6 +534,31 @@ def test_hip_row_bands_match_unsplit_picture(hm, name, world, copies, group):
             return a
         bands.run_banded(enc, len(pics), group, h_ctu, r, world, send, recv, qp)      # rank r only needs ranks < r: one after the other
     assert all(not v for v in wire.values())
+    if world == 2:
+        # the same hand-off with the boundary rows staying on the device (what bench.py --shard rows gives RCCL): rank 1 again, importing
+        # from a device buffer that rank 0 exported into
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so.7")               # the HIP runtime the library itself runs on: a plain device allocation
+        nb = encs[0].boundary_bytes()
+        first1 = bands.band_rows(h_ctu, world, 1)[0]
+        dev = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dev), ctypes.c_size_t(len(pics) * nb)) == 0
+        for i in range(len(pics)):
+            encs[0].export_boundary_ptr(i, first1 - 1, dev.value + i * nb)
+        back = np.zeros(nb, np.uint8)
+        assert hip.hipMemcpy(ctypes.c_void_p(back.ctypes.data), dev, ctypes.c_size_t(nb), 2) == 0     # hipMemcpyDeviceToHost
+        assert np.array_equal(back, encs[0].export_boundary(0, first1 - 1))
+        enc2 = hm.Encoder(w, h, bd, 1, max_batch=len(pics))
+        for i, (planes, _) in enumerate(pics):
+            enc2.upload(i, planes)
+            enc2.import_boundary_ptr(i, first1 - 1, dev.value + i * nb)
+        enc2.run_rows(0, len(pics), qp, first1, h_ctu - 1)
+        for i in range(len(pics)):
+            a, b = enc2.download(i), encs[1].download(i)
+            common.assert_ctus_equal(a[1][first1 * w_ctu:], b[1][first1 * w_ctu:], f"{name} picture {i}: device-resident hand-off")
+            assert all(np.array_equal(a[0][k][first1 * (64 >> (1 if k else 0)):], b[0][k][first1 * (64 >> (1 if k else 0)):]) for k in range(3))
+        enc2.close()
+        hip.hipFree(dev)
     for i, (_, (want_ctus, want_rec)) in enumerate(pics):
         got_ctus = np.zeros_like(encs[0].download(i)[1])
         got_rec = [np.zeros((h, w), np.uint16), np.zeros((h // 2, w // 2), np.uint16), np.zeros((h // 2, w // 2), np.uint16)]

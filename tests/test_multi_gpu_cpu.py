@@ -64,8 +64,9 @@ def test_bench_line_is_complete(world, rows):
     """the JSON line bench.py prints for the headline workload carries every field of the contract (built without a GPU)"""
     import argparse
     import bench
-    args = argparse.Namespace(width=3840, height=2160, qp=32, frames=384, steps=20, warmup=5, budget_s=280.0)
-    line = bench.intra_line(args, world, rows, 12 if rows else 0, 7, 1, 250.0, 248000.0, 7, 2040 * 384 * 7 * (1 if rows else world), 2040 * 384 * 7)
+    args = argparse.Namespace(width=3840, height=2160, qp=32, frames=384, steps=20, warmup=5, budget_s=280.0, lanes=1 if rows else 3)
+    # 7 launches of 3 x 248 / 7 s each, three in flight at a time: 248 s of timed region
+    line = bench.intra_line(args, world, rows, 12 if rows else 0, 7, 1, 250.0, 248000.0 * (1 if rows else 3), 7, 2040 * 384 * 7 * (1 if rows else world), 2040 * 384 * 7, "0123456789ab")
     json.dumps(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in line
@@ -73,3 +74,7 @@ def test_bench_line_is_complete(world, rows):
     r = line["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["unit"] == "GB/s"
     assert abs(line["value"] - 2040 * 384 * 7 * (1 if rows else world) / 250.0) < 1e-6
+    # achieved = algorithmic bytes of all launches of the rank / timed region, however many launches overlap
+    assert abs(r["achieved"] - 54278 * 2040 * 384 * 7 / (250.0 if not rows else 248.0) / 1e9) < 1e-9
+    assert r["traffic"] is None and "traffic_note" in r          # no PMC record of build 0123456789ab under profiles/
+    assert bench.plan_steps(9.0, 5, 20, 280.0, first=4) == (5, 20) and bench.plan_steps(30.0, 5, 20, 280.0, first=4) == (4, 5)
