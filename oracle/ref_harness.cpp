@@ -40,6 +40,8 @@
 #include "TLibCommon/TComTrQuant.h"
 #include "TLibCommon/TComPic.h"
 #include "TLibEncoder/TEncSlice.h"
+#include "TLibEncoder/TEncCu.h"
+#include "TLibEncoder/TEncPic.h"
 #undef private
 #undef protected
 
@@ -179,10 +181,32 @@ static void putMotion(FILE *f, TComDataCU *ctu, int l, bool full)
 extern "C" void __real__ZN9TEncSlice13compressSliceEP7TComPic(TEncSlice *self, TComPic *pic);
 extern "C" void __wrap__ZN9TEncSlice13compressSliceEP7TComPic(TEncSlice *self, TComPic *pic)
 {
+  const int32_t dqpFlagIn = self->m_pcCuEncoder->getdQPFlag() ? 1 : 0;      // TEncCu::m_bEncodeDQP as the previous picture's encodeSlice left it
   __real__ZN9TEncSlice13compressSliceEP7TComPic(self, pic);
   if (!g_dump2) return;
   FILE *f = g_dump2;
   TComSlice *sl = pic->getSlice(self->getSliceIdx());
+  if (sl->getPPS()->getUseDQP())
+  { // 'Q' (before the 'S' record of the same slice, only when cu_qp_delta is enabled): i32 maxCuDQPDepth, dqpFlagIn, dqpFlagOut, qpAdaptationRange;
+    //   u32 numCtus; per CTU i8[256] m_phQP as compressSlice left it; then the layer-0 activities of TEncPreanalyzer when AdaptiveQP is on:
+    //   u32 numUnits (0: off), f64 avgActivity, f64 activity[numUnits]
+    fputc('Q', f);
+    int32_t q[4] = { (int32_t)sl->getPPS()->getMaxCuDQPDepth(), dqpFlagIn, self->m_pcCuEncoder->getdQPFlag() ? 1 : 0, self->m_pcCfg->getUseAdaptiveQP() ? self->m_pcCfg->getQPAdaptationRange() : 0 };
+    fwrite(q, 4, 4, f);
+    const UInt nc = pic->getPicSym()->getNumberOfCtusInFrame();
+    put32(f, nc);
+    for (UInt a = 0; a < nc; a++) { int8_t qp[256]; for (int i = 0; i < 256; i++) qp[i] = (int8_t)pic->getCtu(a)->getQP(i); fwrite(qp, 1, 256, f); }
+    TEncPic *ep = dynamic_cast<TEncPic *>(pic);
+    if (self->m_pcCfg->getUseAdaptiveQP() && ep && ep->getMaxAQDepth() > 0)
+    {
+      TEncPicQPAdaptationLayer *lay = ep->getAQLayer(0);
+      const UInt nu = lay->getNumAQPartInWidth() * lay->getNumAQPartInHeight();
+      put32(f, nu);
+      double avg = lay->getAvgActivity(); fwrite(&avg, 8, 1, f);
+      for (UInt i = 0; i < nu; i++) { double act = lay->getQPAdaptationUnit()[i].getActivity(); fwrite(&act, 8, 1, f); }
+    }
+    else put32(f, 0);
+  }
   fputc('S', f);
   int32_t hdr[5] = { sl->getPOC(), (int32_t)sl->getSliceType(), sl->getSliceQp(), (int32_t)sl->getTLayer(), sl->getDepth() };
   fwrite(hdr, 4, 5, f);

@@ -58,6 +58,15 @@ def parse(path, width, height):
             rl, off = _ref_lists(buf, off); r.update(rl)
             n, = struct.unpack_from("<I", buf, off); off += 4
             r["motion"] = np.frombuffer(buf, MOT_DT, n, off).copy(); off += n * MOT_DT.itemsize
+        elif tag == b"Q":                                   # cu_qp_delta side data of the slice whose 'S' record follows
+            r = {"tag": "Q"}
+            r["max_cu_dqp_depth"], r["dqp_flag_in"], r["dqp_flag_out"], r["aq_range"], n = struct.unpack_from("<4iI", buf, off); off += 20
+            r["qp"] = np.frombuffer(buf, "i1", n * 256, off).reshape(n, 256).copy(); off += n * 256
+            nu, = struct.unpack_from("<I", buf, off); off += 4
+            r["avg_activity"], r["activity"] = 0.0, np.zeros(0)
+            if nu:
+                r["avg_activity"], = struct.unpack_from("<d", buf, off); off += 8
+                r["activity"] = np.frombuffer(buf, "<f8", nu, off).copy(); off += 8 * nu
         elif tag == b"A":
             r = {"tag": "A"}
             r["poc"], r["depth"], en0, en1, n = struct.unpack_from("<4iI", buf, off); off += 20
@@ -87,7 +96,7 @@ def write(path, recs, bits=False):
     with open(path, "wb") as f:
         f.write(b"HMD2")
         for r in recs:
-            if r["tag"] == "A" or (r["tag"] == "B" and not bits):
+            if r["tag"] in ("A", "Q") or (r["tag"] == "B" and not bits):
                 continue                                  # SAO decisions, slice data bytes: not part of what the search replays
             if r["tag"] == "B":
                 for a in recs:

@@ -242,6 +242,64 @@ def test_hip_closed_loop_on_device_matches_reference(hm, name):
     enc.close()
 
 
+def _first_bad(got, want):
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    return f"{len(bad)} CTUs differ, first CTU {int(bad[0])}" if len(bad) else ""
+
+
+@pytest.mark.parametrize("name", common.FULL_CASES)
+def test_full_size_pictures_match_reference_digests(hm, name):
+    """BASELINE.json's sizes against the real reference, every CTU of every picture: the reference encoded these clips in the development
+    container (tests/gen_golden_full.py) and the fixture holds, per picture, a SHA-1 per CTU over decisions / costs / coefficients / motion,
+    MD5s of the reconstruction before the loop filters and of the finished picture, of the SAO parameters and of every substream of the slice
+    data.  The whole per-picture pipeline runs on the device in coding order (search -> deblock -> SAO -> bitstream pass -> device-resident
+    reference for the following pictures): 3840x2160 10-bit WPP I picture; two 1920x1080 10-bit I pictures without WPP (the CABAC state
+    chains through all 510 CTUs); 1080p low-delay I + 2 P; 4K random access POC 0 / 8 / 4 (B slices, references in both directions)."""
+    cfg, pics = common.load_full_case(name)
+    w, h, bd = cfg["width"], cfg["height"], cfg["bit_depth"]
+    enc = hm.Encoder(w, h, bd, cfg["wpp"], max_batch=1)
+    rate = np.zeros((3, 8), np.float64)
+    dev_refs = {}
+    for p in pics:
+        st, poc, qp = int(p["slice_type"]), int(p["poc"]), int(p["qp"])
+        what = f"{name} POC {poc}"
+        planes = synth.frame(w, h, bd, poc, cfg["seed"])
+        if st == 2:
+            enc.upload(0, planes)
+            sl = (hm.SliceDesc * 1)(hm.SliceDesc(2, qp, float(p["lambda"]), float(p["weight_cb"])))
+            enc._check(enc.lib.hm355_run(enc.h_, 1, sl), "hm355_run")
+            rec, ctus, _ = enc.download(0)
+            dig = common.ctu_digests(ctus)
+        else:
+            sp = {k: p[k] for k in ("slice_type", "qp", "lambda", "poc", "cabac_init_type", "num_ref_idx", "ref_poc", "col_from_l0", "col_ref_idx", "tmvp",
+                                    "mvd_l1_zero", "max_merge_cand", "check_ldc", "lambda_motion_sad", "lambda_motion_sse")}
+            sp["chroma_weight"] = p["weight_cb"]
+            refs = {int(q): dev_refs[int(q)] for l in range(2) for q in p["ref_poc"][l][:p["num_ref_idx"][l]]}
+            rec, ctus, ictus, _ = enc.compress_inter(planes, sp, refs)
+            dig = common.ctu_digests(ctus, ictus)
+        assert np.array_equal(dig, p["ctu_sha1"]), f"{what}: {_first_bad(dig, p['ctu_sha1'])} of {len(dig)}"
+        for c in range(3):
+            assert np.array_equal(common.md5_of(rec[c]), p["rec_md5"][c]), f"{what}: pre-deblocking reconstruction plane {c}"
+        enc.deblock_run([(st, qp, p["ref_poc"])])
+        (en3, sao), = enc.sao_run([dict(qp=qp, cabac_init_type=int(p["cabac_init_type"]), depth=int(p["sao_depth"]), disabled_rate=rate,
+                                        chroma_weight=float(p["weight_cb"]), **{"lambda": float(p["lambda"])})])
+        assert (en3[0], en3[1]) == tuple(int(v) for v in p["sao_enabled"]), f"{what}: slice-level SAO flags"
+        assert np.array_equal(common.md5_of(common.normalise_sao(sao)), p["sao_md5"]), f"{what}: SAO parameters"
+        (subs, nxt, bins), = enc.encode_slices_run([dict(slice_type=st, qp=qp, cabac_init_type=int(p["cabac_init_type"]), num_ref_idx=p["num_ref_idx"],
+                                                         mvd_l1_zero=int(p["mvd_l1_zero"]), max_merge_cand=int(p["max_merge_cand"]), sao_enabled=(en3[0], en3[1]))])
+        assert [len(x) for x in subs] == [int(v) for v in p["sub_sizes"]], f"{what}: substream sizes"
+        for k, x in enumerate(subs):
+            assert np.array_equal(common.md5_of(np.frombuffer(x, np.uint8)), p["sub_md5"][k]), f"{what}: substream {k}"
+        assert (nxt, bins) == (int(p["next_cabac_init_type"]), int(p["num_bins"])), f"{what}: next context table / bin count"
+        fin, _, _ = enc.download(0, want_ctus=False)
+        for c in range(3):
+            assert np.array_equal(common.md5_of(fin[c]), p["final_md5"][c]), f"{what}: finished picture plane {c}"
+        dev_refs[poc] = enc.ref_from_slot(0, poc, st != 2, p["num_ref_idx"], p["ref_poc"], p["ref_long_term"])
+    for ref in dev_refs.values():
+        enc.ref_release(ref)
+    enc.close()
+
+
 @pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES + common.DBK_CASES + common.LDP_LONG_CASES)
 def test_hip_bitstream_pass_matches_reference(hm, name):
     """hm355_encode_slice (host buffers in) on the reference's own CTU decisions and SAO parameters: the substream bytes, the bin count and

@@ -155,3 +155,23 @@ def test_oracle_yuv_io_matches_reference(built, name):
         for k in range(3):
             assert np.array_equal(planes[k], c["planes"][i][k]), f"{name} frame {i}: plane {k}"
         assert oracle.yuv_write(planes, c["internal_bd"], c["out_bd"], c["pad_x"], c["pad_y"]) == c["out"][i], f"{name} frame {i}: written bytes"
+
+
+@pytest.mark.parametrize("name", [common.FULL_CASES[1], common.FULL_CASES[0]])
+def test_oracle_matches_full_size_reference_digests(built, name):
+    """the oracle at BASELINE.json's picture sizes against the reference's own full pictures (tests/gen_golden_full.py): every CTU of two
+    1920x1080 10-bit I pictures (no WPP) and of one 3840x2160 10-bit WPP I picture, plus the reconstruction before the loop filters"""
+    import oracle
+    cfg, pics = common.load_full_case(name)
+    for p in pics:
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(p["poc"]), cfg["seed"])
+        rec, ctus = oracle.compress(planes, cfg["bit_depth"], int(p["qp"]), cfg["wpp"])
+        got = np.zeros(len(ctus), __import__("hmd2").CTU_DT)
+        for f in ("total_cost", "total_bits", "total_dist", "depth", "part_size", "pred_mode", "intra_dir_luma", "intra_dir_chroma", "tr_idx", "cbf", "tskip",
+                  "coeff_y", "coeff_cb", "coeff_cr"):
+            got[f] = ctus[f]
+        dig = common.ctu_digests(common.split_fixture_ctus(got)[0])
+        bad = np.nonzero((dig != p["ctu_sha1"]).any(axis=1))[0]
+        assert len(bad) == 0, f"{name} POC {int(p['poc'])}: {len(bad)} of {len(dig)} CTUs differ, first CTU {int(bad[0])}"
+        for c in range(3):
+            assert np.array_equal(common.md5_of(np.ascontiguousarray(rec[c], np.uint16)), p["rec_md5"][c]), f"{name} POC {int(p['poc'])}: reconstruction plane {c}"
