@@ -88,7 +88,7 @@ enum {
   C_SPLIT = 0, C_PART = 3, C_INTRA_LUMA = 7, C_CHROMA_PRED = 8, C_SUBDIV = 10, C_QT_CBF = 13, C_SIG_CG = 23,
   C_SIG = 27, C_LASTX = 71, C_LASTY = 101, C_ONE = 131, C_ABS = 155, C_TSKIP = 161,
   /* inter syntax */ C_SKIP = 163, C_MRG_FLAG = 166, C_MRG_IDX = 167, C_PRED_MODE = 168, C_INTER_DIR = 169, C_MVD = 174, C_REF = 176,
-  C_ROOT_CBF = 178, C_MVP_IDX = 179, NUM_CTX = 180
+  C_ROOT_CBF = 178, C_MVP_IDX = 179, /* cu_qp_delta_abs */ C_DQP = 180, NUM_CTX = 183
 };
 /* I-slice initialisation values, ContextTables.h:170-502 (row [2] of each table; CNU = 154) */
 static const uint8_t CTX_INIT_I[NUM_CTX] = {
@@ -107,7 +107,7 @@ static const uint8_t CTX_INIT_I[NUM_CTX] = {
   /* abs: luma 4, chroma 2 */ 138, 153, 136, 167, 152, 152,
   /* transform skip */ 139, 139,
   /* skip */ 154, 154, 154, /* merge flag, idx */ 154, 154, /* pred mode */ 154, /* inter dir */ 154, 154, 154, 154, 154, /* mvd */ 154, 154,
-  /* ref idx */ 154, 154, /* root cbf */ 154, /* mvp idx */ 154
+  /* ref idx */ 154, 154, /* root cbf */ 154, /* mvp idx */ 154, /* delta qp */ 154, 154, 154
 };
 /* P-slice initialisation values (row [1] of each table) */
 static const uint8_t CTX_INIT_P[NUM_CTX] = {
@@ -126,7 +126,7 @@ static const uint8_t CTX_INIT_P[NUM_CTX] = {
   /* abs: luma 4, chroma 2 */ 107, 167, 91, 122, 107, 167,
   /* transform skip */ 139, 139,
   /* skip */ 197, 185, 201, /* merge flag, idx */ 110, 122, /* pred mode */ 149, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 140, 198,
-  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168, /* delta qp */ 154, 154, 154
 };
 /* B-slice initialisation values (row [0] of each table) */
 static const uint8_t CTX_INIT_B[NUM_CTX] = {
@@ -145,7 +145,7 @@ static const uint8_t CTX_INIT_B[NUM_CTX] = {
   /* abs: luma 4, chroma 2 */ 107, 167, 91, 107, 107, 167,
   /* transform skip */ 139, 139,
   /* skip */ 197, 185, 201, /* merge flag, idx */ 154, 137, /* pred mode */ 134, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 169, 198,
-  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168, /* delta qp */ 154, 154, 154
 };
 
 static void gen_scan(int w, int h, int stride, int type, int offx, int offy, uint16_t *out, int count)
@@ -251,6 +251,7 @@ typedef struct {
   uint8_t skip[256], mrg[256], mrgIdx[256], interDir[256];
   Mv mv[2][256], mvd[2][256];
   int8_t refIdx[2][256], mvpIdx[2][256], mvpNum[2][256];
+  int8_t qp[256];                  /* m_phQP */
 } CtuMeta;
 
 typedef struct {
@@ -293,6 +294,11 @@ typedef struct {
   TCoeff *coef[3];                 /* per CTU: 4096 / 1024 / 1024 */
   double lambda, sqrtLambda, lambdaC, chromaWeight;
   int qpRem[3], qpPer[3];
+  /* cu_qp_delta (MaxCuDQPDepth 0: the CTU is the quantisation group) */
+  const hmo_dqp *dq;               /* NULL: cu_qp_delta disabled, every CU at the slice QP */
+  int dqpFlag;                     /* TEncCu::m_bEncodeDQP */
+  int ctuQp, refQp;                /* QP of the CTU under search (xComputeQP / rate control) and its predictor (TComDataCU::getRefQP) */
+  int8_t *lastQp;                  /* per CTU: QP of its last coded CU (TComDataCU::getLastCodedQP of the next CTU) */
   /* current CTU */
   int ctuX, ctuY, ctuAddr;
   CtuMeta *cm; TCoeff *cc[3];
@@ -1484,7 +1490,23 @@ static uint32_t est_intra_pred_chroma_qt(Enc *e, int cuZ, int cuDepth)
 /* ============================================================================================ */
 /* final syntax of a CU (TEncEntropy::xEncodeTransform, TEncEntropy.cpp:222-412)                 */
 /* ============================================================================================ */
-static void encode_transform(Enc *e, Cabac *c, const TU *t)
+static void code_delta_qp(Enc *e, Cabac *c, int dqp)
+{ /* TEncSbac::codeDeltaQP, TEncSbac.cpp:870-895 */
+  const int off = 6 * (e->cfg.bit_depth - 8);
+  dqp = (dqp + 78 + off + (off / 2)) % (52 + off) - 26 - (off / 2);
+  const unsigned a = (unsigned)(dqp > 0 ? dqp : -dqp), tu = a < 5 ? a : 5;
+  enc_bin(c, C_DQP, tu ? 1 : 0);                               /* xWriteUnaryMaxSymbol(tu, ctx, 1, CU_DQP_TU_CMAX), :281 */
+  if (tu) { unsigned k = tu; while (--k) enc_bin(c, C_DQP + 1, 1); if (5 > tu) enc_bin(c, C_DQP + 1, 0); }
+  if (a >= 5) {                                                /* xWriteEpExGolomb(a - 5, CU_DQP_EG_k = 0), :309 */
+    unsigned sym = a - 5, count = 0, bins = 0; int nb = 0;
+    while (sym >= (1u << count)) { bins = 2 * bins + 1; nb++; sym -= 1u << count; count++; }
+    bins = 2 * bins; nb++;
+    bins = (bins << count) | sym; nb += (int)count;
+    enc_epv(c, bins, nb);
+  }
+  if (a > 0) enc_epv(c, dqp > 0 ? 0 : 1, 1);
+}
+static void encode_transform(Enc *e, Cabac *c, const TU *t, int *codeDqp)
 {
   const CtuMeta *m = e->cm; const int z = t->cuZ + t->relZ;
   const int subdiv = m->tr[z] > t->trDepth;
@@ -1500,9 +1522,10 @@ static void encode_transform(Enc *e, Cabac *c, const TU *t)
   for (int comp = 1; comp < 3; comp++)
     if (first || t->cCodeAll)
       if (first || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)) code_qt_cbf(e, c, t, comp, subdiv == 0);
-  if (subdiv) { for (int s = 0; s < 4; s++) { TU ch = tu_child(t, s, 1); encode_transform(e, c, &ch); } return; }
+  if (subdiv) { for (int s = 0; s < 4; s++) { TU ch = tu_child(t, s, 1); encode_transform(e, c, &ch, codeDqp); } return; }
   code_qt_cbf(e, c, t, 0, 1);
   if (!any) return;
+  if (e->dq && codeDqp && *codeDqp) { code_delta_qp(e, c, m->qp[t->cuZ] - e->refQp); *codeDqp = 0; }   /* "dQP: only for CTU once", TEncEntropy.cpp:343-351 */
   for (int comp = 0; comp < 3; comp++) {
     if (comp && !t->cW) continue;
     if (!cbf[comp]) continue;
@@ -1514,14 +1537,15 @@ static void encode_transform(Enc *e, Cabac *c, const TU *t)
 }
 /* the CU-level syntax shared by xCheckRDCostIntra (:1601-1626) and xEncodeCU (:1246-1288), I slice */
 static void encode_cu_syntax(Enc *e, Cabac *c, int cuZ, int cuDepth)
-{
+{ /* the delta QP goes with the first coded block while TEncCu::m_bEncodeDQP is set -- in the RD search too (xCheckRDCostIntra :1629-1633 hands the
+     member through as it stands, i.e. as the previous CTU's encodeCtu left it) */
   const CtuMeta *m = e->cm;
   if (e->is) { code_skip_flag(e, c, cuZ); enc_bin(c, C_PRED_MODE, 1); }
   if (cuDepth == 3) enc_bin(c, C_PART, m->part[cuZ] == SIZE_2Nx2N);
   code_intra_dir_luma(e, c, cuZ, 1);
   code_intra_dir_chroma(e, c, cuZ);
   TU t = tu_root(cuZ, cuDepth);
-  encode_transform(e, c, &t);
+  encode_transform(e, c, &t, &e->dqpFlag);
 }
 
 /* ============================================================================================ */
@@ -1534,6 +1558,7 @@ static void init_est_data(Enc *e, int cuZ, int cuDepth)
   memset(m->dirL + cuZ, DC_IDX, parts); memset(m->dirC + cuZ, 0, parts); memset(m->tr + cuZ, 0, parts);
   for (int c = 0; c < 3; c++) { memset(m->cbf[c] + cuZ, 0, parts); memset(m->ts[c] + cuZ, 0, parts); }
   memset(m->skip + cuZ, 0, parts); memset(m->mrg + cuZ, 0, parts); memset(m->mrgIdx + cuZ, 0, parts); memset(m->interDir + cuZ, 0, parts);
+  memset(m->qp + cuZ, e->ctuQp, parts);
   for (int l = 0; l < 2; l++) {
     memset(m->mv[l] + cuZ, 0, sizeof(Mv) * parts); memset(m->mvd[l] + cuZ, 0, sizeof(Mv) * parts);
     memset(m->refIdx[l] + cuZ, -1, parts); memset(m->mvpIdx[l] + cuZ, -1, parts); memset(m->mvpNum[l] + cuZ, -1, parts);
@@ -1556,6 +1581,7 @@ static void meta_copy_inter(CtuMeta *d, const CtuMeta *s, int z, int parts)
     memcpy(d->mv[l] + z, s->mv[l] + z, sizeof(Mv) * parts); memcpy(d->mvd[l] + z, s->mvd[l] + z, sizeof(Mv) * parts);
     memcpy(d->refIdx[l] + z, s->refIdx[l] + z, parts); memcpy(d->mvpIdx[l] + z, s->mvpIdx[l] + z, parts); memcpy(d->mvpNum[l] + z, s->mvpNum[l] + z, parts);
   }
+  memcpy(d->qp + z, s->qp + z, parts);
 }
 static void save_best(Enc *e, int cuZ, int cuDepth, double cost, uint32_t bits, uint32_t dist)
 {
@@ -1591,6 +1617,19 @@ static void restore_best(Enc *e, int cuZ, int cuDepth)
 }
 
 /* xCheckRDCostIntra; returns through cost / bits / dist, leaves the trial in place */
+/* TEncCu::xCheckDQP :1742-1763 (RDO_WITHOUT_DQP_BITS 0): a candidate of quantisation-group size or larger -- with MaxCuDQPDepth 0 the 64x64 CU --
+   pays for its delta QP when it has a coded block, and falls back to the predicted QP when it has none */
+static void check_dqp(Enc *e, int cuZ, int cuDepth, double *cost, uint32_t *bits, uint32_t dist)
+{
+  if (!e->dq || cuDepth != 0) return;
+  CtuMeta *m = e->cm;
+  if ((m->cbf[0][cuZ] & 1) || (m->cbf[1][cuZ] & 1) || (m->cbf[2][cuZ] & 1)) {     /* getQtRootCbf(0) */
+    reset_bits(&e->cur);
+    code_delta_qp(e, &e->cur, m->qp[cuZ] - e->refQp);
+    *bits += num_bits(&e->cur);
+    *cost = calc_rd_cost(e, *bits, dist);
+  } else memset(m->qp + cuZ, e->refQp, 256 >> (2 * cuDepth));
+}
 static void check_rd_cost_intra(Enc *e, int cuZ, int cuDepth, int partSize, double *cost, uint32_t *bits, uint32_t *dist)
 {
   CtuMeta *m = e->cm; const int parts = 256 >> (2 * cuDepth);
@@ -1608,6 +1647,7 @@ static void check_rd_cost_intra(Enc *e, int cuZ, int cuDepth, int partSize, doub
   e->slot[cuDepth][CI_TEMP_BEST] = e->cur;
   *bits = num_bits(&e->cur); *dist = d;
   *cost = calc_rd_cost(e, *bits, *dist);
+  check_dqp(e, cuZ, cuDepth, cost, bits, *dist);
 }
 
 #include "hm_oracle_inter.inc"
@@ -1675,6 +1715,17 @@ static void compress_cu(Enc *e, int cuZ, int cuDepth, int parentPartSize, double
       splitBits += num_bits(&e->cur);
     }
     splitCost = calc_rd_cost(e, splitBits, splitDist);
+    if (e->dq && cuDepth == 0) { /* the split candidate of quantisation-group size, TEncCu.cpp:1052-1085 */
+      int first = 256;             /* first CU (z order) with a coded block; setQPSubCUs (TComDataCU.cpp:1763-1787) gives every CU before it the predicted QP */
+      for (int z = 0; z < 256; z++) if (m->cbf[0][z] || m->cbf[1][z] || m->cbf[2][z]) { first = z & ~((256 >> (2 * m->depth[z])) - 1); break; }
+      if (first < 256) {
+        reset_bits(&e->cur);
+        code_delta_qp(e, &e->cur, m->qp[0] - e->refQp);
+        splitBits += num_bits(&e->cur);
+        splitCost = calc_rd_cost(e, splitBits, splitDist);
+      }
+      memset(m->qp, e->refQp, first);
+    }
     e->slot[cuDepth][CI_TEMP_BEST] = e->slot[cuDepth + 1][CI_NEXT_BEST];
     if (splitCost < bestCost) {
       bestCost = splitCost; bestBits = splitBits; bestDist = splitDist;
@@ -1701,7 +1752,7 @@ static void encode_cu(Enc *e, Cabac *c, int z, int depth, int lastCtuOfSlice)
     }
     return;
   }
-  if (m->pred[z] == MODE_INTER) encode_cu_syntax_inter(e, c, z, depth); else encode_cu_syntax(e, c, z, depth);
+  if (m->pred[z] == MODE_INTER) encode_cu_syntax_inter(e, c, z, depth, &e->dqpFlag); else encode_cu_syntax(e, c, z, depth);
   /* finishCU, TEncCu.cpp:1130-1147 */
   const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->cfg.width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->cfg.height);
   if (lastX && lastY && !lastCtuOfSlice) enc_trm(c, 0);
@@ -1718,8 +1769,17 @@ void hmo_cfg_set_qp(hmo_cfg *c, int qp)
   c->chroma_weight = pow(2.0, (qp - qpc) / 3.0);
 }
 
+/* QpParam (TComTrQuant.cpp:71-119) of a CU at QP `qp`: what TComTrQuant::setQPforQuant hands the quantiser */
+static void set_quant_qp(Enc *e, int qp)
+{
+  const int bdOff = 6 * (e->cfg.bit_depth - 8);
+  int q = qp + bdOff; e->qpPer[0] = q / 6; e->qpRem[0] = q % 6;
+  int qc = clip3(-bdOff, 57, qp);
+  qc = (qc < 0) ? qc + bdOff : CHROMA_SCALE_420[qc] + bdOff;
+  e->qpPer[1] = e->qpPer[2] = qc / 6; e->qpRem[1] = e->qpRem[2] = qc % 6;
+}
 static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus, int maxCtus,
-                         const hmo_inter_slice *hs, hmo_ctu_inter *ictus)
+                         const hmo_inter_slice *hs, hmo_ctu_inter *ictus, const hmo_dqp *dq)
 {
   if (!cfg || cfg->width <= 0 || cfg->height <= 0 || (cfg->width & 7) || (cfg->height & 7) || (cfg->bit_depth != 8 && cfg->bit_depth != 10)) return -1;
   init_tables();
@@ -1772,13 +1832,11 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
   }
   e->lambda = cfg->lambda; e->sqrtLambda = sqrt(cfg->lambda);
   e->chromaWeight = cfg->chroma_weight; e->lambdaC = cfg->lambda / cfg->chroma_weight;
-  { /* QpParam, TComTrQuant.cpp:71-119 */
-    const int bdOff = 6 * (cfg->bit_depth - 8);
-    int q = cfg->qp + bdOff; e->qpPer[0] = q / 6; e->qpRem[0] = q % 6;
-    int qc = clip3(-bdOff, 57, cfg->qp);
-    qc = (qc < 0) ? qc + bdOff : CHROMA_SCALE_420[qc] + bdOff;
-    e->qpPer[1] = e->qpPer[2] = qc / 6; e->qpRem[1] = e->qpRem[2] = qc % 6;
-  }
+  set_quant_qp(e, cfg->qp);
+  e->ctuQp = e->refQp = cfg->qp;
+  e->dq = (dq && dq->use_dqp) ? dq : NULL;
+  e->dqpFlag = e->dq ? (dq->dqp_flag_in != 0) : 0;
+  e->lastQp = (int8_t *)calloc(numCtus, 1);
   cabac_init(&e->slot[0][CI_CURR_BEST], cfg->qp);
   const int limit = (maxCtus > 0 && maxCtus < numCtus) ? maxCtus : numCtus;
   for (int a = 0; a < limit; a++) {
@@ -1791,6 +1849,14 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
       for (int c = 0; c < 3; c++) { memset(m->cbf[c], 0, 256); memset(m->ts[c], 0, 256); }
       memset(m->skip, 0, 256); memset(m->mrg, 0, 256); memset(m->mrgIdx, 0, 256); memset(m->interDir, 0, 256);
       for (int l = 0; l < 2; l++) { memset(m->mv[l], 0, sizeof(m->mv[l])); memset(m->mvd[l], 0, sizeof(m->mvd[l])); memset(m->refIdx[l], -1, 256); memset(m->mvpIdx[l], -1, 256); memset(m->mvpNum[l], -1, 256); }
+      memset(m->qp, cfg->qp, 256);
+    }
+    if (e->dq) {
+      /* the QP of this CTU (TEncCu::xComputeQP :1154 / the rate control's, TEncSlice.cpp:767-808) and its predictor: both neighbouring quantisation
+         groups lie outside the CTU, so TComDataCU::getRefQP (:1413) is the QP of the last CU coded before it in this CTU row / slice (:1434-1468) */
+      e->ctuQp = dq->ctu_qp ? dq->ctu_qp[a] : cfg->qp;
+      e->refQp = (a == 0 || (e->ctuX == 0 && cfg->wpp)) ? cfg->qp : e->lastQp[a - 1];
+      set_quant_qp(e, e->ctuQp);
     }
     if (a == 0) cabac_init(&e->slot[0][CI_CURR_BEST], cfg->qp);
     else if (e->ctuX == 0 && cfg->wpp) {
@@ -1804,9 +1870,14 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
     o->total_cost = cost; o->total_bits = bits; o->total_dist = dist;
     /* TEncCu::encodeCtu on m_pppcRDSbacCoder[0][CI_CURR_BEST], TEncSlice.cpp:818-825 */
     reset_bits(&e->slot[0][CI_CURR_BEST]);
+    if (e->dq) e->dqpFlag = 1;                                   /* TEncCu::encodeCtu :358-361 */
     encode_cu(e, &e->slot[0][CI_CURR_BEST], 0, 0, a == numCtus - 1);
     if (e->ctuX == 1 && cfg->wpp) e->wppSync = e->slot[0][CI_CURR_BEST];
+    { int z = 255; while (z > 0 && e->cm->pred[z] == MODE_NONE) z--; e->lastQp[a] = e->cm->qp[z]; }   /* getLastValidPartIdx :1421 */
+    if (dq && dq->qp_out) memcpy(dq->qp_out + (size_t)a * 256, e->cm->qp, 256);
   }
+  if (dq && dq->dqp_flag_out) *dq->dqp_flag_out = e->dqpFlag;
+  free(e->lastQp);
   for (int a = 0; a < limit; a++) {
     const CtuMeta *m = e->meta + a; hmo_ctu *o = ctus + a;
     memcpy(o->depth, m->depth, 256); memcpy(o->part_size, m->part, 256); memcpy(o->pred_mode, m->pred, 256);
@@ -1841,9 +1912,47 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
 #include "hm_oracle_yuv.inc"
 
 int hmo_compress_slice(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus)
-{ return compress_impl(cfg, org, rec, ctus, 0, NULL, NULL); }
+{ return compress_impl(cfg, org, rec, ctus, 0, NULL, NULL, NULL); }
 int hmo_compress_rows(const hmo_cfg *cfg, const uint16_t *const org[3], uint16_t *const rec[3], hmo_ctu *ctus, int max_ctus)
-{ return compress_impl(cfg, org, rec, ctus, max_ctus, NULL, NULL); }
+{ return compress_impl(cfg, org, rec, ctus, max_ctus, NULL, NULL, NULL); }
 int hmo_compress_slice_inter(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],
                              hmo_ctu *ctus, hmo_ctu_inter *ictus)
-{ return slice ? compress_impl(cfg, org, rec, ctus, 0, slice, ictus) : -1; }
+{ return slice ? compress_impl(cfg, org, rec, ctus, 0, slice, ictus, NULL) : -1; }
+int hmo_compress_slice_dqp(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],
+                           hmo_ctu *ctus, hmo_ctu_inter *ictus, const hmo_dqp *dq)
+{ return compress_impl(cfg, org, rec, ctus, 0, slice, ictus, dq); }
+
+/* TEncPreanalyzer::xPreanalyze (TEncPreanalyzer.cpp:64-139), layer 0 (one unit per CTU): activity = 1 + the smallest "variance" of the unit's four
+   quadrants, where -- as in the reference -- every quadrant's sums are divided by the sample count of the WHOLE unit; the average is the
+   running sum over the units in raster order divided by their number */
+void hmo_preanalyze(const uint16_t *luma, int width, int height, double *activity, double *avg_activity)
+{
+  const int wU = (width + 63) / 64, hU = (height + 63) / 64;
+  double sumAct = 0.0;
+  for (int uy = 0; uy < hU; uy++) for (int ux = 0; ux < wU; ux++) {
+    const int x0 = ux * 64, y0 = uy * 64, w = width - x0 < 64 ? width - x0 : 64, h = height - y0 < 64 ? height - y0 : 64;
+    uint64_t sum[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0}; unsigned n = 0;
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++, n++) {
+      const int k = (y >= (h >> 1) ? 2 : 0) + (x >= (w >> 1) ? 1 : 0);
+      const int v = (int16_t)luma[(size_t)(y0 + y) * width + x0 + x];
+      sum[k] += (uint64_t)(int64_t)v; sq[k] += (uint64_t)(int64_t)(v * v);
+    }
+    double minVar = 1.7976931348623157e308;
+    for (int k = 0; k < 4; k++) {
+      const double average = (double)sum[k] / n;
+      const double variance = (double)sq[k] / n - average * average;
+      if (variance < minVar) minVar = variance;
+    }
+    activity[uy * wU + ux] = 1.0 + minVar;
+    sumAct += activity[uy * wU + ux];
+  }
+  *avg_activity = sumAct / (wU * hU);
+}
+/* TEncCu::xComputeQP, TEncCu.cpp:1154-1176 */
+int hmo_aq_qp(double activity, double avg_activity, int aq_range, int slice_qp, int bit_depth)
+{
+  const double maxQScale = pow(2.0, aq_range / 6.0);
+  const double normAct = (maxQScale * activity + avg_activity) / (activity + maxQScale * avg_activity);
+  const double qpOffset = log(normAct) / log(2.0) * 6.0;
+  return clip3(-6 * (bit_depth - 8), 51, slice_qp + (int)floor(qpOffset + 0.49999));
+}

@@ -80,6 +80,24 @@ typedef struct {
 int hmo_compress_slice_inter(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],
                              hmo_ctu *ctus, hmo_ctu_inter *ictus);
 
+/* ---- cu_qp_delta: adaptive QP and rate control hand compressSlice a QP per CTU (MaxCuDQPDepth 0: the CTU is the
+ * quantisation group; MaxDeltaQP 0).  The search then quantises every CU of the CTU at that QP, prices the delta QP where the reference
+ * does (TEncCu::xCheckDQP :1742, the split candidate :1052-1085, and -- while TEncCu::m_bEncodeDQP happens to be set -- with the first
+ * coded block of an intra candidate, TEncCu.cpp:1629-1633) and leaves TComDataCU::m_phQP behind. ---- */
+typedef struct {
+  int use_dqp;                       /* PPS cu_qp_delta_enabled_flag */
+  int dqp_flag_in;                   /* TEncCu::m_bEncodeDQP on entry: what the previous picture's encodeSlice left */
+  const int8_t *ctu_qp;              /* [numCtus] QP of each CTU (TEncCu::xComputeQP / TEncRateCtrl::getRCQP); NULL: the slice QP */
+  int8_t *qp_out;                    /* [numCtus*256] m_phQP as compressSlice leaves it; may be NULL */
+  int *dqp_flag_out;                 /* m_bEncodeDQP on exit; may be NULL */
+} hmo_dqp;
+/* slice NULL: I slice */
+int hmo_compress_slice_dqp(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],
+                           hmo_ctu *ctus, hmo_ctu_inter *ictus, const hmo_dqp *dq);
+/* TEncPreanalyzer::xPreanalyze for layer 0 (one unit per CTU): activity[numCtus] and their average; hmo_aq_qp = TEncCu::xComputeQP */
+void hmo_preanalyze(const uint16_t *luma, int width, int height, double *activity, double *avg_activity);
+int hmo_aq_qp(double activity, double avg_activity, int aq_range, int slice_qp, int bit_depth);
+
 /* ---- deblocking filter (TComLoopFilter::loopFilterPic, TComLoopFilter.cpp:130-158) on the picture compressSlice left:
  * rec is filtered in place (vertical edges of the whole picture, then horizontal edges).  cfg->qp = slice QP; ref_poc = POCs of the
  * slice's reference pictures [list][idx] (boundary strength compares pictures); ictus may be NULL for an I slice. ---- */

@@ -92,13 +92,8 @@ CTU_INTER_DTYPE = np.dtype([("skip", "u1", 256), ("merge_flag", "u1", 256), ("me
                             ("ref_idx", "i1", (2, 256)), ("mvp_idx", "i1", (2, 256)), ("mvp_num", "i1", (2, 256))])
 
 
-def compress_inter(planes, bit_depth, srec, finals, trace=None, wpp=0):
-    """One P slice.  srec: an 'S' record of tests/hmd2.py (slice parameters as the reference used them);
-    finals: {poc: 'F' record} of the pictures it references.  Returns (rec planes, ctus, inter ctus)."""
-    L = lib()
-    h, w = planes[0].shape
-    cfg = Cfg(w, h, bit_depth, int(srec["qp"]), wpp, float(srec["lambda"]), float(srec["weight_cb"]))
-    n = ((w + 63) // 64) * ((h + 63) // 64)
+def _inter_slice(srec, finals):
+    """(InterSlice struct, objects to keep alive) from an 'S' record of tests/hmd2.py and the 'F' records of the pictures it references"""
     keep, refs = [], {}
     for poc in set(int(srec["ref_poc"][l][i]) for l in range(2) for i in range(srec["num_ref_idx"][l])):
         f = finals[poc]
@@ -126,6 +121,18 @@ def compress_inter(planes, bit_depth, srec, finals, trace=None, wpp=0):
     s.col_from_l0, s.col_ref_idx, s.tmvp = int(srec["col_from_l0"]), int(srec["col_ref_idx"]), int(srec["tmvp"])
     s.mvd_l1_zero, s.max_merge_cand, s.check_ldc = int(srec["mvd_l1_zero"]), int(srec["max_merge_cand"]), int(srec["check_ldc"])
     s.lambda_motion_sad, s.lambda_motion_sse = int(srec["lambda_motion_sad"]), int(srec["lambda_motion_sse"])
+    keep.append(refs)
+    return s, keep
+
+
+def compress_inter(planes, bit_depth, srec, finals, trace=None, wpp=0):
+    """One P slice.  srec: an 'S' record of tests/hmd2.py (slice parameters as the reference used them);
+    finals: {poc: 'F' record} of the pictures it references.  Returns (rec planes, ctus, inter ctus)."""
+    L = lib()
+    h, w = planes[0].shape
+    cfg = Cfg(w, h, bit_depth, int(srec["qp"]), wpp, float(srec["lambda"]), float(srec["weight_cb"]))
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    s, keep = _inter_slice(srec, finals)
     org = [np.ascontiguousarray(p, np.uint16) for p in planes]
     rec = [np.zeros_like(p) for p in org]
     ctus, ictus = np.zeros(n, CTU_DTYPE), np.zeros(n, CTU_INTER_DTYPE)
@@ -141,6 +148,60 @@ def compress_inter(planes, bit_depth, srec, finals, trace=None, wpp=0):
     if rc != 0:
         raise RuntimeError(f"oracle (inter) failed rc={rc}")
     return rec, ctus, ictus
+
+
+# ---- cu_qp_delta: adaptive QP / rate control ---------------------------------------------------------
+class Dqp(C.Structure):
+    _fields_ = [("use_dqp", C.c_int), ("dqp_flag_in", C.c_int), ("ctu_qp", C.c_void_p), ("qp_out", C.c_void_p), ("dqp_flag_out", C.POINTER(C.c_int))]
+
+
+def preanalyze(luma):
+    """TEncPreanalyzer::xPreanalyze, layer 0: (activity per CTU in raster order, their average)"""
+    L = lib()
+    y = np.ascontiguousarray(luma, np.uint16)
+    h, w = y.shape
+    act = np.zeros(((w + 63) // 64) * ((h + 63) // 64), np.float64)
+    avg = C.c_double(0)
+    L.hmo_preanalyze.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+    L.hmo_preanalyze(y.ctypes.data, w, h, act.ctypes.data, C.byref(avg))
+    return act, avg.value
+
+
+def aq_qp(activity, avg_activity, aq_range, slice_qp, bit_depth):
+    """TEncCu::xComputeQP for every unit -> int8 array"""
+    L = lib()
+    L.hmo_aq_qp.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+    return np.array([L.hmo_aq_qp(float(a), float(avg_activity), int(aq_range), int(slice_qp), int(bit_depth)) for a in activity], np.int8)
+
+
+def compress_dqp(planes, bit_depth, srec, finals, wpp, ctu_qp, dqp_flag_in, trace=None):
+    """One slice (I, P or B: srec["slice_type"]) with cu_qp_delta enabled: ctu_qp = int8 QP per CTU (None: the slice QP everywhere, as the
+    picture-level rate control runs it).  Returns (rec planes, ctus, inter ctus or None, qp (numCtus, 256) int8, dqp_flag_out)."""
+    L = lib()
+    h, w = planes[0].shape
+    st = int(srec["slice_type"])
+    cfg = Cfg(w, h, bit_depth, int(srec["qp"]), wpp, float(srec["lambda"]), float(srec["weight_cb"]))
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    s, keep = (None, None) if st == 2 else _inter_slice(srec, finals)
+    org = [np.ascontiguousarray(p, np.uint16) for p in planes]
+    rec = [np.zeros_like(p) for p in org]
+    ctus, ictus = np.zeros(n, CTU_DTYPE), np.zeros(n, CTU_INTER_DTYPE)
+    po = (C.c_void_p * 3)(*[p.ctypes.data for p in org])
+    pr = (C.c_void_p * 3)(*[p.ctypes.data for p in rec])
+    cq = np.ascontiguousarray(ctu_qp, np.int8) if ctu_qp is not None else None
+    assert cq is None or len(cq) == n
+    qp_out = np.zeros((n, 256), np.int8); flag_out = C.c_int(-1)
+    d = Dqp(1, int(dqp_flag_in), cq.ctypes.data if cq is not None else None, qp_out.ctypes.data, C.pointer(flag_out))
+    L.hmo_compress_slice_dqp.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Dqp)]
+    L.hmo_set_trace.argtypes = [C.c_char_p]
+    if trace:
+        L.hmo_set_trace(trace.encode())
+    rc = L.hmo_compress_slice_dqp(C.byref(cfg), C.addressof(s) if s is not None else None, po, pr, ctus.ctypes.data, ictus.ctypes.data if st != 2 else None, C.byref(d))
+    if trace:
+        L.hmo_set_trace(None)
+    if rc != 0:
+        raise RuntimeError(f"oracle (dqp) failed rc={rc}")
+    return rec, ctus, (ictus if st != 2 else None), qp_out, flag_out.value
 
 
 def deblock(rec, bit_depth, qp, slice_type, ref_poc, ctus, ictus=None):

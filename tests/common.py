@@ -82,7 +82,15 @@ def load_ldp_case(name, records=None, sao=None, bits=None):
     cfg = {k: int(g[k]) for k in ("width", "height", "bit_depth", "frames", "seed")}
     cfg["wpp"] = int(g["wpp"]) if "wpp" in g else 0
     slices, finals = [], {}
+    pending_q = None
     for i in range(int(g["num_records"])):
+        if chr(int(g[f"r{i}_tag"])) == "Q":                      # cu_qp_delta side data of the slice that follows (tests/hmd2.py 'Q' record)
+            pending_q = {"tag": "Q", "qp": g[f"r{i}_qp"], "activity": g[f"r{i}_activity"]}
+            for k in ("max_cu_dqp_depth", "dqp_flag_in", "dqp_flag_out", "aq_range", "avg_activity"):
+                pending_q[k] = g[f"r{i}_{k}"][()]
+            if records is not None:
+                records.append(pending_q)
+            continue
         if chr(int(g[f"r{i}_tag"])) == "A":                      # SAO decisions of the picture (tests/hmd2.py 'A' record)
             r = {"tag": "A", "poc": int(g[f"r{i}_poc"]), "depth": int(g[f"r{i}_depth"]), "enabled": tuple(int(v) for v in g[f"r{i}_enabled"]), "sao": g[f"r{i}_sao"]}
             if sao is not None:
@@ -106,6 +114,7 @@ def load_ldp_case(name, records=None, sao=None, bits=None):
             for k in _S_KEYS:
                 r[k] = g[f"r{i}_{k}"][()]
             r["ctus"] = g[f"r{i}_ctus"]
+            r["dqp"], pending_q = pending_q, None               # None unless cu_qp_delta was enabled
             slices.append(r)
         else:
             r["poc"] = int(g[f"r{i}_poc"]); r["slice_type"] = int(g[f"r{i}_slice_type"]); r["motion"] = g[f"r{i}_motion"]
@@ -113,6 +122,9 @@ def load_ldp_case(name, records=None, sao=None, bits=None):
         if records is not None:
             records.append(r)
     return cfg, slices, finals
+
+
+DQP_CASES = ["aq_i_256x192_8b_qp30", "aq_iwpp_320x200_10b_qp27", "aq_ldp_256x136_8b_qp32", "aq_ra_192x128_10b_qp30", "rc_ldp_256x128_8b"]
 
 
 INTER_PAIRS = [("skip", "skip"), ("merge_flag", "merge_flag"), ("merge_idx", "merge_idx"), ("inter_dir", "inter_dir")]

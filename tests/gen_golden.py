@@ -118,6 +118,13 @@ LDP_CASES = [
     # deblocking pins: SAO off, so the finished picture ('F' record) is the deblocked pre-deblock reconstruction of the 'S' record
     ("dbk_ldp_200x136_8b_qp30", 200, 136, 8, 3, 30, 31, 0, "encoder_lowdelay_P_main.cfg", ("--SAO=0",)),
     ("dbk_ldb_192x128_10b_qp34", 192, 128, 10, 3, 34, 32, 0, "encoder_lowdelay_main10.cfg", ("--SAO=0",)),
+    # cu_qp_delta.  AdaptiveQP (TEncPreanalyzer activity -> per-CTU QP, MaxCuDQPDepth 0) on I / P / B clips, and the
+    # picture-level rate control (cu_qp_delta enabled with every CTU at the slice QP the rate model chose)
+    ("aq_i_256x192_8b_qp30", 256, 192, 8, 2, 30, 51, 0, "encoder_intra_main.cfg", ("--AdaptiveQP=1",)),
+    ("aq_iwpp_320x200_10b_qp27", 320, 200, 10, 2, 27, 52, 1, "encoder_intra_main10.cfg", ("--AdaptiveQP=1", "--MaxQPAdaptationRange=8")),
+    ("aq_ldp_256x136_8b_qp32", 256, 136, 8, 4, 32, 53, 1, "encoder_lowdelay_P_main.cfg", ("--AdaptiveQP=1",)),
+    ("aq_ra_192x128_10b_qp30", 192, 128, 10, 5, 30, 54, 0, "encoder_randomaccess_main10.cfg", ("--AdaptiveQP=1",)),
+    ("rc_ldp_256x128_8b", 256, 128, 8, 5, 32, 55, 1, "encoder_lowdelay_P_main.cfg", ("--RateControl=1", "--TargetBitrate=400000", "--LCULevelRateControl=0", "--InitialQP=30")),
 ]
 S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
           "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
@@ -137,6 +144,11 @@ def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_ma
     out = {"width": w, "height": h, "bit_depth": bd, "frames": nf, "seed": seed, "wpp": wpp, "num_records": len(recs)}
     for i, r in enumerate(recs):
         out[f"r{i}_tag"] = np.array(ord(r["tag"]))
+        if r["tag"] == "Q":
+            for k in ("max_cu_dqp_depth", "dqp_flag_in", "dqp_flag_out", "aq_range", "avg_activity"):
+                out[f"r{i}_{k}"] = np.array(r[k])
+            out[f"r{i}_qp"] = r["qp"]; out[f"r{i}_activity"] = r["activity"]
+            continue
         if r["tag"] == "A":
             out[f"r{i}_poc"] = np.array(r["poc"]); out[f"r{i}_depth"] = np.array(r["depth"])
             out[f"r{i}_enabled"] = np.array(r["enabled"]); out[f"r{i}_sao"] = r["sao"]

@@ -175,3 +175,35 @@ def test_oracle_matches_full_size_reference_digests(built, name):
         assert len(bad) == 0, f"{name} POC {int(p['poc'])}: {len(bad)} of {len(dig)} CTUs differ, first CTU {int(bad[0])}"
         for c in range(3):
             assert np.array_equal(common.md5_of(np.ascontiguousarray(rec[c], np.uint16)), p["rec_md5"][c]), f"{name} POC {int(p['poc'])}: reconstruction plane {c}"
+
+
+@pytest.mark.parametrize("name", common.DQP_CASES)
+def test_oracle_cu_qp_delta_matches_reference(built, name):
+    """clips the reference encoded with AdaptiveQP (I, P and B slices, WPP on / off, 8 / 10 bit) and with the picture-level rate
+    control.  The restated TEncPreanalyzer reproduces the reference's activities and xComputeQP its per-CTU QPs; with them the search
+    reproduces decisions, motion, coefficients, costs, the reconstruction, TComDataCU::m_phQP and TEncCu::m_bEncodeDQP bit for bit."""
+    import oracle
+    cfg, slices, finals = common.load_ldp_case(name)
+    n_q = 0
+    for r in slices:
+        q = r["dqp"]
+        assert q is not None and int(q["max_cu_dqp_depth"]) == 0
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"])
+        ctu_qp = None
+        if int(q["aq_range"]) > 0:
+            act, avg = oracle.preanalyze(planes[0])
+            assert np.array_equal(act, q["activity"]) and avg == float(q["avg_activity"]), f"{name} POC {int(r['poc'])}: activities"
+            ctu_qp = oracle.aq_qp(act, avg, int(q["aq_range"]), int(r["qp"]), cfg["bit_depth"])
+        rec, ctus, ictus, qp, flag = oracle.compress_dqp(planes, cfg["bit_depth"], r, finals, cfg["wpp"], ctu_qp, int(q["dqp_flag_in"]))
+        what = f"{name} POC {int(r['poc'])}"
+        if ictus is None:
+            common.assert_ctus_equal(ctus, common.split_fixture_ctus(r["ctus"])[0], what)
+        else:
+            common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], what)
+        for c in range(3):
+            assert np.array_equal(rec[c], r["rec"][c]), f"{what}: reconstruction plane {c}"
+        m = common.inside_mask(len(ctus), cfg["width"], cfg["height"])
+        assert np.array_equal(qp[m], q["qp"][m]), f"{what}: QP differs in CTUs {np.nonzero((qp != q['qp']).any(axis=1))[0][:8]}"
+        assert flag == int(q["dqp_flag_out"]), f"{what}: m_bEncodeDQP after the slice"
+        n_q += 1
+    assert n_q >= 2
