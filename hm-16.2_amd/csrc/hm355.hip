@@ -91,7 +91,6 @@ extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Param
 // reference's recursion; waves 1.. evaluate the unsplit candidates it hands them.  Used for launches that cannot fill the device with
 // one-wavefront searches (a few pictures, or pictures whose CABAC state chains through every CTU), where the time of ONE CTU search is
 // what the launch takes.  I slices.
-__shared__ Team g_team;
 extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
 {
   Team *T = &g_team;
@@ -176,6 +175,9 @@ struct Slot {           // one picture resident in HBM
   Pel *saoSrc[3]; SaoStat *saoStat; SaoCand *saoCand; SaoBlk *saoCoded, *saoRecon;   // SAO working buffers (allocated on first use)
   uint8_t *rawIn, *rawOut;   // file frames as they are on disk (ingest / output, allocated on first use)
   uint8_t *bitsRaw, *bitsPacked; uint32_t *bitsSizes; CabacW *bitsSync; uint32_t *bitsFlag; InterPic *bitsIp;   // bitstream pass (allocated on first use)
+  // cu_qp_delta (hm355_set_dqp): device state of the picture, allocated on first use; dqpOn: the next searches of the slot run with it
+  DqpPic *dDqp; int8_t *dCtuQp; CtuDqp *dDqpOut; uint8_t *dRowFlag; int dqpOn, dqpFlagIn;
+  std::vector<int8_t> ctuQp; std::vector<uint8_t> rowFlag; hm355_slice_desc lastSlice;
 };
 #define HM_BITS_CAP_PER_CTU 16384u   /* bytes reserved per CTU in the raw substream buffers: above the raw size of a 10-bit 4:2:0 CTU (7.7 KB) */
 #define HM_MAX_LANES 4
@@ -187,7 +189,7 @@ struct Lane {           // one launch of the search in flight: its own stream, s
   unsigned int *dSched; // [0] ticket, [1] abort
   std::vector<WorkItem> items; std::vector<int> stepStart; std::vector<FrameBuf> fbs;
   long long key[5]; int keyValid, fewWaves;
-  int busy, grid;
+  int busy, grid, inFixup;
   Pel *dTeamWin; size_t teamCap;   // team launches (hm355_team.h): the helpers' reconstruction windows, for teamCap teams
 };
 struct hm355_ctx {
@@ -243,7 +245,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   hm355_ctx *c = new hm355_ctx();
   c->cfg = *cfg; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
   c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
-  for (int l = 0; l < HM_MAX_LANES; l++) { Lane &L = c->lane[l]; L.stream = NULL; L.ev0 = L.ev1 = NULL; L.dP = NULL; L.dWs = NULL; L.wsCount = 0; L.dItems = NULL; L.itemsCap = 0; L.dSched = NULL; L.keyValid = 0; L.fewWaves = -1; L.busy = 0; L.grid = 0; L.dTeamWin = NULL; L.teamCap = 0; }
+  for (int l = 0; l < HM_MAX_LANES; l++) { Lane &L = c->lane[l]; L.stream = NULL; L.ev0 = L.ev1 = NULL; L.dP = NULL; L.dWs = NULL; L.wsCount = 0; L.dItems = NULL; L.itemsCap = 0; L.dSched = NULL; L.keyValid = 0; L.fewWaves = -1; L.busy = 0; L.grid = 0; L.inFixup = 0; L.dTeamWin = NULL; L.teamCap = 0; }
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
   P.wCtu = (cfg->width + 63) / 64; P.hCtu = (cfg->height + 63) / 64;
@@ -281,6 +283,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
       c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCand = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
       c->slots[s].rawIn = c->slots[s].rawOut = NULL;
       c->slots[s].bitsRaw = c->slots[s].bitsPacked = NULL; c->slots[s].bitsSizes = NULL; c->slots[s].bitsSync = NULL; c->slots[s].bitsFlag = NULL; c->slots[s].bitsIp = NULL;
+      c->slots[s].dDqp = NULL; c->slots[s].dCtuQp = NULL; c->slots[s].dDqpOut = NULL; c->slots[s].dRowFlag = NULL; c->slots[s].dqpOn = 0; c->slots[s].dqpFlagIn = 0;
       uint8_t *p = c->arena + off;
       for (int k = 0; k < 3; k++) { fb.org[k] = (Pel *)p; p += planeBytes[k]; fb.rec[k] = (Pel *)p; p += planeBytes[k]; }
       fb.meta = (CtuMeta *)p; p += metaBytes; fb.coef = (TCoeff *)p; p += coefBytes; fb.stat = (CtuStat *)p; p += statBytes;
@@ -306,6 +309,7 @@ extern "C" void hm355_destroy(hm355_ctx *c)
     for (int k = 0; k < 3; k++) if (c->slots[s].saoSrc[k]) hipFree(c->slots[s].saoSrc[k]);
     { Slot &sl = c->slots[s]; if (sl.rawIn) hipFree(sl.rawIn); if (sl.rawOut) hipFree(sl.rawOut); if (sl.bitsRaw) hipFree(sl.bitsRaw); if (sl.bitsPacked) hipFree(sl.bitsPacked); if (sl.bitsSizes) hipFree(sl.bitsSizes);
       if (sl.bitsSync) hipFree(sl.bitsSync); if (sl.bitsFlag) hipFree(sl.bitsFlag); if (sl.bitsIp) hipFree(sl.bitsIp); }
+    { Slot &sl = c->slots[s]; if (sl.dDqp) hipFree(sl.dDqp); if (sl.dCtuQp) hipFree(sl.dCtuQp); if (sl.dDqpOut) hipFree(sl.dDqpOut); if (sl.dRowFlag) hipFree(sl.dRowFlag); }
     if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCand) hipFree(c->slots[s].saoCand); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
   }
   for (int l = 0; l < HM_MAX_LANES; l++) {
@@ -341,6 +345,37 @@ extern "C" int hm355_upload(hm355_ctx *c, int slot, const hm355_planes *org)
   return HM355_OK;
 }
 
+// cu_qp_delta state of a slot for the search about to be launched (hm355_set_dqp armed it): the quantiser parameters of every QP the CTUs can
+// take (they depend on the slice's lambda), the CTUs' QPs, m_bEncodeDQP on entry, the per-row assumptions under WaveFrontSynchro
+static int dqp_prepare(hm355_ctx *c, int slot, const hm355_slice_desc *sd, hipStream_t stream)
+{
+  Slot &sl = c->slots[slot]; const Params &P = c->hp;
+  sl.lastSlice = *sd;
+  if (!sl.dqpOn) { sl.fb.dqp = NULL; return HM355_OK; }
+  if (!sl.dDqp) {
+    HM_CHECK(c, hipMalloc((void **)&sl.dDqp, sizeof(DqpPic))); HM_CHECK(c, hipMalloc((void **)&sl.dCtuQp, c->numCtus));
+    HM_CHECK(c, hipMalloc((void **)&sl.dDqpOut, sizeof(CtuDqp) * c->numCtus)); HM_CHECK(c, hipMalloc((void **)&sl.dRowFlag, P.hCtu));
+  }
+  DqpPic *hp = new DqpPic; memset(hp, 0, sizeof(*hp));
+  hp->flagIn = sl.dqpFlagIn; hp->sliceQp = sd->qp; hp->ctuQp = sl.dCtuQp; hp->out = sl.dDqpOut; hp->rowFlag = sl.dRowFlag;
+  for (int q = -12; q <= 51; q++) {
+    FrameBuf t; memset(&t, 0, sizeof(t));
+    hm355_fill_slice_params(&t, P.bitDepth, q, sd->lambda, sd->chroma_weight);
+    QpTab &e = hp->tab[q + 12];
+    for (int k = 0; k < 2; k++) { e.qpPer[k] = t.qpPer[k]; e.qpRem[k] = t.qpRem[k]; e.rdFactor[k] = t.rdFactor[k]; for (int l = 0; l < 4; l++) e.errScale[k][l] = t.errScale[k][l]; }
+  }
+  std::vector<int8_t> q(c->numCtus, (int8_t)sd->qp);
+  if (!sl.ctuQp.empty()) q = sl.ctuQp;
+  hipError_t e1 = hipMemcpyAsync(sl.dDqp, hp, sizeof(DqpPic), hipMemcpyHostToDevice, stream);
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(sl.dCtuQp, q.data(), c->numCtus, hipMemcpyHostToDevice, stream);
+  if (e1 == hipSuccess) e1 = hipMemcpyAsync(sl.dRowFlag, sl.rowFlag.data(), P.hCtu, hipMemcpyHostToDevice, stream);
+  if (e1 == hipSuccess) e1 = hipStreamSynchronize(stream);
+  delete hp;
+  HM_CHECK(c, e1);
+  sl.fb.dqp = sl.dDqp;
+  return HM355_OK;
+}
+
 // Lane l of the context: lane 0 wraps the context's own stream, scratch areas and scheduler words; further lanes get theirs on first use.
 static int lane_prepare(hm355_ctx *c, int l)
 {
@@ -372,6 +407,7 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
     if (slices[f].slice_type != 2) return fail(c, HM355_ERR_ARG, "only I slices are supported");
     if (slices[f].qp < 0 || slices[f].qp > 51 || !(slices[f].lambda > 0) || !(slices[f].chroma_weight > 0)) return fail(c, HM355_ERR_ARG, "bad slice parameters");
     hm355_fill_slice_params(&c->slots[slot0 + f].fb, P.bitDepth, slices[f].qp, slices[f].lambda, slices[f].chroma_weight);
+    { const int rc2 = dqp_prepare(c, slot0 + f, slices + f, L.stream); if (rc2 != HM355_OK) return rc2; }
     L.fbs[f] = c->slots[slot0 + f].fb;
   }
   HM_CHECK(c, hipMemcpyAsync(c->dFrames + slot0, L.fbs.data(), sizeof(FrameBuf) * n, hipMemcpyHostToDevice, L.stream));
@@ -439,6 +475,35 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
   L.busy = 1;
   return HM355_OK;
 }
+static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_desc *slices, int row0, int row1);
+static int run_wait(hm355_ctx *c, int l, double *kernelMs);
+// WaveFrontSynchro with cu_qp_delta: TEncCu::m_bEncodeDQP reaches the first CTU of a row from the LAST CTU of the row above (coding order), which the
+// wavefront has not searched yet when that row starts.  The launch ran on an assumption per row (Slot::rowFlag, "clear" to begin with: a CTU with
+// any coded block leaves it clear); here the assumptions are checked against what the rows above actually left, and from the first row that was
+// started on a wrong one the picture is searched again with the corrected value -- rare, and then repeated for the rows below.
+static int dqp_verify_rows(hm355_ctx *c, int l, int slot0, int n)
+{
+  const Params &P = c->hp;
+  if (!P.wpp || P.wCtu < 1) return HM355_OK;
+  for (int f = 0; f < n; f++) {
+    Slot &sl = c->slots[slot0 + f];
+    if (!sl.dqpOn || !sl.fb.dqp) continue;
+    std::vector<CtuDqp> out(c->numCtus);
+    for (int y = 1; y < P.hCtu; y++) {
+      HM_CHECK(c, hipMemcpy(out.data(), sl.dDqpOut, sizeof(CtuDqp) * c->numCtus, hipMemcpyDeviceToHost));
+      int bad = -1;
+      for (int yy = y; yy < P.hCtu; yy++) if (sl.rowFlag[yy] != out[(size_t)yy * P.wCtu - 1].flagOut) { bad = yy; break; }
+      if (bad < 0) break;
+      sl.rowFlag[bad] = out[(size_t)bad * P.wCtu - 1].flagOut;
+      const hm355_slice_desc sd = sl.lastSlice;
+      int rc = run_begin(c, l, slot0 + f, 1, &sd, bad, P.hCtu - 1);
+      if (rc == HM355_OK) rc = run_wait(c, l, NULL);
+      if (rc != HM355_OK) return rc;
+      y = bad;
+    }
+  }
+  return HM355_OK;
+}
 static int run_wait(hm355_ctx *c, int l, double *kernelMs)
 {
   Lane &L = c->lane[l];
@@ -451,6 +516,13 @@ static int run_wait(hm355_ctx *c, int l, double *kernelMs)
   if (sched[1] != 0) return fail(c, HM355_ERR_DEVICE, "scheduler aborted: a dependency wait timed out");
   c->lastKernelMs = ms; c->lastLaunches = 1;
   if (kernelMs) *kernelMs = ms;
+  if (L.keyValid && !L.inFixup) {
+    L.inFixup = 1;
+    const int rc = dqp_verify_rows(c, l, (int)L.key[0], (int)L.key[1]);
+    L.inFixup = 0; L.keyValid = 0;          // the fix-up launches reused the lane's work list
+    c->lastKernelMs = ms;
+    if (rc != HM355_OK) return rc;
+  }
   return HM355_OK;
 }
 static int run_rows_impl(hm355_ctx *c, int slot0, int n, const hm355_slice_desc *slices, int row0, int row1)
@@ -473,6 +545,54 @@ extern "C" int hm355_run_wait(hm355_ctx *c, int lane, double *kernel_ms)
 {
   if (!c || lane < 0 || lane >= HM_MAX_LANES) return HM355_ERR_ARG;
   return run_wait(c, lane, kernel_ms);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cu_qp_delta: adaptive QP / rate control hooks of compressSlice
+// ------------------------------------------------------------------------------------------------
+extern "C" int hm355_set_dqp(hm355_ctx *c, int slot, const hm355_dqp_desc *d)
+{
+  if (!c || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
+  Slot &sl = c->slots[slot];
+  if (!d || !d->use_dqp) { sl.dqpOn = 0; sl.fb.dqp = NULL; sl.ctuQp.clear(); return HM355_OK; }
+  const int lo = -6 * (c->hp.bitDepth - 8);
+  sl.ctuQp.clear();
+  if (d->ctu_qp) {
+    for (int a = 0; a < c->numCtus; a++) if (d->ctu_qp[a] < lo || d->ctu_qp[a] > 51) return fail(c, HM355_ERR_ARG, "hm355_set_dqp: CTU QP out of range");
+    sl.ctuQp.assign(d->ctu_qp, d->ctu_qp + c->numCtus);
+  }
+  sl.dqpOn = 1; sl.dqpFlagIn = d->dqp_flag_in != 0;
+  sl.rowFlag.assign(c->hp.hCtu, 0);
+  return HM355_OK;
+}
+extern "C" int hm355_get_dqp(hm355_ctx *c, int slot, int8_t *qp_out, int32_t *dqp_flag_out)
+{
+  if (!c || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
+  Slot &sl = c->slots[slot];
+  if (!sl.dqpOn || !sl.dDqpOut) return fail(c, HM355_ERR_ARG, "hm355_get_dqp: the slot was not searched with cu_qp_delta");
+  std::vector<CtuDqp> out(c->numCtus);
+  HM_CHECK(c, hipMemcpy(out.data(), sl.dDqpOut, sizeof(CtuDqp) * c->numCtus, hipMemcpyDeviceToHost));
+  if (qp_out) for (int a = 0; a < c->numCtus; a++) for (int z = 0; z < 256; z++) qp_out[(size_t)a * 256 + z] = z < out[a].firstZ ? out[a].refQp : out[a].qp;
+  if (dqp_flag_out) *dqp_flag_out = out[c->numCtus - 1].flagOut;
+  return HM355_OK;
+}
+extern "C" int hm355_preanalyze(hm355_ctx *c, int slot, uint64_t *sums)
+{
+  if (!c || !sums || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
+  unsigned long long *d = NULL;
+  HM_CHECK(c, hipMemcpy(c->dFrames + slot, &c->slots[slot].fb, sizeof(FrameBuf), hipMemcpyHostToDevice));
+  HM_CHECK(c, hipMalloc((void **)&d, sizeof(unsigned long long) * 8 * c->numCtus));
+  HM_CHECK(c, hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(hm355_preanalyze_kernel, dim3(c->numCtus), dim3(64), 0, c->stream, (const Params *)c->dP, slot, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(sums, d, sizeof(unsigned long long) * 8 * c->numCtus, hipMemcpyDeviceToHost);
+  hipFree(d);
+  HM_CHECK(c, e);
+  float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->lastKernelMs = ms; c->lastLaunches = 1;
+  return HM355_OK;
 }
 
 extern "C" int hm355_run(hm355_ctx *c, int n, const hm355_slice_desc *slices)

@@ -8,8 +8,8 @@
 #pragma once
 
 struct CabacW {
-  uint8_t s[184];                     // context states, numbering of Cabac; [HM_NUM_CTX] = SAO merge, [HM_NUM_CTX + 1] = SAO type index
-  uint8_t used[184];                  // ContextModel::m_binsCoded (read by determineCabacInitIdx)
+  uint8_t s[192];                     // context states, numbering of Cabac; [HM_NUM_CTX] = SAO merge, [HM_NUM_CTX + 1] = SAO type index
+  uint8_t used[192];                  // ContextModel::m_binsCoded (read by determineCabacInitIdx)
   uint32_t low, range; int32_t bitsLeft; uint32_t bufferedByte; int32_t numBufferedBytes;   // TEncBinCABAC
   uint32_t held; int32_t numHeld;     // TComOutputBitstream::m_held_bits
   uint8_t *out; uint32_t len, cap;    // byte FIFO of the substream (HBM)
@@ -17,7 +17,7 @@ struct CabacW {
   int32_t tabLps[64], tabNlps[32];    // LDS copies of the LPS range table (4 bytes per state) and of the LPS transitions (4 states per word)
 };
 enum { C_SAO_MERGE = HM_NUM_CTX, C_SAO_TYPE = HM_NUM_CTX + 1 };
-static_assert(HM_NUM_CTX + 2 <= 184, "SAO contexts live in the padding of the context array");
+static_assert(HM_NUM_CTX + 2 <= 192, "SAO contexts live behind the estimator's contexts");
 
 HM_CONST uint8_t HM_LPS_TABLE[64][4] __attribute__((aligned(4))) = {   // TComCABACTables::sm_aucLPSTable (H.265 table 9-46)
   {128,176,208,240},{128,167,197,227},{128,158,187,216},{123,150,178,205},{116,142,169,195},{111,135,160,185},{105,128,152,175},{100,122,144,166},
@@ -124,7 +124,7 @@ HM_DEV inline void cabr_load(const Shared *e, CabacWR &r, CabacW *c)
   (void)e;
   r.w = c;
   HM_WAVE_FOR(k) {
-    HM_LVK(r.st, k) = k < 46 ? (((const int32_t *)c->s)[k] | ((((const int32_t *)c->used)[k] & 0x01010101) << 7)) : 0;
+    HM_LVK(r.st, k) = k < 48 ? (((const int32_t *)c->s)[k] | ((((const int32_t *)c->used)[k] & 0x01010101) << 7)) : 0;
     HM_LVK(r.lpsRow, k) = c->tabLps[k];
     HM_LVK(r.nlps, k) = c->tabNlps[k & 31];
   }
@@ -132,7 +132,7 @@ HM_DEV inline void cabr_load(const Shared *e, CabacWR &r, CabacW *c)
 }
 HM_DEV inline void cabr_store(const CabacWR &r, CabacW *c)
 {
-  HM_WAVE_FOR(k) { if (k < 46) { ((int32_t *)c->s)[k] = HM_LVK(r.st, k) & 0x7f7f7f7f; ((int32_t *)c->used)[k] = (int32_t)(((uint32_t)HM_LVK(r.st, k) >> 7) & 0x01010101u); } }
+  HM_WAVE_FOR(k) { if (k < 48) { ((int32_t *)c->s)[k] = HM_LVK(r.st, k) & 0x7f7f7f7f; ((int32_t *)c->used)[k] = (int32_t)(((uint32_t)HM_LVK(r.st, k) >> 7) & 0x01010101u); } }
   c->low = r.low; c->range = r.range; c->bitsLeft = r.bitsLeft; c->bins = r.bins;
   HM_SYNC();
 }

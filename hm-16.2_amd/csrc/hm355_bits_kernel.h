@@ -91,7 +91,7 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
   const int saoOn = bp->sao && (bp->saoEnabled[0] || bp->saoEnabled[1]);
   // start of the substream: resetEntropy (context init + TEncBinCABAC::start); a WPP row then takes the contexts stored after the
   // second CTU of the row above (TEncSlice.cpp:975-994)
-  HM_PAR_FOR(i, 184) { w->s[i] = (uint8_t)(i < HM_NUM_CTX + 2 ? bits_ctx_init_state(bits_ctx_init_value(i, initType), qp) : 0); w->used[i] = 0; }
+  HM_PAR_FOR(i, 192) { w->s[i] = (uint8_t)(i < HM_NUM_CTX + 2 ? bits_ctx_init_state(bits_ctx_init_value(i, initType), qp) : 0); w->used[i] = 0; }
   cabw_load_tables(w);
   cabw_start(w);
   w->held = 0; w->numHeld = 0; w->len = 0; w->bins = 0;
@@ -113,7 +113,7 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
     const CabacW *src = bp->sync + (sub - 1);
-    HM_PAR_FOR(i, 184) { w->s[i] = src->s[i]; w->used[i] = src->used[i]; }
+    HM_PAR_FOR(i, 192) { w->s[i] = src->s[i]; w->used[i] = src->used[i]; }
     HM_SYNC();
   }
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
@@ -130,12 +130,17 @@ HM_DEV inline int bits_encode_substream(Shared *e, CabacW *w, const Params *P, i
       HM_SYNC();
     }
     if (saoOn) bits_sao_blk_param(e, w, bp->sao + (size_t)a * 105, bp->saoEnabled, e->ctuX > 0, e->ctuY > 0, maxOffQ);
+    if (e->fb.dqp) { // cu_qp_delta: the QP the search gave this CTU and its predictor; TEncCu::encodeCtu :358-361 sets m_bEncodeDQP
+      const CtuDqp o = e->fb.dqp->out[a];
+      if (hm_lane() == 0) { e->ws->dq.ctuQp = o.qp; e->ws->dq.refQp = o.refQp; e->ws->dq.flag = 1; }
+      HM_SYNC();
+    }
     { HM_PROF_BEGIN(e, PR_ENCCU); encode_ctu(e, w, a == numCtus - 1); HM_PROF_END(e, PR_ENCCU); }
     HM_PROF_END(e, PR_TOTAL);
     if (wpp && a == first + 1) { // m_entropyCodingSyncContextState.loadContexts, TEncSlice.cpp:1050
       HM_SYNC();
       CabacW *dst = bp->sync + sub;
-      HM_PAR_FOR(i, 184) { dst->s[i] = w->s[i]; dst->used[i] = w->used[i]; }
+      HM_PAR_FOR(i, 192) { dst->s[i] = w->s[i]; dst->used[i] = w->used[i]; }
 #ifndef HM355_HOSTSIM
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

@@ -218,7 +218,7 @@ HM_CONST uint8_t HM_CTX_INIT_I[HM_NUM_CTX] = {
   /* abs: luma 4, chroma 2 */ 138, 153, 136, 167, 152, 152,
   /* transform skip */ 139, 139,
   /* skip */ 154, 154, 154, /* merge flag, idx */ 154, 154, /* pred mode */ 154, /* inter dir */ 154, 154, 154, 154, 154, /* mvd */ 154, 154,
-  /* ref idx */ 154, 154, /* root cbf */ 154, /* mvp idx */ 154
+  /* ref idx */ 154, 154, /* root cbf */ 154, /* mvp idx */ 154, /* delta qp */ 154, 154, 154
 };
 // P- and B-slice rows of the same tables
 HM_CONST uint8_t HM_CTX_INIT_P[HM_NUM_CTX] = {
@@ -237,7 +237,7 @@ HM_CONST uint8_t HM_CTX_INIT_P[HM_NUM_CTX] = {
   /* abs: luma 4, chroma 2 */ 107, 167, 91, 122, 107, 167,
   /* transform skip */ 139, 139,
   /* skip */ 197, 185, 201, /* merge flag, idx */ 110, 122, /* pred mode */ 149, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 140, 198,
-  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168, /* delta qp */ 154, 154, 154
 };
 HM_CONST uint8_t HM_CTX_INIT_B[HM_NUM_CTX] = {
   /* split */ 107, 139, 126,
@@ -255,7 +255,7 @@ HM_CONST uint8_t HM_CTX_INIT_B[HM_NUM_CTX] = {
   /* abs: luma 4, chroma 2 */ 107, 167, 91, 107, 107, 167,
   /* transform skip */ 139, 139,
   /* skip */ 197, 185, 201, /* merge flag, idx */ 154, 137, /* pred mode */ 134, /* inter dir */ 95, 79, 63, 31, 31, /* mvd */ 169, 198,
-  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168
+  /* ref idx */ 153, 153, /* root cbf */ 79, /* mvp idx */ 168, /* delta qp */ 154, 154, 154
 };
 // first column of the 32-point core transform (TComRom.cpp:456-484); the matrix follows the cosine index law
 HM_CONST int8_t HM_DCT_C[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
@@ -366,7 +366,6 @@ struct Shared {
   int32_t width, height, bitDepth, wCtu, stride[3];
   const Params *P; FrameBuf fb; WorkSpace *ws; const Tables *tab;
   CtuMeta meta;                        // decision arrays of the CTU under search (written back to HBM at the end)
-  Team *team;                          // the team this wavefront belongs to (0: it searches its CTU alone)
   TCoeff *cc;
   int32_t ctuX, ctuY, ctuAddr;
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
@@ -2331,6 +2330,57 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_chroma_qt(Shared *e, int cuZ, int cuD
 }
 
 // ------------------------------------------------------------------------------------------------
+// cu_qp_delta (MaxCuDQPDepth 0: the CTU is the quantisation group)
+// ------------------------------------------------------------------------------------------------
+template <class C> HM_DEV inline void code_delta_qp(Shared *e, C *c, int dqp)
+{ // TEncSbac::codeDeltaQP, TEncSbac.cpp:870-895
+  const int off = 6 * (e->bitDepth - 8);
+  dqp = (dqp + 78 + off + (off / 2)) % (52 + off) - 26 - (off / 2);
+  const uint32_t a = (uint32_t)hm_abs(dqp), tu = a < 5 ? a : 5;
+  enc_bin(e, c, C_DQP, tu ? 1 : 0);                              // xWriteUnaryMaxSymbol(tu, ctx, 1, CU_DQP_TU_CMAX), :281
+  if (tu) { for (uint32_t k = tu; --k;) enc_bin(e, c, C_DQP + 1, 1); if (5 > tu) enc_bin(e, c, C_DQP + 1, 0); }
+  if (a >= 5) {                                                  // xWriteEpExGolomb(a - 5, CU_DQP_EG_k = 0), :309
+    uint32_t sym = a - 5, count = 0, bins = 0; int nb = 0;
+    while (sym >= (1u << count)) { bins = 2 * bins + 1; nb++; sym -= 1u << count; count++; }
+    bins = 2 * bins; nb++;
+    bins = (bins << count) | sym; nb += (int)count;
+    enc_epv(c, bins, nb);
+  }
+  if (a > 0) enc_epv(c, dqp > 0 ? 0u : 1u, 1);
+}
+// "dQP: only for CTU once" (TEncEntropy.cpp:343-351): with the first coded block met while TEncCu::m_bEncodeDQP is set
+template <class C> HM_DEV inline void code_dqp_if_due(Shared *e, C *c)
+{
+  if (!e->fb.dqp) return;
+  WorkSpace *ws = e->ws;
+  if (!HM_UNI(ws->dq.flag)) return;
+  code_delta_qp(e, c, HM_UNI(ws->dq.ctuQp) - HM_UNI(ws->dq.refQp));
+  HM_SYNC();
+  if (hm_lane() == 0) ws->dq.flag = 0;
+  HM_SYNC();
+}
+// TEncCu::xCheckDQP :1742-1763 (RDO_WITHOUT_DQP_BITS 0) on the candidate in e->outBits / outDist / outCost: a candidate of quantisation-group
+// size pays for its delta QP when it has a coded block (one without falls back to the predicted QP, which only the QP bookkeeping sees)
+HM_DEV inline void check_dqp(Shared *e, int cuZ, int cuDepth)
+{
+  if (!e->fb.dqp || cuDepth != 0) return;
+  const CtuMeta *m = &e->meta;
+  if (!(((m->cbf[0][cuZ] | m->cbf[1][cuZ] | m->cbf[2][cuZ]) & 1))) return;
+  reset_bits(&e->cur);
+  code_delta_qp(e, &e->cur, HM_UNI(e->ws->dq.ctuQp) - HM_UNI(e->ws->dq.refQp));
+  e->outBits += num_bits(&e->cur);
+  e->outCost = calc_rd_cost(e, e->outBits, e->outDist);
+}
+// first CU (z order) of the CTU with a coded block, 256 if none (TComDataCU::setQPSubCUs :1763 stops there)
+HM_DEV inline int first_coded_cu(const Shared *e)
+{
+  const CtuMeta *m = &e->meta;
+  int best = 256;
+  HM_PAR_FOR(z, 256) if (m->cbf[0][z] | m->cbf[1][z] | m->cbf[2][z]) { const int zz = z & ~((256 >> (2 * m->depth[z])) - 1); if (zz < best) best = zz; }
+  return -hm_wave_max_i(-best);
+}
+
+// ------------------------------------------------------------------------------------------------
 // final syntax of a CU (TEncEntropy::xEncodeTransform, TEncEntropy.cpp:222-412)
 // ------------------------------------------------------------------------------------------------
 template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, C *c, int cuZ, int cuDepth)
@@ -2361,6 +2411,7 @@ template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax(Shared *e, C *c, int
           if (first || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)) code_qt_cbf(e, c, t, comp, subdiv == 0);
       if (!subdiv) {
         code_qt_cbf(e, c, t, 0, 1);
+        if (((m->cbf[0][z] | m->cbf[1][z] | m->cbf[2][z]) >> t->trDepth) & 1) code_dqp_if_due(e, c);      // bHaveACodedBlock, TEncEntropy.cpp:343
         for (int comp = 0; comp < 3; comp++) {
           if (comp && !t->cW) continue;
           if (!((m->cbf[comp][z] >> t->trDepth) & 1)) continue;
@@ -2468,6 +2519,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_intra(Shared *e, int cuZ, int cuDepth, int
   cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->cur);
   e->outBits = num_bits(&e->cur); e->outDist = d;
   e->outCost = calc_rd_cost(e, e->outBits, e->outDist);
+  check_dqp(e, cuZ, cuDepth);
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   { const int pid = partSize == SIZE_NxN ? PR_NXN : PR_D0 + cuDepth; e->prof[pid] += __builtin_readcyclecounter() - profCu0; e->profCnt[pid] += 1; }
 #endif
@@ -2541,6 +2593,12 @@ HM_DEV HM_NOINLINE void compress_ctu(Shared *e)
         f->splitBits += num_bits(&e->cur);
       }
       f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
+      if (e->fb.dqp && cuDepth == 0 && first_coded_cu(e) < 256) {   // the split candidate of quantisation-group size pays for its delta QP, TEncCu.cpp:1052-1085
+        reset_bits(&e->cur);
+        code_delta_qp(e, &e->cur, HM_UNI(e->ws->dq.ctuQp) - HM_UNI(e->ws->dq.refQp));
+        f->splitBits += num_bits(&e->cur);
+        f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
+      }
       cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
       if (f->splitCost < f->bestCost) {
         f->bestCost = f->splitCost; f->bestBits = f->splitBits; f->bestDist = f->splitDist;
@@ -2590,7 +2648,7 @@ template <class C> HM_DEV HM_NOINLINE void encode_ctu(Shared *e, C *c, int lastC
     if (stackNext[sp] < 0) {
       if (inside && depth != 3) enc_bin(e, c, C_SPLIT + ctx_split_flag(e, z, depth), m->depth[z] > depth);
       if (!((depth < m->depth[z] && depth < 3) || !inside)) {
-        if (m->pred[z] == MODE_INTER) encode_cu_syntax_inter(e, c, z, depth); else encode_cu_syntax(e, c, z, depth);
+        if (m->pred[z] == MODE_INTER) encode_cu_syntax_inter(e, c, z, depth, 1); else encode_cu_syntax(e, c, z, depth);
         // finishCU, TEncCu.cpp:1130-1147
         const int lastX = ((lx + size) % 64 == 0) || (lx + size == e->width), lastY = ((ty + size) % 64 == 0) || (ty + size == e->height);
         if (lastX && lastY && !lastCtuOfSlice) enc_trm(e, c, 0);
@@ -2615,7 +2673,7 @@ template <class C> HM_DEV HM_NOINLINE void encode_ctu(Shared *e, C *c, int lastC
 HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, int wsIndex, Team *team = 0)
 {
   // uniform context (every lane writes the same values)
-  e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab; e->team = team;
+  e->P = P; e->fb = P->frames[it->frame]; e->ws = P->ws + wsIndex; e->tab = P->tab;
   e->width = P->width; e->height = P->height; e->bitDepth = P->bitDepth; e->wCtu = P->wCtu; e->mpmZ = -1; e->s8Reuse = 0;
   for (int c = 0; c < 3; c++) e->stride[c] = P->stride[c];
   e->ctuX = it->ctuX; e->ctuY = it->ctuY; e->ctuAddr = it->ctuY * P->wCtu + it->ctuX;
@@ -2647,12 +2705,28 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     HM_SYNC();
     if (e->im) init_est_data_inter(e, 0, 0);
   }
+  const int sliceQp = e->fb.qp;
+  if (e->fb.dqp) {
+    // cu_qp_delta: the QP of this CTU (TEncCu::xComputeQP :1154 / the rate control's, TEncSlice.cpp:767-808) replaces the slice's in the quantiser
+    // parameters; its predictor is the QP of the last CU coded before it in this CTU row / slice (both neighbouring quantisation groups lie
+    // outside the CTU: TComDataCU::getRefQP :1413, getLastCodedQP :1434-1468); TEncCu::m_bEncodeDQP arrives from the previous CTU in coding order
+    const DqpPic *dp = e->fb.dqp;
+    const int rowStart = e->ctuX == 0 && P->wpp;
+    const int q = dp->ctuQp[a];
+    const int refQp = (a == 0 || rowStart) ? sliceQp : dp->out[a - 1].lastQp;
+    const int flag = a == 0 ? dp->flagIn : (rowStart ? dp->rowFlag[e->ctuY] : dp->out[a - 1].flagOut);
+    const QpTab *t = &dp->tab[q + 12];
+    e->fb.qp = q;
+    for (int k = 0; k < 2; k++) { e->fb.qpPer[k] = t->qpPer[k]; e->fb.qpRem[k] = t->qpRem[k]; e->fb.rdFactor[k] = t->rdFactor[k]; for (int l = 0; l < 4; l++) e->fb.errScale[k][l] = t->errScale[k][l]; }
+    if (hm_lane() == 0) { e->ws->dq.ctuQp = q; e->ws->dq.refQp = refQp; e->ws->dq.flag = flag; }
+    HM_SYNC();
+  }
   // CABAC state hand-off (TEncSlice.cpp:733-761)
   Cabac *cb0 = &e->ws->slot[HM_SLOT(0, CI_CURR_BEST)];
   const int initType = e->im ? e->fb.ip->cabacInitType : 2;   // context table of the slice type (TEncSbac::resetEntropy :106-115)
-  if (a == 0) cabac_init(cb0, e->fb.qp, initType);
+  if (a == 0) cabac_init(cb0, sliceQp, initType);
   else if (e->ctuX == 0 && P->wpp) {
-    cabac_init(cb0, e->fb.qp, initType);
+    cabac_init(cb0, sliceQp, initType);
     if (e->ctuY > 0 && P->wCtu > 1) { // contexts of the 2nd CTU of the row above, fresh bit accumulator
       const Cabac *src = e->fb.endState + ((e->ctuY - 1) * P->wCtu + 1);
       HM_PAR_FOR(i, HM_NUM_CTX) cb0->s[i] = src->s[i];
@@ -2661,7 +2735,9 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   } else cabac_copy(cb0, e->fb.endState + (a - 1));
   cabac_copy(&e->cur, cb0);
 #if !defined(HM355_HOSTSIM)
-  if (team) compress_ctu_team(e); else
+  // (a team hands the 64x64 candidate to a helper while it goes on: with m_bEncodeDQP set the later candidates would need to know whether that
+  // one consumed it, so such a CTU -- rare -- is searched by the main wavefront alone)
+  if (team && !(e->fb.dqp && HM_UNI(e->ws->dq.flag))) compress_ctu_team(e); else
 #endif
   compress_ctu(e);
   e->fb.stat[a].cost = e->outCost; e->fb.stat[a].bits = e->outBits; e->fb.stat[a].dist = e->outDist;
@@ -2669,8 +2745,14 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   // run it on the LDS-resident coder and hand the end state to the next CTU
   cabac_copy(&e->cur, cb0);
   reset_bits(&e->cur);
+  if (e->fb.dqp) { if (hm_lane() == 0) e->ws->dq.flag = 1; HM_SYNC(); }      // TEncCu::encodeCtu :358-361
   encode_ctu(e, &e->cur, a == numCtus - 1);
   cabac_copy(e->fb.endState + a, &e->cur);
+  if (e->fb.dqp) {
+    const int firstZ = first_coded_cu(e), q = HM_UNI(e->ws->dq.ctuQp), refQp = HM_UNI(e->ws->dq.refQp), flag = HM_UNI(e->ws->dq.flag);
+    if (hm_lane() == 0) { CtuDqp o; o.qp = (int8_t)q; o.refQp = (int8_t)refQp; o.lastQp = (int8_t)(firstZ < 256 ? q : refQp); o.flagOut = (uint8_t)flag; o.firstZ = (int16_t)firstZ; o.pad = 0; e->fb.dqp->out[a] = o; }
+    HM_SYNC();
+  }
   if (e->im) { HM_PAR_FOR(i, 32) e->fb.intMv[(size_t)a * 32 + i] = e->ws->intMv[i >> 4][i & 15]; HM_SYNC(); }   // carried to the next CTU in coding order
   { // decision arrays back to HBM (TComDataCU::copyToPic of the whole CTU)
     const uint32_t *src = (const uint32_t *)&e->meta; uint32_t *dst = (uint32_t *)(e->fb.meta + a);

@@ -59,6 +59,20 @@ HM_DEV inline int dbk_bs(const Params *P, const FrameBuf *fb, const DbkParams *d
 #undef HM_DBK_FAR
 }
 
+// QP of the edge between the partition (x4, y4) and its left (dir 0) / upper (dir 1) neighbour: (QP_P + QP_Q + 1) >> 1 of the two CUs
+// (xEdgeFilterLuma :582-586).  Without cu_qp_delta every CU carries the slice QP.
+HM_DEV inline int dbk_part_qp(const Params *P, const FrameBuf *fb, int x4, int y4)
+{
+  const int a = (y4 >> 4) * P->wCtu + (x4 >> 4), z = hm_r2z((y4 & 15) * 16 + (x4 & 15));
+  const CtuDqp d = fb->dqp->out[a];
+  return z < d.firstZ ? d.refQp : d.qp;
+}
+HM_DEV inline int dbk_edge_qp(const Params *P, const FrameBuf *fb, const DbkParams *dp, int dir, int x4, int y4)
+{
+  if (!fb->dqp) return dp->qp;
+  return (dbk_part_qp(P, fb, x4 - (dir == 0), y4 - (dir == 1)) + dbk_part_qp(P, fb, x4, y4) + 1) >> 1;
+}
+
 // one luma edge segment: 4 lines of 8 samples across the edge; s[line][0..7] = p3 p2 p1 p0 | q0 q1 q2 q3 (xEdgeFilterLuma :540, xPelFilterLuma :800)
 HM_DEV inline void dbk_filter_luma4(int s[4][8], int bs, int qp, int bd)
 {
@@ -121,7 +135,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dbk_kernel(const Params *
     for (int r = 0; r < 4; r++) { const uint4 v = *(const uint4 *)(p + r * st); const Pel *q = (const Pel *)&v;
 #pragma unroll
       for (int k = 0; k < 8; k++) s[r][k] = q[k]; }
-    dbk_filter_luma4(s, bs, dp->qp, bd);
+    dbk_filter_luma4(s, bs, dbk_edge_qp(P, fb, dp, 0, x >> 2, y >> 2), bd);
 #pragma unroll
     for (int r = 0; r < 4; r++) { uint4 v; Pel *q = (Pel *)&v;
 #pragma unroll
@@ -138,7 +152,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dbk_kernel(const Params *
     for (int k = 0; k < 8; k++) { const uint2 v = *(const uint2 *)(p + k * st); const Pel *q = (const Pel *)&v;
 #pragma unroll
       for (int r = 0; r < 4; r++) s[r][k] = q[r]; }
-    dbk_filter_luma4(s, bs, dp->qp, bd);
+    dbk_filter_luma4(s, bs, dbk_edge_qp(P, fb, dp, 1, x >> 2, y >> 2), bd);
 #pragma unroll
     for (int k = 1; k < 7; k++) { uint2 v; Pel *q = (Pel *)&v;
 #pragma unroll
@@ -149,7 +163,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dbk_kernel(const Params *
     if (x >= w || y >= h) return;
     const int bs = dbk_bs(P, fb, dp, 0, x >> 2, y >> 2);
     if (bs <= 1) return;
-    const int tc = dbk_chroma_tc(dp->qp, bs, bd), maxv = (1 << bd) - 1;
+    const int tc = dbk_chroma_tc(dbk_edge_qp(P, fb, dp, 0, x >> 2, y >> 2), bs, bd), maxv = (1 << bd) - 1;
     for (int c = 1; c < 3; c++) {
       const int st = P->stride[c]; Pel *p = fb->rec[c] + (size_t)(y >> 1) * st + (x >> 1);
 #pragma unroll
@@ -164,7 +178,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dbk_kernel(const Params *
     if (x >= w || y >= h) return;
     const int bs = dbk_bs(P, fb, dp, 1, x >> 2, y >> 2);
     if (bs <= 1) return;
-    const int tc = dbk_chroma_tc(dp->qp, bs, bd), maxv = (1 << bd) - 1;
+    const int tc = dbk_chroma_tc(dbk_edge_qp(P, fb, dp, 1, x >> 2, y >> 2), bs, bd), maxv = (1 << bd) - 1;
     for (int c = 1; c < 3; c++) {
       const int st = P->stride[c]; Pel *p = fb->rec[c] + (size_t)(y >> 1) * st + (x >> 1);
 #pragma unroll
@@ -174,6 +188,34 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dbk_kernel(const Params *
         q[-st] = (Pel)hm_clip3(0, maxv, m3 + delta); q[0] = (Pel)hm_clip3(0, maxv, m4 - delta);
       }
     }
+  }
+}
+
+// ---- TEncPreanalyzer::xPreanalyze (TEncPreanalyzer.cpp:64-139), layer 0, integer part: per CTU the sum and the sum of squares of the original
+// luma samples of its four quadrants (split at half of the unit's size inside the picture).  One wavefront per CTU, lanes along the rows
+// (coalesced 128-byte reads), 64-bit accumulators, butterfly reduction.  The caller derives activity = 1 + min "variance" and the QP offsets
+// in double precision exactly as the reference does (sums[a][0..3] = sum, [4..7] = sum of squares of quadrant TL, TR, BL, BR).
+extern "C" __global__ void __launch_bounds__(64) hm355_preanalyze_kernel(const Params *P, int frame, unsigned long long *sums)
+{
+  const FrameBuf *fb = P->frames + frame;
+  const int a = (int)blockIdx.x, cx = a % P->wCtu, cy = a / P->wCtu, lane = (int)threadIdx.x;
+  const int x0 = cx * 64, y0 = cy * 64;
+  const int w = P->width - x0 < 64 ? P->width - x0 : 64, h = P->height - y0 < 64 ? P->height - y0 : 64;
+  unsigned long long s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lane < w) {
+    const int right = lane >= (w >> 1);
+    const Pel *p = fb->org[0] + (size_t)y0 * P->stride[0] + x0 + lane;
+    for (int y = 0; y < h; y++) {
+      const int v = p[(size_t)y * P->stride[0]], k = (y >= (h >> 1) ? 2 : 0) + right;
+      s[k] += (unsigned long long)v; s[4 + k] += (unsigned long long)(v * v);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    unsigned long long v = s[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) sums[(size_t)a * 8 + k] = v;
   }
 }
 

@@ -1085,7 +1085,7 @@ template <class C> HM_DEV inline void code_pu_wise(Shared *e, C *c, int cuZ, int
 HM_DEV inline int qt_root_cbf(const CtuMeta *m, int z) { return (m->cbf[0][z] & 1) || (m->cbf[1][z] & 1) || (m->cbf[2][z] & 1); }
 
 // TEncEntropy::xEncodeTransform :222-412 for an inter CU (coefficients from the CTU arrays)
-template <class C> HM_DEV inline void encode_transform_inter(Shared *e, C *c, const TU *root)
+template <class C> HM_DEV inline void encode_transform_inter(Shared *e, C *c, const TU *root, int codeDqp)
 {
   const CtuMeta *m = &e->meta;
   TuWalk &w = e->walkOuter; walk_begin(&w, root);
@@ -1104,6 +1104,7 @@ template <class C> HM_DEV inline void encode_transform_inter(Shared *e, C *c, co
           if (first || ((m->cbf[comp][z] >> (t->trDepth - 1)) & 1)) code_qt_cbf(e, c, t, comp, subdiv == 0);
       if (!subdiv) {
         if (!(first && !(m->cbf[1][z] & 1) && !(m->cbf[2][z] & 1))) code_qt_cbf(e, c, t, 0, 1);
+        if (codeDqp && (((m->cbf[0][z] | m->cbf[1][z] | m->cbf[2][z]) >> t->trDepth) & 1)) code_dqp_if_due(e, c);
         for (int comp = 0; comp < 3; comp++) {
           if (comp && !t->cW) continue;
           if (!((m->cbf[comp][z] >> t->trDepth) & 1)) continue;
@@ -1121,10 +1122,10 @@ template <class C> HM_DEV inline void encode_transform_inter(Shared *e, C *c, co
     w.node[w.sp + 1] = tu_child(t, s, 1); w.next[w.sp + 1] = -1; w.sp++;
   }
 }
-// the whole inter CU: xAddSymbolBitsInter :5517 and xEncodeCU :1246-1290
-template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax_inter(Shared *e, C *c, int cuZ, int cuDepth)
+// the whole inter CU: xAddSymbolBitsInter :5517 (codeDqp 0: "Bool codeDeltaQp = false") and xEncodeCU :1246-1290 (codeDqp 1: TEncCu::m_bEncodeDQP decides)
+template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax_inter(Shared *e, C *c, int cuZ, int cuDepth, int codeDqp)
 {
-  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); c = hm_uni_ptr(c); HM_ASSUME_LDS(c);
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); codeDqp = HM_UNI(codeDqp); c = hm_uni_ptr(c); HM_ASSUME_LDS(c);
   const CtuMeta *m = &e->meta; const InterMeta *im = e->im;
   code_skip_flag(e, c, cuZ);
   if (im->skip[cuZ]) { code_merge_index(e, c, cuZ); return; }
@@ -1134,7 +1135,7 @@ template <class C> HM_DEV HM_NOINLINE void encode_cu_syntax_inter(Shared *e, C *
   if (!(im->mrg[cuZ] && m->part[cuZ] == SIZE_2Nx2N)) enc_bin(e, c, C_ROOT_CBF, qt_root_cbf(m, cuZ));
   if (!qt_root_cbf(m, cuZ)) return;
   const TU root = tu_root(e, cuZ, cuDepth);
-  encode_transform_inter(e, c, &root);
+  encode_transform_inter(e, c, &root, codeDqp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1434,7 +1435,7 @@ HM_DEV HM_NOINLINE void encode_res_and_calc_rd_inter(Shared *e, int cuZ, int cuD
   cabac_copy(&e->cur, &ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
   if (im->mrg[cuZ] && m->part[cuZ] == SIZE_2Nx2N && !qt_root_cbf(m, cuZ)) par_set8(im->skip + cuZ, 1, parts);
   reset_bits(&e->cur);
-  encode_cu_syntax_inter(e, &e->cur, cuZ, cuDepth);
+  encode_cu_syntax_inter(e, &e->cur, cuZ, cuDepth, 0);
   bits = num_bits(&e->cur);
   for (int c = 0; c < 3; c++) {
     const int sh = c ? 1 : 0, st = HM_PLANE_STRIDE(c), po = HM_PLANE_OFF(c), nn = n >> sh, ll = l2 - sh, o0 = po + (y0 >> sh) * st + (x0 >> sh);

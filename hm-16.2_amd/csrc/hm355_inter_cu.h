@@ -36,6 +36,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_merge_2Nx2N(Shared *e, int cuZ, int cuDept
       { HM_PROF_BEGIN(e, PR_IRES); encode_res_and_calc_rd_inter(e, cuZ, cuDepth, noResidual != 0); HM_PROF_END(e, PR_IRES); }
       if (noResidual == 0 && !qt_root_cbf(m, cuZ)) mergeCandBuffer[cand] = 1;
       par_set8(im->skip + cuZ, !qt_root_cbf(m, cuZ), parts);
+      check_dqp(e, cuZ, cuDepth);                                 // TEncCu.cpp:1500-1502
       check_best_mode(e, f, cuZ, cuDepth);
       init_est_data(e, cuZ, cuDepth);
       if (!bestIsSkip) bestIsSkip = f->bestCost < HM_MAX_DOUBLE && !qt_root_cbf(&e->ws->best[cuDepth].m, cuZ);   // FDM
@@ -51,6 +52,7 @@ HM_DEV HM_NOINLINE void check_rd_cost_inter(Shared *e, int cuZ, int cuDepth, int
   par_set8(m->part + cuZ, partSize, parts); par_set8(m->pred + cuZ, MODE_INTER, parts);
   pred_inter_search(e, cuZ, cuDepth, partSize, useMRG);
   { HM_PROF_BEGIN(e, PR_IRES); encode_res_and_calc_rd_inter(e, cuZ, cuDepth, 0); HM_PROF_END(e, PR_IRES); }
+  check_dqp(e, cuZ, cuDepth);                                     // TEncCu.cpp:1563
   check_best_mode(e, f, cuZ, cuDepth);
 }
 // the mode tests of one CU in a P / B slice (TEncCu::xCompressCU :600-857 with ESD/CFM/ECU off)

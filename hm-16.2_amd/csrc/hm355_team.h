@@ -38,6 +38,8 @@ struct Team {
   WorkItem item;
 };
 
+__shared__ Team g_team;               // only the team kernel (hm355_ctu_team_kernel) reaches it
+#define HM_TEAM_PTR() (&g_team)
 __device__ __forceinline__ uint32_t team_ld(const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void team_st(uint32_t *p, uint32_t v) { if (hm_lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define HM_TEAM_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -46,7 +48,7 @@ __device__ __forceinline__ void team_st(uint32_t *p, uint32_t v) { if (hm_lane()
 // ---- main wavefront ----
 HM_DEV inline void team_post(Shared *e, int h, int cuZ, int depth, int part)
 {
-  TeamBox *b = &e->team->box[h];
+  TeamBox *b = &HM_TEAM_PTR()->box[h];
   if (hm_lane() == 0) { b->cuZ = cuZ; b->depth = depth; b->part = part; }
   const uint32_t seq = team_ld(&b->reqSeq) + 1u;
   HM_TEAM_RELEASE();
@@ -54,7 +56,7 @@ HM_DEV inline void team_post(Shared *e, int h, int cuZ, int depth, int part)
 }
 HM_DEV inline int team_ready(Shared *e, int h)
 {
-  TeamBox *b = &e->team->box[h];
+  TeamBox *b = &HM_TEAM_PTR()->box[h];
   if (team_ld(&b->doneSeq) != team_ld(&b->reqSeq)) return 0;
   HM_TEAM_ACQUIRE();
   return 1;
@@ -62,7 +64,7 @@ HM_DEV inline int team_ready(Shared *e, int h)
 HM_DEV HM_NOINLINE void team_wait(Shared *e, int h)
 {
   HM_ENTRY(e); h = HM_UNI(h);
-  Team *T = e->team; TeamBox *b = &T->box[h];
+  Team *T = HM_TEAM_PTR(); TeamBox *b = &T->box[h];
   const uint32_t want = team_ld(&b->reqSeq);
   const unsigned long long t0 = wall_clock64();
   while (team_ld(&b->doneSeq) != want) {
@@ -112,7 +114,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
           check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN);
           const double cN = e->outCost; const uint32_t bN = e->outBits, dN = e->outDist;
           team_wait(e, 3); pending[3] = 0;
-          const TeamBox *b = &e->team->box[3];
+          const TeamBox *b = &HM_TEAM_PTR()->box[3];
           f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
           if (cN < f->bestCost) {
             f->bestCost = cN; f->bestBits = bN; f->bestDist = dN;
@@ -149,10 +151,16 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
         f->splitBits += num_bits(&e->cur);
       }
       f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
+      if (e->fb.dqp && cuDepth == 0 && first_coded_cu(e) < 256) {   // the split candidate of quantisation-group size pays for its delta QP, TEncCu.cpp:1052-1085
+        reset_bits(&e->cur);
+        code_delta_qp(e, &e->cur, HM_UNI(e->ws->dq.ctuQp) - HM_UNI(e->ws->dq.refQp));
+        f->splitBits += num_bits(&e->cur);
+        f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
+      }
       cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
       if (pending[cuDepth]) {
         team_wait(e, cuDepth); pending[cuDepth] = 0;
-        const TeamBox *b = &e->team->box[cuDepth];
+        const TeamBox *b = &HM_TEAM_PTR()->box[cuDepth];
         f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
       }
       if (f->splitCost < f->bestCost) {
@@ -166,7 +174,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
       // the exact early stop of compress_ctu (same conditions), applied when the unsplit result is already there
       if (pending[cuDepth] && team_ready(e, cuDepth)) {
         pending[cuDepth] = 0;
-        const TeamBox *b = &e->team->box[cuDepth];
+        const TeamBox *b = &HM_TEAM_PTR()->box[cuDepth];
         f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
       }
       bool laterSibling = sp == 0;
@@ -191,11 +199,12 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
 // the uniform per-CTU context of the main wavefront, with private places for everything a candidate writes
 HM_DEV inline void team_adopt(Shared *e, const Shared *mainSh, int h, Pel *win)
 {
-  e->P = mainSh->P; e->fb = mainSh->fb; e->tab = mainSh->tab; e->team = mainSh->team;
+  e->P = mainSh->P; e->fb = mainSh->fb; e->tab = mainSh->tab;
   e->width = mainSh->width; e->height = mainSh->height; e->bitDepth = mainSh->bitDepth; e->wCtu = mainSh->wCtu;
   for (int c = 0; c < 3; c++) e->stride[c] = mainSh->stride[c];
   e->ctuX = mainSh->ctuX; e->ctuY = mainSh->ctuY; e->ctuAddr = mainSh->ctuAddr;
   e->ws = mainSh->ws + 1 + h; e->cc = e->ws->teamCoef; e->im = (InterMeta *)0; e->mpmZ = -1; e->s8Reuse = 0;
+  if (e->fb.dqp && hm_lane() == 0) e->ws->dq = mainSh->ws->dq;    // QP of the CTU, its predictor (m_bEncodeDQP is clear whenever a team searches)
   // the window: rows [ctuY * S - 1, ctuY * S + S) of a plane with the picture's stride, addressed like the picture
   Pel *w = win;
   for (int c = 0; c < 3; c++) {

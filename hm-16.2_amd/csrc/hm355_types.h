@@ -13,7 +13,7 @@ enum {
   C_SPLIT = 0, C_PART = 3, C_INTRA_LUMA = 7, C_CHROMA_PRED = 8, C_SUBDIV = 10, C_QT_CBF = 13, C_SIG_CG = 23,
   C_SIG = 27, C_LASTX = 71, C_LASTY = 101, C_ONE = 131, C_ABS = 155, C_TSKIP = 161,
   /* inter syntax */ C_SKIP = 163, C_MRG_FLAG = 166, C_MRG_IDX = 167, C_PRED_MODE = 168, C_INTER_DIR = 169, C_MVD = 174, C_REF = 176,
-  C_ROOT_CBF = 178, C_MVP_IDX = 179, HM_NUM_CTX = 180
+  C_ROOT_CBF = 178, C_MVP_IDX = 179, /* cu_qp_delta_abs */ C_DQP = 180, HM_NUM_CTX = 183
 };
 struct Cabac {
   uint8_t s[184];          // HM_NUM_CTX used, padded to 8-byte multiple
@@ -90,7 +90,23 @@ struct WorkSpace {
   } ps;
   struct { MvD mv[5][2]; int32_t ref[5][2]; uint8_t dir[5]; int32_t num; } mrg2N;   // merge list of xCheckRDCostMerge2Nx2N (outlives the per-PU list in LDS)
   uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
+  struct { int32_t ctuQp, refQp, flag, pad; } dq;   // cu_qp_delta: QP of the CTU under search, its predictor, TEncCu::m_bEncodeDQP
   TCoeff teamCoef[HM_COEF_CTU];      // a team helper's private coefficient area (the team's main wavefront works in the picture's own, hm355_team.h)
+};
+
+// ---- cu_qp_delta (adaptive QP / rate control; MaxCuDQPDepth 0, i.e. one quantisation group per CTU) ----
+struct QpTab { int32_t qpPer[2], qpRem[2]; double errScale[2][4]; int64_t rdFactor[2]; };   // what hm355_fill_slice_params derives from one QP
+struct CtuDqp {                      // what a searched CTU leaves for the next CTU, the loop filter and the bitstream pass
+  int8_t qp, refQp, lastQp;          // its QP, the predictor (TComDataCU::getRefQP), the QP of its last coded CU (getLastCodedQP of the next CTU)
+  uint8_t flagOut;                   // TEncCu::m_bEncodeDQP after its encodeCtu
+  int16_t firstZ, pad;               // first CU (z order) with a coded block, 256 if none: partitions before it carry refQp, the rest qp (m_phQP)
+};
+struct DqpPic {
+  int32_t flagIn, sliceQp;           // m_bEncodeDQP on entry to the slice
+  const int8_t *ctuQp;               // [numCtus] QP of every CTU (TEncCu::xComputeQP / TEncRateCtrl::getRCQP)
+  CtuDqp *out;                       // [numCtus]
+  const uint8_t *rowFlag;            // [hCtu] WaveFrontSynchro: m_bEncodeDQP assumed at the first CTU of each row (checked by the host afterwards)
+  QpTab tab[64];                     // indexed by QP + 12
 };
 
 // lookup tables generated on the host at create time (scan orders: TComRom.cpp:52-225)
@@ -111,6 +127,7 @@ struct FrameBuf {
   InterMeta *imeta;                  // [numCtus] (P / B slices; NULL for I slices)
   InterPic *ip;                      // slice-level inter parameters (NULL for I slices)
   MvD *intMv;                        // [numCtus][2][16] m_integerMv2Nx2N as each CTU left it (carried in coding order)
+  DqpPic *dqp;                       // cu_qp_delta state of the picture (NULL: disabled, every CU at the slice QP)
   // slice parameters (TEncSlice::setUpLambda, TEncSlice.cpp:132-159)
   double lambda, sqrtLambda, lambdaC, chromaWeight;
   double errScale[2][4];             // [luma/chroma][log2-2]  TComTrQuant::setErrScaleCoeff :2933

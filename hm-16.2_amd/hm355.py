@@ -70,13 +70,17 @@ class SaoDesc(C.Structure):
                 ("disabled_rate", (C.c_double * 8) * 3), ("enabled", C.c_int32 * 3), ("params", C.c_void_p)]
 
 
+class DqpDesc(C.Structure):
+    _fields_ = [("use_dqp", C.c_int32), ("dqp_flag_in", C.c_int32), ("ctu_qp", C.c_void_p)]
+
+
 class BitsDesc(C.Structure):
     _fields_ = [("slice_type", C.c_int32), ("qp", C.c_int32), ("cabac_init_type", C.c_int32), ("num_ref_idx", C.c_int32 * 2), ("mvd_l1_zero", C.c_int32),
                 ("max_merge_cand", C.c_int32), ("sao_enabled", C.c_int32 * 2), ("out", C.c_void_p), ("out_cap", C.c_size_t), ("sub_sizes", C.c_void_p),
                 ("next_cabac_init_type", C.c_int32), ("num_bins", C.c_uint32)]
 
 
-EXPORTS = ["hm355_build_id", "hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
+EXPORTS = ["hm355_build_id", "hm355_set_dqp", "hm355_get_dqp", "hm355_preanalyze", "hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
            "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_sao_run",
            "hm355_num_substreams", "hm355_encode_slices_run", "hm355_encode_slice",
            "hm355_upload_file_frames", "hm355_download_file_frames", "hm355_download_org",
@@ -100,6 +104,9 @@ def load_library(path=LIB_PATH):
     lib.hm355_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SliceDesc)]
     lib.hm355_run_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(SliceDesc)]
     lib.hm355_run_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    lib.hm355_set_dqp.argtypes = [C.c_void_p, C.c_int, C.POINTER(DqpDesc)]
+    lib.hm355_get_dqp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.hm355_preanalyze.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.hm355_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(Planes), C.c_void_p, C.POINTER(SliceStats)]
     lib.hm355_run_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(SliceDesc), C.c_int, C.c_int]
     lib.hm355_boundary_bytes.argtypes = [C.c_void_p]
@@ -139,6 +146,36 @@ def intra_lambda(qp):
     lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
     qpc = chroma_scale[min(max(qp, 0), 57)]
     return lam, 2.0 ** ((qp - qpc) / 3.0)
+
+
+def aq_activities(sums):
+    """TEncPreanalyzer::xPreanalyze (TEncPreanalyzer.cpp:117-137) from the per-CTU quadrant sums hm355_preanalyze returns: activity per CTU
+    (1 + the smallest quadrant "variance", every quadrant's sums divided by the sample count of the WHOLE unit, as the reference does) and
+    the average (running sum in raster order / number of units)."""
+    import math
+    act = np.zeros(len(sums), np.float64)
+    total = 0.0
+    for a, s in enumerate(sums):
+        n = int(s[8])
+        mv = math.inf
+        for k in range(4):
+            avg = float(int(s[k])) / n
+            mv = min(mv, float(int(s[4 + k])) / n - avg * avg)
+        act[a] = 1.0 + mv
+        total += act[a]
+    return act, total / len(sums)
+
+
+def aq_ctu_qp(act, avg, aq_range, slice_qp, bit_depth):
+    """TEncCu::xComputeQP (TEncCu.cpp:1154-1176) for every CTU -> int8 array"""
+    import math
+    out = np.zeros(len(act), np.int8)
+    max_q_scale = math.pow(2.0, aq_range / 6.0)
+    for a, d in enumerate(act):
+        norm = (max_q_scale * d + avg) / (d + max_q_scale * avg)
+        off = int(math.floor(math.log(norm) / math.log(2.0) * 6.0 + 0.49999))
+        out[a] = min(51, max(-6 * (bit_depth - 8), slice_qp + off))
+    return out
 
 
 def _planes(arrs):
@@ -191,6 +228,27 @@ class Encoder:
         ms, launches = C.c_double(), C.c_int()
         self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
         return ms.value, launches.value
+
+    def set_dqp(self, slot, ctu_qp=None, dqp_flag_in=0, use_dqp=1):
+        """hm355_set_dqp: the following searches / deblocking / bitstream pass of the slot run with cu_qp_delta; ctu_qp int8 [numCtus] or None"""
+        q = np.ascontiguousarray(ctu_qp, np.int8) if ctu_qp is not None else None
+        assert q is None or len(q) == self.num_ctus
+        d = DqpDesc(int(use_dqp), int(dqp_flag_in), q.ctypes.data if q is not None else None)
+        self._check(self.lib.hm355_set_dqp(self.h_, slot, C.byref(d)), "hm355_set_dqp")
+
+    def get_dqp(self, slot):
+        """hm355_get_dqp -> (m_phQP int8 (numCtus, 256), m_bEncodeDQP after the slice)"""
+        qp = np.zeros((self.num_ctus, 256), np.int8); f = C.c_int32(-1)
+        self._check(self.lib.hm355_get_dqp(self.h_, slot, qp.ctypes.data, C.byref(f)), "hm355_get_dqp")
+        return qp, f.value
+
+    def preanalyze(self, slot):
+        """hm355_preanalyze -> uint64 (numCtus, 9): the eight quadrant sums of every CTU and, last, the number of samples of the unit inside the picture"""
+        s = np.zeros((self.num_ctus, 8), np.uint64)
+        self._check(self.lib.hm355_preanalyze(self.h_, slot, s.ctypes.data), "hm355_preanalyze")
+        wc = (self.w + 63) // 64
+        n = np.array([min(64, self.w - (a % wc) * 64) * min(64, self.h - (a // wc) * 64) for a in range(self.num_ctus)], np.uint64)
+        return np.concatenate([s, n[:, None]], axis=1)
 
     def run_begin(self, lane, first_slot, n, qp):
         """enqueue the search over slots [first_slot, first_slot + n) on pipeline lane `lane`; returns at once (hm355_run_begin)"""

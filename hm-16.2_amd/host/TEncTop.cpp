@@ -1,4 +1,5 @@
 #include "TEncTop.h"
+#include <algorithm>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -39,6 +40,7 @@ Void TEncTop::encode(Bool flush, TComPicYuv *pcPicYuvOrg, std::list<TComPic *> &
              sizeof(uint16_t) * pcPicYuvOrg->getWidth(ComponentID(c)) * pcPicYuvOrg->getHeight(ComponentID(c)));
     m_iPOCLast++; m_iNumPicRcvd++;
     pic->getSlice(0)->setPOC(m_iPOCLast);
+    if (getUseAdaptiveQP()) { m_cPreanalyzer.init(this); m_cPreanalyzer.xPreanalyze(pic); }   // TEncTop.cpp:271-274
     m_cListPic.push_back(pic);
   }
   if (!m_iNumPicRcvd || (!flush && m_iPOCLast != 0 && m_iNumPicRcvd != m_iGOPSize && m_iGOPSize)) return;   // TEncTop.cpp:277: POC 0 goes alone
@@ -252,9 +254,49 @@ Void TEncSlice::encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, U
   numBinsCoded = bd.num_bins;
   m_pcEncTop->setEncCABACTableIdx(bd.next_cabac_init_type);               // determineCabacInitIdx, TEncSlice.cpp:1083-1093 (cabac_init_present_flag)
 }
+// TEncPreanalyzer.cpp:64-139 for the CTU-sized units of layer 0
+Void TEncPreanalyzer::xPreanalyze(TComPic *pcPic)
+{
+  hm355_ctx *ctx = m_pcEncTop->getDeviceContext();
+  hm355_planes org; for (Int c = 0; c < 3; c++) org.plane[c] = pcPic->getPicYuvOrg()->getAddr(ComponentID(c));
+  const UInt n = pcPic->getNumberOfCtusInFrame();
+  std::vector<uint64_t> sums((size_t)n * 8);
+  if (hm355_upload(ctx, 0, &org) != HM355_OK || hm355_preanalyze(ctx, 0, sums.data()) != HM355_OK) { fprintf(stderr, "TEncPreanalyzer::xPreanalyze: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
+  const Int w = m_pcEncTop->getSourceWidth(), h = m_pcEncTop->getSourceHeight(), wCtu = (w + 63) / 64;
+  std::vector<Double> &act = pcPic->getAQActivities(); act.assign(n, 0.0);
+  Double dSumAct = 0.0;
+  for (UInt a = 0; a < n; a++) {
+    const Int cw = std::min(64, w - (Int)(a % wCtu) * 64), ch = std::min(64, h - (Int)(a / wCtu) * 64);
+    const UInt uiNumPixInAQPart = (UInt)(cw * ch);
+    Double dMinVar = 1.7976931348623157e308;
+    for (Int i = 0; i < 4; i++) {
+      const Double dAverage = Double(sums[(size_t)a * 8 + i]) / uiNumPixInAQPart;
+      const Double dVariance = Double(sums[(size_t)a * 8 + 4 + i]) / uiNumPixInAQPart - dAverage * dAverage;
+      dMinVar = std::min(dMinVar, dVariance);
+    }
+    act[a] = 1.0 + dMinVar;
+    dSumAct += act[a];
+  }
+  pcPic->setAvgActivity(dSumAct / n);
+}
+Int TEncSlice::xComputeQP(TComPic *pcPic, UInt ctuRsAddr, Int sliceQp)
+{
+  const Double dMaxQScale = pow(2.0, m_pcEncTop->getQPAdaptationRange() / 6.0);
+  const Double dAvgAct = pcPic->getAvgActivity(), dCUAct = pcPic->getAQActivities()[ctuRsAddr];
+  const Double dNormAct = (dMaxQScale * dCUAct + dAvgAct) / (dCUAct + dMaxQScale * dAvgAct);
+  const Double dQpOffset = log(dNormAct) / log(2.0) * 6.0;
+  const Int iQpOffset = Int(floor(dQpOffset + 0.49999));
+  return std::min(51, std::max(-6 * (m_pcEncTop->getInternalBitDepth() - 8), sliceQp + iQpOffset));
+}
 Void TEncSlice::compressSlice(TComPic *pcPic)
 {
   TComSlice *pcSlice = pcPic->getSlice(0);
+  if (m_pcEncTop->getUseAdaptiveQP()) { // cu_qp_delta is on (TEncTop::xInitPPS :608-622): every CTU at its xComputeQP, TEncCu::m_bEncodeDQP handed in
+    std::vector<int8_t> qp(pcPic->getNumberOfCtusInFrame());
+    for (UInt a = 0; a < pcPic->getNumberOfCtusInFrame(); a++) qp[a] = (int8_t)xComputeQP(pcPic, a, pcSlice->getSliceQp());
+    hm355_dqp_desc dq; dq.use_dqp = 1; dq.dqp_flag_in = m_bEncodeDQP ? 1 : 0; dq.ctu_qp = qp.data();
+    if (hm355_set_dqp(m_pcEncTop->getDeviceContext(), 0, &dq) != HM355_OK) { fprintf(stderr, "TEncSlice::compressSlice: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
+  }
   if (!pcSlice->isIntra()) { // P / B slice: the reference pictures are device-resident (hm355_ref_from_slot)
     hm355_inter_slice_desc d; memset(&d, 0, sizeof(d));
     d.base.slice_type = (int32_t)pcSlice->getSliceType(); d.base.qp = pcSlice->getSliceQp(); d.base.lambda = m_dLambda; d.base.chroma_weight = m_dChromaWeight;
@@ -272,6 +314,7 @@ Void TEncSlice::compressSlice(TComPic *pcPic)
     const int rc = hm355_compress_slice_inter(m_pcEncTop->getDeviceContext(), &d, &org, &rec, pcPic->getCtu(0), pcPic->getCtuInter(0), &st);
     if (rc != HM355_OK) { fprintf(stderr, "TEncSlice::compressSlice: device path failed (%d): %s\n", rc, hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
     m_uiPicTotalBits = st.pic_total_bits; m_dPicRdCost = st.pic_rd_cost; m_uiPicDist = st.pic_dist;
+    if (m_pcEncTop->getUseAdaptiveQP()) { int32_t f = 0; hm355_get_dqp(m_pcEncTop->getDeviceContext(), 0, NULL, &f); m_bEncodeDQP = f != 0; }
     return;
   }
   hm355_slice_desc sd; sd.slice_type = (int32_t)pcSlice->getSliceType(); sd.qp = pcSlice->getSliceQp(); sd.lambda = m_dLambda; sd.chroma_weight = m_dChromaWeight;
@@ -281,4 +324,5 @@ Void TEncSlice::compressSlice(TComPic *pcPic)
   const int rc = hm355_compress_slice(m_pcEncTop->getDeviceContext(), &sd, &org, &rec, pcPic->getCtu(0), &st);
   if (rc != HM355_OK) { fprintf(stderr, "TEncSlice::compressSlice: device path failed (%d): %s\n", rc, hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
   m_uiPicTotalBits = st.pic_total_bits; m_dPicRdCost = st.pic_rd_cost; m_uiPicDist = st.pic_dist;     // TEncSlice.cpp:889-891
+  if (m_pcEncTop->getUseAdaptiveQP()) { int32_t f = 0; hm355_get_dqp(m_pcEncTop->getDeviceContext(), 0, NULL, &f); m_bEncodeDQP = f != 0; }
 }

@@ -91,7 +91,10 @@ public:
   Void setReconMark(Bool b) { m_reconMark = b; } Bool getReconMark() const { return m_reconMark; }
   Void setTLayer(Int t) { m_tLayer = t; } Int getTLayer() const { return m_tLayer; }
   Void setDeviceRef(hm355_ref *r) { m_devRef = r; } hm355_ref *getDeviceRef() const { return m_devRef; }   // the finished picture as a device-resident reference
+  // TEncPic (TEncPic.h:100-112), layer 0 of the QP adaptation: one activity per CTU and their average (TEncPreanalyzer::xPreanalyze)
+  std::vector<Double> &getAQActivities() { return m_aqAct; } Void setAvgActivity(Double d) { m_aqAvg = d; } Double getAvgActivity() const { return m_aqAvg; }
 private:
+  std::vector<Double> m_aqAct; Double m_aqAvg = 0;
   TComPicYuv m_org, m_rec; TComSlice m_slice; std::vector<hm355_ctu_out> m_ctus; std::vector<TComOutputBitstream> m_substreams;
   std::vector<hm355_ctu_inter_out> m_ictus; Bool m_reconMark = false; hm355_ref *m_devRef = nullptr; Int m_tLayer = 0;
 };
@@ -108,6 +111,8 @@ public:
   Void setMaxNumMergeCand(UInt n) { m_maxNumMergeCand = n; } UInt getMaxNumMergeCand() const { return m_maxNumMergeCand; }
   Void setTMVPModeId(Int m) { m_TMVPModeId = m; } Int getTMVPModeId() const { return m_TMVPModeId; }
   Int getFramesToBeEncoded() const { return m_framesToBeEncoded; }
+  Void setUseAdaptiveQP(Bool b) { m_bUseAdaptiveQP = b; } Bool getUseAdaptiveQP() const { return m_bUseAdaptiveQP; }                  // --AdaptiveQP
+  Void setQPAdaptationRange(Int r) { m_iQPAdaptationRange = r; } Int getQPAdaptationRange() const { return m_iQPAdaptationRange; }   // --MaxQPAdaptationRange
   Void setSourceWidth(Int v) { m_iSourceWidth = v; } Void setSourceHeight(Int v) { m_iSourceHeight = v; }
   Void setInternalBitDepth(Int v) { m_bitDepth = v; } Void setQP(Int v) { m_iQP = v; }
   Void setIntraPeriod(Int v) { m_uiIntraPeriod = v; } Void setGOPSize(Int v) { m_iGOPSize = v; }
@@ -120,6 +125,7 @@ public:
 protected:
   Int m_iSourceWidth = 0, m_iSourceHeight = 0, m_bitDepth = 8, m_iQP = 32, m_uiIntraPeriod = 1, m_iGOPSize = 1, m_iWaveFrontSynchro = 0, m_framesToBeEncoded = 0;
   Bool m_bLoopFilterDisable = true, m_bUseSAO = false;      // the loop filters are opt-in here (the reference's cfg files switch both on)
+  Bool m_bUseAdaptiveQP = false; Int m_iQPAdaptationRange = 6;
   GOPEntry m_GOPList[16]; Bool m_bUseHADME = true; UInt m_maxNumMergeCand = 5; Int m_TMVPModeId = 1;
 };
 
@@ -134,13 +140,15 @@ public:
   const Double *getLambdas() const { return m_dLambdas; }                            // TComSlice::getLambdas of the current slice
   Void precompressSlice(TComPic *) {}                                                // DeltaQpRD = 0 in every config: no-op
   Void compressSlice(TComPic *pcPic);                                                // TEncSlice.cpp:640 -> hm355_compress_slice
+  Int xComputeQP(TComPic *pcPic, UInt ctuRsAddr, Int sliceQp);                       // TEncCu::xComputeQP, TEncCu.cpp:1154 (the CTU-level unit of MaxCuDQPDepth 0)
+  Void setdQPFlag(Bool b) { m_bEncodeDQP = b; } Bool getdQPFlag() const { return m_bEncodeDQP; }   // TEncCu::m_bEncodeDQP: carried from picture to picture
   Void encodeSlice(TComPic *pcPic, TComOutputBitstream *pcSubstreams, UInt &numBinsCoded);   // TEncSlice.cpp:910 -> hm355_encode_slices_run
   uint64_t getTotalBits() const { return m_uiPicTotalBits; }
   Double getPicRdCost() const { return m_dPicRdCost; }
   uint64_t getPicDist() const { return m_uiPicDist; }
 private:
   TEncTop *m_pcEncTop = nullptr;
-  Double m_dLambda = 0, m_dChromaWeight = 1, m_dLambdas[3] = {0, 0, 0};
+  Double m_dLambda = 0, m_dChromaWeight = 1, m_dLambdas[3] = {0, 0, 0}; Bool m_bEncodeDQP = false;
   uint64_t m_uiPicTotalBits = 0, m_uiPicDist = 0; Double m_dPicRdCost = 0;
 };
 
@@ -159,6 +167,15 @@ public:
   Void SAOProcess(TComPic *pPic, Bool *sliceEnabled, const Double *lambdas);
 private:
   TEncTop *m_pcEncTop = nullptr; Double m_saoDisabledRate[3][8] = {};
+};
+
+// TEncPreanalyzer::xPreanalyze (TEncPreanalyzer.cpp:64): the quadrant sums come from the device (hm355_preanalyze), the double arithmetic is the reference's
+class TEncPreanalyzer {
+public:
+  Void init(TEncTop *pcEncTop) { m_pcEncTop = pcEncTop; }
+  Void xPreanalyze(TComPic *pcPic);
+private:
+  TEncTop *m_pcEncTop = nullptr;
 };
 
 class TEncGOP {
@@ -190,6 +207,7 @@ public:
   Void setEncCABACTableIdx(Int i) { m_encCABACTableIdx = i; } Int getEncCABACTableIdx() const { return m_encCABACTableIdx; }   // TComPPS::m_encCABACTableIdx
 private:
   Int m_encCABACTableIdx = I_SLICE;
+  TEncPreanalyzer m_cPreanalyzer;
   hm355_ctx *m_ctx = nullptr; TEncGOP m_cGOPEncoder; TEncSlice m_cSliceEncoder; TComLoopFilter m_cLoopFilter; TEncSampleAdaptiveOffset m_cEncSAO;
   std::list<TComPic *> m_cListPic; Int m_iPOCLast = -1, m_iNumPicRcvd = 0;
 };

@@ -2,7 +2,7 @@
 // 4:2:0 file, feeds TEncTop::encode picture by picture and dumps what compressSlice left behind in the
 // same "HMD1" format the reference harness writes (oracle/ref_harness.cpp), for the parity tests.
 //   hm355_encmain <in.yuv> <w> <h> <bitdepth> <frames> <qp> <wpp> <dump.bin> [lf]     lf: run deblocking + SAO, the dump then holds the finished pictures
-//   ... <dump.bin> ldp | ldb | ra : the GOP table of cfg/encoder_lowdelay_P_main.cfg / encoder_lowdelay_main.cfg / encoder_randomaccess_main10.cfg (IntraPeriod -1, GOPSize 4, P slices with up to 4 references, loop filters
+//   ... <dump.bin> ldp | ldb | ra [aq[range]] : (aq: --AdaptiveQP=1) the GOP table of cfg/encoder_lowdelay_P_main.cfg / encoder_lowdelay_main.cfg / encoder_randomaccess_main10.cfg (IntraPeriod -1, GOPSize 4, P slices with up to 4 references, loop filters
 //   on); the dump is then a "HMD3" stream in coding order: per picture i32 poc, sliceType, qp, depth, cabacInitType, numRefIdx0, numRefIdx1, colFromL0, mvdL1Zero, refPoc[2][16]; f64 lambda;
 //   u32 numCtus; per CTU the record of tests/hmd2.py CTU_DT (cost, bits, dist, decision arrays, motion arrays, coefficients); the finished planes.
 // The slice data of every picture (TEncSlice::encodeSlice) goes to <dump.bin>.bits: per picture u32 numSubstreams, then per substream u32 size + bytes.
@@ -25,6 +25,7 @@ int main(int argc, char **argv)
   const bool ra = argc > 9 && !strcmp(argv[9], "ra");              // cfg/encoder_randomaccess_main*.cfg
   const bool ldp = ldb || ra || (argc > 9 && !strcmp(argv[9], "ldp"));
   if (argc > 9 && (!strcmp(argv[9], "lf") || ldp)) { enc.setLoopFilterDisable(false); enc.setUseSAO(true); }
+  if (argc > 10 && !strncmp(argv[10], "aq", 2)) { enc.setUseAdaptiveQP(true); if (argv[10][2]) enc.setQPAdaptationRange(atoi(argv[10] + 2)); }   // --AdaptiveQP=1 [--MaxQPAdaptationRange=n]
   if (ra) { // cfg/encoder_randomaccess_main10.cfg:20-31
     enc.setIntraPeriod(32); enc.setGOPSize(8);
     static const int poc[8] = { 8, 4, 2, 1, 3, 6, 5, 7 }, qpOff[8] = { 1, 2, 3, 4, 4, 3, 4, 4 }, tid[8] = { 0, 0, 0, 1, 1, 0, 1, 1 }, act[8] = { 4, 2, 2, 2, 2, 2, 2, 2 }, num[8] = { 4, 3, 4, 4, 4, 4, 4, 4 };

@@ -201,6 +201,24 @@ int hm355_upload_file_frames(hm355_ctx *ctx, int n, const void *const *frames, i
 int hm355_download_file_frames(hm355_ctx *ctx, int n, void *const *frames, int file_bit_depth, int conf_right, int conf_bottom, int source);
 int hm355_download_org(hm355_ctx *ctx, int slot, hm355_planes *org);
 
+/* ---- cu_qp_delta: the hooks adaptive QP and rate control have inside compressSlice (TEncSlice.cpp:767-808 hands the CTU its QP through
+ * TEncRateCtrl::setRCQP, TEncCu::xComputeQP :1154 derives it from the TEncPreanalyzer activities; TEncCu::xCheckDQP :1742, the split candidate
+ * :1052-1085 and TEncEntropy.cpp:343-351 price / code the delta QP; TComDataCU::m_phQP feeds the deblocking filter).  MaxCuDQPDepth 0 (the CTU
+ * is the quantisation group), MaxDeltaQP 0.  hm355_set_dqp arms a slot: its following searches (hm355_run*, hm355_compress_slice(s)(_inter)),
+ * hm355_deblock_run and hm355_encode_slices_run run with cu_qp_delta enabled until it is called again with NULL / use_dqp 0.
+ * hm355_get_dqp returns what the search left: m_phQP of every CTU ([numCtus*256]) and TEncCu::m_bEncodeDQP (input of the next picture).
+ * hm355_preanalyze: TEncPreanalyzer::xPreanalyze (TEncPreanalyzer.cpp:64) for layer 0 on the slot's original picture -- the integer part on
+ * the device: sums[a*8 + 0..3] = sum, [4..7] = sum of squares of the luma samples of CTU a's four quadrants; the caller derives the activities
+ * and the QP offsets in double precision as the reference does (hm-16.2_amd/host/TEncTop.cpp, hm-16.2_amd/hm355.py aq_ctu_qp). ---- */
+typedef struct {
+  int32_t use_dqp;                     /* PPS cu_qp_delta_enabled_flag */
+  int32_t dqp_flag_in;                 /* TEncCu::m_bEncodeDQP on entry (what the previous picture's encodeSlice left) */
+  const int8_t *ctu_qp;                /* [numCtus] QP of every CTU; NULL: the slice QP (picture-level rate control) */
+} hm355_dqp_desc;
+int hm355_set_dqp(hm355_ctx *ctx, int slot, const hm355_dqp_desc *desc);
+int hm355_get_dqp(hm355_ctx *ctx, int slot, int8_t *qp_out, int32_t *dqp_flag_out);
+int hm355_preanalyze(hm355_ctx *ctx, int slot, uint64_t *sums);
+
 /* ---- device-resident variant (what bench.py times: inputs already in HBM) ----
  * Upload / run / download are separate so that a caller can keep pictures resident. */
 int hm355_upload(hm355_ctx *ctx, int slot, const hm355_planes *org);          /* host -> HBM picture slot */

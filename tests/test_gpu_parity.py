@@ -242,6 +242,61 @@ def test_hip_closed_loop_on_device_matches_reference(hm, name):
     enc.close()
 
 
+@pytest.mark.parametrize("name", common.DQP_CASES)
+def test_hip_cu_qp_delta_matches_reference(hm, name):
+    """the clips the reference encoded with AdaptiveQP (I / P / B, WPP on and off) and with the picture-level rate control, closed loop
+    on the device: hm355_preanalyze + the reference's double arithmetic give the reference's activities and per-CTU QPs; the search with
+    hm355_set_dqp reproduces decisions, motion, coefficients, costs, reconstruction, TComDataCU::m_phQP and TEncCu::m_bEncodeDQP; deblocking with
+    the CUs' QPs, SAO and the bitstream pass with the cu_qp_delta syntax reproduce the finished picture and the slice data bytes."""
+    saod, bitd = {}, {}
+    cfg, slices, finals = common.load_ldp_case(name, sao=saod, bits=bitd)
+    w, h, bd = cfg["width"], cfg["height"], cfg["bit_depth"]
+    rate = np.zeros((3, 8), np.float64)
+    enc = hm.Encoder(w, h, bd, cfg["wpp"], max_batch=1)
+    dev_refs = {}
+    for r in slices:
+        st, poc, q = int(r["slice_type"]), int(r["poc"]), r["dqp"]
+        what = f"{name} POC {poc}"
+        planes = synth.frame(w, h, bd, poc, cfg["seed"])
+        enc.upload(0, planes)
+        ctu_qp = None
+        if int(q["aq_range"]) > 0:
+            act, avg = hm.aq_activities(enc.preanalyze(0))
+            assert np.array_equal(act, q["activity"]) and avg == float(q["avg_activity"]), f"{what}: activities"
+            ctu_qp = hm.aq_ctu_qp(act, avg, int(q["aq_range"]), int(r["qp"]), bd)
+        enc.set_dqp(0, ctu_qp, int(q["dqp_flag_in"]))
+        if st == 2:
+            sl = (hm.SliceDesc * 1)(hm.SliceDesc(2, int(r["qp"]), float(r["lambda"]), float(r["weight_cb"])))
+            enc._check(enc.lib.hm355_run(enc.h_, 1, sl), "hm355_run")
+            rec, ctus, _ = enc.download(0)
+            common.assert_ctus_equal(ctus, common.split_fixture_ctus(r["ctus"])[0], what)
+        else:
+            sp, _ = common.ldp_slice_inputs(r, finals)
+            refs = {int(p): dev_refs[int(p)] for l in range(2) for p in r["ref_poc"][l][:r["num_ref_idx"][l]]}
+            rec, ctus, ictus, _ = enc.compress_inter(planes, sp, refs)
+            common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], what)
+        for c in range(3):
+            assert np.array_equal(rec[c], r["rec"][c]), f"{what}: pre-deblocking reconstruction plane {c}"
+        qp, flag = enc.get_dqp(0)
+        m = common.inside_mask(len(ctus), w, h)
+        assert np.array_equal(qp[m], q["qp"][m]), f"{what}: m_phQP differs in CTUs {np.nonzero(((qp != q['qp']) & m).any(axis=1))[0][:8]}"
+        assert flag == int(q["dqp_flag_out"]), f"{what}: m_bEncodeDQP after the slice"
+        enc.deblock_run([(st, int(r["qp"]), r["ref_poc"])])
+        (en3, _), = enc.sao_run([dict(qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), depth=saod[poc]["depth"], disabled_rate=rate,
+                                      chroma_weight=float(r["weight_cb"]), **{"lambda": float(r["lambda"])})])
+        (subs, nxt, bins), = enc.encode_slices_run([dict(slice_type=st, qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), num_ref_idx=r["num_ref_idx"],
+                                                         mvd_l1_zero=int(r["mvd_l1_zero"]), max_merge_cand=int(r["max_merge_cand"]), sao_enabled=(en3[0], en3[1]))])
+        assert subs == bitd[poc]["substreams"], f"{what}: slice data bytes differ"
+        assert (nxt, bins) == (bitd[poc]["next_cabac_init_type"], bitd[poc]["num_bins"]), f"{what}: next context table / bin count"
+        fin, _, _ = enc.download(0, want_ctus=False)
+        for c in range(3):
+            assert np.array_equal(fin[c], finals[poc]["rec"][c]), f"{what}: finished picture plane {c}"
+        dev_refs[poc] = enc.ref_from_slot(0, poc, st != 2, r["num_ref_idx"], r["ref_poc"], r["ref_long_term"])
+    for ref in dev_refs.values():
+        enc.ref_release(ref)
+    enc.close()
+
+
 def _first_bad(got, want):
     bad = np.nonzero((got != want).any(axis=1))[0]
     return f"{len(bad)} CTUs differ, first CTU {int(bad[0])}" if len(bad) else ""
@@ -827,7 +882,7 @@ def test_cpp_host_mirror_with_loop_filters(built, tmp_path):
 
 
 
-@pytest.mark.parametrize("name", [common.LDP_CASES[2]] + common.B_CASES + common.LDP_LONG_CASES)     # low-delay P (WPP; two GOPs), random access, low-delay B
+@pytest.mark.parametrize("name", [common.LDP_CASES[2]] + common.B_CASES + common.LDP_LONG_CASES + ["aq_ldp_256x136_8b_qp32", "aq_ra_192x128_10b_qp30"])     # low-delay P (WPP; two GOPs), random access, low-delay B, AdaptiveQP
 def test_cpp_host_mirror_inter_configurations(tmp_path, name):
     """The C++ mirror driven like the reference's encoder on encoder_lowdelay_P_main.cfg (P slices), encoder_lowdelay_main.cfg (B slices,
     list 1 = list 0, mvd_l1_zero, collocated picture from list 1) and encoder_randomaccess_main10.cfg (hierarchical GOP of 8 in coding order,
@@ -846,7 +901,7 @@ def test_cpp_host_mirror_inter_configurations(tmp_path, name):
     dump = tmp_path / "dump.bin"
     exe = os.path.join(common.ROOT, "hm-16.2_amd", "hm355_encmain")
     qp0 = int(slices[0]["qp"])
-    subprocess.run([exe, str(yuv), str(w), str(h), str(cfg["bit_depth"]), str(cfg["frames"]), str(qp0), str(cfg["wpp"]), str(dump), "ldb" if name.startswith("ldb") else ("ra" if name.startswith("ra_") else "ldp")], check=True)
+    subprocess.run([exe, str(yuv), str(w), str(h), str(cfg["bit_depth"]), str(cfg["frames"]), str(qp0), str(cfg["wpp"]), str(dump), "ldb" if name.startswith("ldb") else ("ra" if "ra_" in name else "ldp")] + (["aq"] if name.startswith("aq_") else []), check=True)
     buf = open(dump, "rb").read()
     assert buf[:4] == b"HMD3"
     off = 4 + 20
