@@ -299,6 +299,103 @@ def run_inter(args, torch):
     enc.close()
 
 
+def run_as_stated(args, torch):
+    """BASELINE.json configs[1] and configs[2] exactly as they are stated -- no batching of extra pictures or streams to fill the device, so the
+    time of ONE CTU search is what the step takes.
+      c2: encoder_intra_main10.cfg, synthetic 1920x1080 10-bit, 8 frames (WaveFrontSynchro 0 as the cfg has it: the CABAC state chains through
+          all 510 CTUs of a picture, the 8 pictures are the only parallelism).  A step = hm355_run over the 8 resident pictures; the launch runs
+          as teams of wavefronts (hm355_team.h).
+      c3: encoder_lowdelay_P_main.cfg, synthetic 1920x1080 8-bit, SearchRange 64, one stream in closed loop through the C++ host mirror
+          (hm-16.2_amd/hm355_encmain: TEncTop / TEncGOP / TEncSlice look-alikes over the C ABI; search -> deblocking -> SAO -> slice data -> device-resident
+          reference, every picture referencing the ones before it).  A step = one P picture; value = CTUs / HIP-event time of its search."""
+    import hm355
+    import synth
+    kind, qp = args.workload, args.qp
+    w, h = 1920, 1080
+    n_ctus = ((w + 63) // 64) * ((h + 63) // 64)
+    enc_bin = os.path.join(ROOT, "oracle", "_ref", "hm_encoder")
+    if kind == "c2":
+        bd, F = 10, 8
+        enc = hm355.Encoder(w, h, bd, 0, F)
+        frames = [synth.frame(w, h, bd, f, 1234) for f in range(F)]
+        for i in range(F):
+            enc.upload(i, frames[i])
+        ms_total = 0.0
+        t0 = time.perf_counter()
+        for it in range(args.warmup + args.steps):
+            if it == args.warmup:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            ms, _ = enc.run(F, qp)
+            if it >= args.warmup:
+                ms_total += ms
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ctus = n_ctus * F * args.steps
+        ach = ALG_BYTES_PER_CTU * ctus / (ms_total * 1e-3) / 1e9
+        line = {"metric": "CTUs/sec (enc), BASELINE configs[1] as stated; bit-exact CU partition vs HM", "value": ctus / dt, "unit": "CTU/s", "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic",
+                "config": {"workload": f"encoder_intra_main10, synthetic {w}x{h} 10-bit, {F} frames, QP {qp}, WaveFrontSynchro=0 (serial CABAC chain per picture), inputs resident in HBM",
+                           "frames_per_gpu": F, "ctus_per_step": n_ctus * F, "seconds_per_picture": dt / args.steps},
+                "roofline": {"bound": "hbm", "kernel": "hm355_ctu_team_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                             "avg_launch_ms": ms_total / args.steps, "launches": args.steps,
+                             "note": "8 serial chains of 510 CTU searches: latency-bound by construction (54,278 algorithmic bytes per CTU, SURVEY 8d)"}}
+        if not args.no_cpu_baseline and os.path.exists(enc_bin):
+            with tempfile.TemporaryDirectory() as td:
+                nf = 3
+                yuv = os.path.join(td, "in.yuv")
+                with open(yuv, "wb") as fh:
+                    for f in range(nf):
+                        for p in frames[f]:
+                            fh.write(np.ascontiguousarray(p).astype("<u2").tobytes())
+                cfg = os.path.join(td, "c.cfg"); open(cfg, "w").write(REF_CFG)
+                out = subprocess.run([enc_bin, "-c", cfg, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "50", "-f", str(nf), "--InputBitDepth=10", "-q", str(qp),
+                                      "-b", os.path.join(td, "o.bin"), "-o", os.path.join(td, "r.yuv")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+                tt = [float(l.split()[2]) for l in out.splitlines() if "Total Time" in l][0]
+            line["cpu_baseline"] = {"value": n_ctus * nf / tt, "unit": "CTU/s", "cores": 1, "kind": "reference",
+                                    "sample": f"the first {nf} of the 8 frames, same cfg (whole encoder, HM 'Total Time'; the reference is single threaded)"}
+            line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+        enc.close()
+        return
+    # c3: one low-delay P stream, closed loop, through the C++ host mirror
+    bd, nf = 8, 1 + args.warmup + args.steps
+    exe = os.path.join(ROOT, "hm-16.2_amd", "hm355_encmain")
+    with tempfile.TemporaryDirectory() as td:
+        yuv = os.path.join(td, "in.yuv")
+        synth.write_yuv(yuv, w, h, bd, nf, 1234)
+        p = subprocess.run([exe, yuv, str(w), str(h), str(bd), str(nf), str(qp), str(args.wpp), os.path.join(td, "dump.bin"), "ldp"], env=dict(os.environ, HM355_TIMING="1"),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        pics = [json.loads(l) for l in p.stderr.decode().splitlines() if l.startswith("{")]
+        timed = [x for x in pics if x["slice_type"] != 2][args.warmup:]
+        assert len(timed) == args.steps
+        kernel_ms = sum(x["search_kernel_ms"] for x in timed); wall_ms = sum(x["picture_wall_ms"] for x in timed)
+        alg = 54278 + 4 * 80000 + 4608
+        ach = alg * n_ctus * args.steps / (kernel_ms * 1e-3) / 1e9
+        line = {"metric": "CTUs/sec (enc), P slices, BASELINE configs[2] as stated (one stream, closed loop); bit-exact CU partition / MV vs HM", "value": n_ctus * args.steps / (kernel_ms * 1e-3),
+                "unit": "CTU/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": kernel_ms / args.steps, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic",
+                "config": {"workload": f"encoder_lowdelay_P_main, synthetic {w}x{h} 8-bit, SearchRange 64, QP {qp}, WaveFrontSynchro={args.wpp}, ONE stream in closed loop "
+                                       "(search -> deblocking -> SAO -> slice data -> device-resident reference per picture), a step = one P picture",
+                           "ctus_per_step": n_ctus, "picture_wall_ms_incl_loop_filters_and_slice_data": wall_ms / args.steps,
+                           "pictures": [{k: x[k] for k in ("poc", "qp", "bits", "search_kernel_ms")} for x in pics]},
+                "roofline": {"bound": "hbm", "kernel": "hm355_ctu_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                             "avg_launch_ms": kernel_ms / args.steps, "launches": args.steps, "note": f"algorithmic bytes {alg} B/CTU (SURVEY 8d: 4 reference windows)"}}
+        if not args.no_cpu_baseline and os.path.exists(enc_bin):
+            cfg = os.path.join(td, "ldp.cfg")
+            common = REF_CFG.split("IntraPeriod")[0] + "".join(l + "\n" for l in REF_CFG.splitlines() if l.split(" ")[0] in (
+                "FastSearch", "SearchRange", "HadamardME", "FEN", "FDM", "QP", "MaxDeltaQP", "MaxCuDQPDepth", "DeltaQpRD", "RDOQ", "RDOQTS", "SAO", "AMP", "TransformSkip", "TransformSkipFast"))
+            open(cfg, "w").write(common + REF_CFG_INTER["ldp_p"][2] + "BipredSearchRange : 4\nInternalBitDepth : 8\nProfile : main\n")
+            times = []
+            for frames in (1, 1 + min(2, args.steps)):
+                out = subprocess.run([enc_bin, "-c", cfg, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "50", "-f", str(frames), "--InputBitDepth=8", "-q", str(qp),
+                                      f"--WaveFrontSynchro={args.wpp}", "-b", os.path.join(td, "o.bin"), "-o", os.path.join(td, "r.yuv")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+                times.append([float(l.split()[2]) for l in out.splitlines() if "Total Time" in l][0])
+            line["cpu_baseline"] = {"value": n_ctus * min(2, args.steps) / max(1e-9, times[1] - times[0]), "unit": "CTU/s", "cores": 1, "kind": "reference",
+                                    "sample": f"the first {min(2, args.steps)} P pictures of the same stream, same cfg (HM 'Total Time' of 1+n pictures minus the I picture alone)"}
+            line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+
+
 def run_dbk(args, torch):
     """Secondary workload: the deblocking filter (hm355_deblock_run) over `--frames` 3840x2160 10-bit pictures whose I-slice
     search results are resident in their slots.  A step = one pass of the filter over the batch (four launches: vertical luma / chroma,
@@ -520,7 +617,7 @@ def intra_line(args, world, rows_mode, group, steps, warmup, dt, kernel_ms, laun
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "ldp_p", "ra_b", "dbk", "sao", "bits", "ingest"], help="intra4k = the BASELINE.json metric (default)")
+    ap.add_argument("--workload", default="intra4k", choices=["intra4k", "c2", "c3", "ldp_p", "ra_b", "dbk", "sao", "bits", "ingest"], help="intra4k = the BASELINE.json metric (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -534,6 +631,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--wpp", type=int, default=0, help="--workload c3: WaveFrontSynchro (the cfg has 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -558,6 +656,8 @@ def main():
     if args.workload != "intra4k":
         if world > 1:
             raise SystemExit("--workload ldp_p / ra_b / dbk are single-GPU measurements")
+        if args.workload in ("c2", "c3"):
+            return run_as_stated(args, torch)
         if args.workload == "bits":
             return run_bits(args, torch)
         if args.workload == "ingest":

@@ -892,6 +892,72 @@ extern "C" int hm355_ref_from_slot(hm355_ctx *c, int slot, int32_t poc, int32_t 
   return HM355_OK;
 }
 
+// A finished reference picture as one blob ("Inter (C5)": pictures of one temporal layer run on different devices, the finished
+// pictures are all-gathered): header, the three border-extended planes, the compressed motion field.  buf may be host or device memory,
+// so a device buffer goes to RCCL as it is.
+struct RefBlobHdr { uint32_t magic, width, height, bitDepth; int32_t stride[3], poc, isLongTerm, refPoc[2][16], refLT[2][16]; double user[4]; };
+static size_t ref_plane_bytes(const hm355_ctx *c, int k)
+{ const int cw = c->hp.width >> (k ? 1 : 0), ch = c->hp.height >> (k ? 1 : 0), mg = HM_REF_MARGIN >> (k ? 1 : 0); return (size_t)(cw + 2 * mg) * (ch + 2 * mg) * sizeof(Pel); }
+extern "C" size_t hm355_ref_bytes(const hm355_ctx *c)
+{
+  if (!c) return 0;
+  const size_t np = (size_t)c->numCtus * 256;
+  size_t n = (sizeof(RefBlobHdr) + 255) & ~(size_t)255;
+  for (int k = 0; k < 3; k++) n += (ref_plane_bytes(c, k) + 255) & ~(size_t)255;
+  return n + ((np + 255) & ~(size_t)255) + 2 * (((np * sizeof(MvD)) + 255) & ~(size_t)255) + 2 * ((np + 255) & ~(size_t)255);
+}
+static int ref_blob_copy(hm355_ctx *c, hm355_ref *r, uint8_t *p, int toBlob)
+{ // the buffers of r in the order hm355_ref_from_slot allocates them: planes Y, Cb, Cr, predMode, mv0, refIdx0, mv1, refIdx1
+  const size_t np = (size_t)c->numCtus * 256;
+  const size_t sizes[8] = { ref_plane_bytes(c, 0), ref_plane_bytes(c, 1), ref_plane_bytes(c, 2), np, np * sizeof(MvD), np, np * sizeof(MvD), np };
+  if (r->owned.size() != 8) return fail(c, HM355_ERR_ARG, "hm355_ref_export / import: not a device-resident reference picture");
+  for (int i = 0; i < 8; i++) {
+    HM_CHECK(c, toBlob ? hipMemcpy(p, r->owned[i], sizes[i], hipMemcpyDefault) : hipMemcpy(r->owned[i], p, sizes[i], hipMemcpyDefault));
+    p += (sizes[i] + 255) & ~(size_t)255;
+  }
+  return HM355_OK;
+}
+extern "C" int hm355_ref_export(hm355_ctx *c, const hm355_ref *r, void *buf, const double user[4])
+{
+  if (!c || !r || !buf) return HM355_ERR_ARG;
+  RefBlobHdr h; memset(&h, 0, sizeof(h));
+  h.magic = 0x52464d48u; h.width = (uint32_t)c->hp.width; h.height = (uint32_t)c->hp.height; h.bitDepth = (uint32_t)c->hp.bitDepth;
+  for (int k = 0; k < 3; k++) h.stride[k] = r->dev.stride[k];
+  h.poc = r->dev.poc; h.isLongTerm = r->dev.isLongTerm; memcpy(h.refPoc, r->dev.refPoc, sizeof(h.refPoc)); memcpy(h.refLT, r->dev.refLT, sizeof(h.refLT));
+  if (user) memcpy(h.user, user, sizeof(h.user));
+  HM_CHECK(c, hipMemcpy(buf, &h, sizeof(h), hipMemcpyDefault));
+  return ref_blob_copy(c, (hm355_ref *)r, (uint8_t *)buf + ((sizeof(RefBlobHdr) + 255) & ~(size_t)255), 1);
+}
+extern "C" int hm355_ref_import(hm355_ctx *c, const void *buf, hm355_ref **out, double user[4])
+{
+  if (!c || !buf || !out) return HM355_ERR_ARG;
+  RefBlobHdr h;
+  HM_CHECK(c, hipMemcpy(&h, buf, sizeof(h), hipMemcpyDefault));
+  if (h.magic != 0x52464d48u || (int)h.width != c->hp.width || (int)h.height != c->hp.height || (int)h.bitDepth != c->hp.bitDepth)
+    return fail(c, HM355_ERR_ARG, "hm355_ref_import: not a reference picture of this sequence");
+  const Params &P = c->hp; const size_t np = (size_t)c->numCtus * 256;
+  hm355_ref *r = new hm355_ref(); memset(&r->dev, 0, sizeof(r->dev));
+  const size_t sizes[8] = { ref_plane_bytes(c, 0), ref_plane_bytes(c, 1), ref_plane_bytes(c, 2), np, np * sizeof(MvD), np, np * sizeof(MvD), np };
+  for (int i = 0; i < 8; i++) {
+    void *d = NULL;
+    if (hipMalloc(&d, sizes[i]) != hipSuccess) { (void)hipGetLastError(); hm355_ref_release(c, r); return fail(c, HM355_ERR_NOMEM, "hm355_ref_import: out of device memory"); }
+    r->owned.push_back(d);
+  }
+  for (int k = 0; k < 3; k++) {
+    const int mg = HM_REF_MARGIN >> (k ? 1 : 0), st = (P.width >> (k ? 1 : 0)) + 2 * mg;
+    if (h.stride[k] != st) { hm355_ref_release(c, r); return fail(c, HM355_ERR_ARG, "hm355_ref_import: plane layout mismatch"); }
+    r->dev.plane[k] = (Pel *)r->owned[k] + (size_t)mg * st + mg; r->dev.stride[k] = st;
+  }
+  r->dev.predMode = (uint8_t *)r->owned[3]; r->dev.mv[0] = (MvD *)r->owned[4]; r->dev.refIdx[0] = (int8_t *)r->owned[5];
+  r->dev.mv[1] = (MvD *)r->owned[6]; r->dev.refIdx[1] = (int8_t *)r->owned[7];
+  r->dev.poc = h.poc; r->dev.isLongTerm = h.isLongTerm; memcpy(r->dev.refPoc, h.refPoc, sizeof(h.refPoc)); memcpy(r->dev.refLT, h.refLT, sizeof(h.refLT));
+  if (user) memcpy(user, h.user, sizeof(h.user));
+  const int rc = ref_blob_copy(c, r, (uint8_t *)buf + ((sizeof(RefBlobHdr) + 255) & ~(size_t)255), 0);
+  if (rc != HM355_OK) { hm355_ref_release(c, r); return rc; }
+  *out = r;
+  return HM355_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // deblocking (TComLoopFilter::loopFilterPic): in place on the reconstruction planes of the slots
 // ------------------------------------------------------------------------------------------------

@@ -576,6 +576,21 @@ HM_DEV inline void load_tmat(Shared *e)
 }
 HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst ? e->dst4[k * 4 + j] : e->tmat[(k * (32 / n)) * HM_TSTRIDE + j]; }
 
+// The DCT rows are symmetric (even k) or antisymmetric (odd k) about their middle -- what partialButterfly4/8/16/32 (TComTrQuant.cpp:387-763) build
+// on -- so an output needs n/2 products of the folded input (x[i] +- x[n-1-i]) instead of n.  One fold level: the sums are the same integers in
+// another order, and half the multiplies and half the LDS reads go.  The 4-point DST has no such symmetry and takes the plain product.
+HM_DEV inline void fold_rows(int32_t *X, int n, int l2)
+{ // every row of X in place: [0, n/2) <- x[i] + x[n-1-i], [n/2, n) <- x[i] - x[n-1-i].  The pairs (i, n-1-i) and (n/2-1-i, n/2+i) read and write the
+  // same four positions, so one lane takes both: in place whatever the order the lanes run in.
+  const int h = n >> 1, q = n >> 2;
+  HM_PAR_FOR(o, n * q) {
+    const int j = o >> (l2 - 2), i = o & (q - 1);
+    int32_t *r = X + j * HM_TSTRIDE;
+    const int32_t a = r[i], b = r[n - 1 - i], c = r[h - 1 - i], d = r[h + i];
+    r[i] = a + b; r[h + i] = a - b; r[h - 1 - i] = c + d; r[n - 1 - i] = c - d;
+  }
+  HM_SYNC();
+}
 // forward: src (bufA, [row][col]) -> dst (bufA); xTrMxN, TComTrQuant.cpp:836-890
 HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth)
 {
@@ -583,39 +598,82 @@ HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth
   const int l2 = hm_log2(n), s1 = l2 + bitDepth + 6 - 15, s2 = l2 + 6;
   const int a1 = s1 > 0 ? 1 << (s1 - 1) : 0, a2 = 1 << (s2 - 1);
   int32_t *A = e->bufA, *B = e->u.bufB;
-  HM_PAR_FOR(o, n * n) { // o = j*n + k with k fastest: lanes of one row share the source row (LDS broadcast)
+  if (useDst) {
+    HM_PAR_FOR(o, n * n) { // o = j*n + k with k fastest: lanes of one row share the source row (LDS broadcast)
+      const int j = o >> l2, k = o & (n - 1);
+      int32_t acc = 0;
+      for (int i = 0; i < n; i++) acc += tm(e, n, 1, k, i) * A[j * HM_TSTRIDE + i];
+      B[k * HM_TSTRIDE + j] = (acc + a1) >> s1;
+    }
+    HM_SYNC();
+    HM_PAR_FOR(o, n * n) {
+      const int j = o >> l2, k = o & (n - 1);
+      int32_t acc = 0;
+      for (int i = 0; i < n; i++) acc += tm(e, n, 1, k, i) * B[j * HM_TSTRIDE + i];
+      A[k * HM_TSTRIDE + j] = (acc + a2) >> s2;
+    }
+    HM_SYNC();
+    return;
+  }
+  const int h = n >> 1, step = 32 / n;
+  fold_rows(A, n, l2);
+  HM_PAR_FOR(o, n * n) {
     const int j = o >> l2, k = o & (n - 1);
+    const int32_t *x = A + j * HM_TSTRIDE + ((k & 1) ? h : 0); const int8_t *t = e->tmat + (k * step) * HM_TSTRIDE;
     int32_t acc = 0;
-    for (int i = 0; i < n; i++) acc += tm(e, n, useDst, k, i) * A[j * HM_TSTRIDE + i];
+    for (int i = 0; i < h; i++) acc += t[i] * x[i];
     B[k * HM_TSTRIDE + j] = (acc + a1) >> s1;
   }
   HM_SYNC();
+  fold_rows(B, n, l2);
   HM_PAR_FOR(o, n * n) {
     const int j = o >> l2, k = o & (n - 1);
+    const int32_t *x = B + j * HM_TSTRIDE + ((k & 1) ? h : 0); const int8_t *t = e->tmat + (k * step) * HM_TSTRIDE;
     int32_t acc = 0;
-    for (int i = 0; i < n; i++) acc += tm(e, n, useDst, k, i) * B[j * HM_TSTRIDE + i];
+    for (int i = 0; i < h; i++) acc += t[i] * x[i];
     A[k * HM_TSTRIDE + j] = (acc + a2) >> s2;
   }
   HM_SYNC();
 }
-// inverse: coefficients in bufA -> residual in bufA; xITrMxN, TComTrQuant.cpp:894-935
+// inverse: coefficients in bufA -> residual in bufA; xITrMxN, TComTrQuant.cpp:894-935.  Outputs i and n-1-i share the even-row sum and differ in the
+// sign of the odd-row sum: one lane makes both from n products.
 HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth)
 {
   HM_ENTRY(e); n = HM_UNI(n); useDst = HM_UNI(useDst); bitDepth = HM_UNI(bitDepth);
   const int l2 = hm_log2(n), s1 = 7, s2 = 20 - bitDepth;
   int32_t *A = e->bufA, *B = e->u.bufB;
-  HM_PAR_FOR(o, n * n) {
-    const int j = o >> l2, i = o & (n - 1);
-    int32_t acc = 0;
-    for (int k = 0; k < n; k++) acc += tm(e, n, useDst, k, i) * A[k * HM_TSTRIDE + j];
-    B[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (acc + (1 << (s1 - 1))) >> s1);
+  if (useDst) {
+    HM_PAR_FOR(o, n * n) {
+      const int j = o >> l2, i = o & (n - 1);
+      int32_t acc = 0;
+      for (int k = 0; k < n; k++) acc += tm(e, n, 1, k, i) * A[k * HM_TSTRIDE + j];
+      B[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (acc + (1 << (s1 - 1))) >> s1);
+    }
+    HM_SYNC();
+    HM_PAR_FOR(o, n * n) {
+      const int j = o >> l2, i = o & (n - 1);
+      int32_t acc = 0;
+      for (int k = 0; k < n; k++) acc += tm(e, n, 1, k, i) * B[k * HM_TSTRIDE + j];
+      A[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (acc + (1 << (s2 - 1))) >> s2);
+    }
+    HM_SYNC();
+    return;
+  }
+  const int h = n >> 1, step = 32 / n;
+  HM_PAR_FOR(o, n * h) {
+    const int j = o >> (l2 - 1), i = o & (h - 1);
+    int32_t ev = 0, od = 0;
+    for (int k = 0; k < n; k += 2) { ev += e->tmat[(k * step) * HM_TSTRIDE + i] * A[k * HM_TSTRIDE + j]; od += e->tmat[((k + 1) * step) * HM_TSTRIDE + i] * A[(k + 1) * HM_TSTRIDE + j]; }
+    B[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (ev + od + (1 << (s1 - 1))) >> s1);
+    B[j * HM_TSTRIDE + n - 1 - i] = hm_clip3(-32768, 32767, (ev - od + (1 << (s1 - 1))) >> s1);
   }
   HM_SYNC();
-  HM_PAR_FOR(o, n * n) {
-    const int j = o >> l2, i = o & (n - 1);
-    int32_t acc = 0;
-    for (int k = 0; k < n; k++) acc += tm(e, n, useDst, k, i) * B[k * HM_TSTRIDE + j];
-    A[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (acc + (1 << (s2 - 1))) >> s2);
+  HM_PAR_FOR(o, n * h) {
+    const int j = o >> (l2 - 1), i = o & (h - 1);
+    int32_t ev = 0, od = 0;
+    for (int k = 0; k < n; k += 2) { ev += e->tmat[(k * step) * HM_TSTRIDE + i] * B[k * HM_TSTRIDE + j]; od += e->tmat[((k + 1) * step) * HM_TSTRIDE + i] * B[(k + 1) * HM_TSTRIDE + j]; }
+    A[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (ev + od + (1 << (s2 - 1))) >> s2);
+    A[j * HM_TSTRIDE + n - 1 - i] = hm_clip3(-32768, 32767, (ev - od + (1 << (s2 - 1))) >> s2);
   }
   HM_SYNC();
 }

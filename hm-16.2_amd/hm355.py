@@ -81,7 +81,7 @@ class BitsDesc(C.Structure):
 
 
 EXPORTS = ["hm355_build_id", "hm355_set_dqp", "hm355_get_dqp", "hm355_preanalyze", "hm355_create", "hm355_destroy", "hm355_last_error", "hm355_compress_slice", "hm355_compress_slices",
-           "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_sao_run",
+           "hm355_compress_slice_inter", "hm355_compress_slices_inter", "hm355_deblock", "hm355_deblock_run", "hm355_ref_from_slot", "hm355_ref_release", "hm355_ref_bytes", "hm355_ref_export", "hm355_ref_import", "hm355_sao_run",
            "hm355_num_substreams", "hm355_encode_slices_run", "hm355_encode_slice",
            "hm355_upload_file_frames", "hm355_download_file_frames", "hm355_download_org",
            "hm355_upload", "hm355_run", "hm355_run_begin", "hm355_run_wait", "hm355_run_rows", "hm355_boundary_bytes", "hm355_export_boundary", "hm355_import_boundary", "hm355_download", "hm355_last_run_info", "hm355_dist_batch",
@@ -125,6 +125,10 @@ def load_library(path=LIB_PATH):
     lib.hm355_ref_from_slot.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.hm355_ref_release.argtypes = [C.c_void_p, C.c_void_p]
     lib.hm355_ref_release.restype = None
+    lib.hm355_ref_bytes.argtypes = [C.c_void_p]
+    lib.hm355_ref_bytes.restype = C.c_size_t
+    lib.hm355_ref_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hm355_ref_import.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
     lib.hm355_sao_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(SaoDesc)]
     lib.hm355_upload_file_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]
     lib.hm355_download_file_frames.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]
@@ -402,6 +406,27 @@ class Encoder:
         self._check(self.lib.hm355_ref_from_slot(self.h_, slot, int(poc), int(bool(is_inter)), nr, rp.ctypes.data, rl.ctypes.data, C.byref(h)),
                     "hm355_ref_from_slot")
         return {"dev": h.value}
+
+    def ref_bytes(self):
+        return int(self.lib.hm355_ref_bytes(self.h_))
+
+    def ref_export(self, ref, ptr=None, user=(0.0, 0.0, 0.0, 0.0)):
+        """hm355_ref_export: the reference picture as one blob; into ref_bytes() bytes at `ptr` (host or device memory), or into a new uint8 array"""
+        u = (C.c_double * 4)(*[float(v) for v in user])
+        buf = None
+        if ptr is None:
+            buf = np.empty(self.ref_bytes(), np.uint8); ptr = buf.ctypes.data
+        self._check(self.lib.hm355_ref_export(self.h_, ref["dev"], C.c_void_p(ptr), u), "hm355_ref_export")
+        return buf
+
+    def ref_import(self, data):
+        """hm355_ref_import: blob (uint8 array, or an address of host / device memory) -> ({"dev": handle}, the four user doubles)"""
+        u = (C.c_double * 4)()
+        if not isinstance(data, int):
+            data = np.ascontiguousarray(data, np.uint8); assert data.size == self.ref_bytes()
+        h = C.c_void_p()
+        self._check(self.lib.hm355_ref_import(self.h_, C.c_void_p(data if isinstance(data, int) else data.ctypes.data), C.byref(h), u), "hm355_ref_import")
+        return {"dev": h.value}, tuple(u)
 
     def ref_release(self, ref):
         self.lib.hm355_ref_release(self.h_, ref["dev"])

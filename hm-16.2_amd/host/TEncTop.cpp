@@ -1,5 +1,6 @@
 #include "TEncTop.h"
 #include <algorithm>
+#include <chrono>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -100,7 +101,10 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
       pcSlice->setCabacInitType((!pcSlice->isIntra() && (idx == B_SLICE || idx == P_SLICE)) ? idx : (Int)pcSlice->getSliceType());
     }
     m_pcSliceEncoder->precompressSlice(pcPic);                                                        // :1137
+    const auto tPic0 = std::chrono::steady_clock::now();
     m_pcSliceEncoder->compressSlice(pcPic);                                                           // :1138
+    double searchKernelMs = 0; hm355_last_run_info(ctx, &searchKernelMs, NULL);
+    const double searchWallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tPic0).count();
     pcSlice->setSliceBits((UInt)m_pcSliceEncoder->getTotalBits());
     // loop filters (TEncGOP.cpp:1184, :1475-1497), then the finished picture back into getPicYuvRec()
     const Bool bLF = !m_pcEncTop->getLoopFilterDisable(), bSAO = m_pcEncTop->getUseSAO();
@@ -123,6 +127,10 @@ Void TEncGOP::compressGOP(Int iPOCLast, Int iNumPicRcvd, std::list<TComPic *> &r
       if (hm355_download(ctx, 0, &rec, NULL, NULL) != HM355_OK) { fprintf(stderr, "TEncGOP::compressGOP: download failed: %s\n", hm355_last_error(ctx)); exit(EXIT_FAILURE); }
     }
     pcPic->setReconMark(true); m_codedPics.push_back(pcPic);
+    if (getenv("HM355_TIMING"))   // one line per picture for bench.py: the search (TEncSlice::compressSlice) as the HIP events and the host clock saw it
+      fprintf(stderr, "{\"poc\": %d, \"slice_type\": %d, \"qp\": %d, \"search_kernel_ms\": %.3f, \"search_wall_ms\": %.3f, \"picture_wall_ms\": %.3f, \"bits\": %llu}\n", pocCurr,
+              (int)pcSlice->getSliceType(), pcSlice->getSliceQp(), searchKernelMs, searchWallMs,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tPic0).count(), (unsigned long long)m_pcSliceEncoder->getTotalBits());
     if (m_pcEncTop->getGOPSize() > 1) {
       // the finished picture becomes a reference on the device: border extension + TComPic::compressMotion (:1660), no host round trip
       int32_t numRef[2] = { pcSlice->getNumRefIdx(REF_PIC_LIST_0), pcSlice->getNumRefIdx(REF_PIC_LIST_1) }, refPoc[2][16], refLT[2][16];

@@ -140,6 +140,14 @@ typedef struct hm355_ref hm355_ref;
 int hm355_ref_from_slot(hm355_ctx *ctx, int slot, int32_t poc, int32_t is_inter, const int32_t num_ref[2], const int32_t ref_poc[2][16],
                         const int32_t ref_lt[2][16], hm355_ref **out);
 void hm355_ref_release(hm355_ctx *ctx, hm355_ref *ref);
+/* The same reference picture as ONE blob of hm355_ref_bytes() bytes (header, border-extended planes, compressed motion field), in host or
+ * device memory: what crosses devices when pictures of one temporal layer are searched on different GPUs and the finished pictures are
+ * all-gathered (SURVEY.md 8e "Inter"; TEncGOP.cpp:1184,1483,1660 make a picture a reference only after deblocking, SAO and
+ * compressMotion, which is the state hm355_ref_from_slot captures).  A device buffer goes to RCCL as it is (hm-16.2_amd/gop_shard.py).
+ * user[4]: four doubles that travel with the picture (the scheduler's per-picture state, e.g. the SAO disabled rates); may be NULL. */
+size_t hm355_ref_bytes(const hm355_ctx *ctx);
+int hm355_ref_export(hm355_ctx *ctx, const hm355_ref *ref, void *buf, const double user[4]);
+int hm355_ref_import(hm355_ctx *ctx, const void *buf, hm355_ref **out, double user[4]);
 
 /* ---- deblocking filter: TComLoopFilter::loopFilterPic (TLibCommon/TComLoopFilter.cpp:130-158), the step TEncGOP runs after
  * compressSlice (TEncGOP.cpp:1184) to turn the reconstruction into a reference picture.  Deblocking offsets 0, one slice,

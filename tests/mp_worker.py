@@ -13,6 +13,34 @@ import torch.distributed as dist
 
 import bands
 import bench
+import gop_shard
+
+RA_GOP = [dict(poc=0, refs=[], depth=0), dict(poc=8, refs=[0], depth=0), dict(poc=4, refs=[0, 8], depth=1), dict(poc=2, refs=[0, 4], depth=2),
+          dict(poc=1, refs=[0, 2], depth=3), dict(poc=3, refs=[2, 4], depth=3), dict(poc=6, refs=[4, 8], depth=2), dict(poc=5, refs=[4, 6], depth=3),
+          dict(poc=7, refs=[6, 8], depth=3)]          # cfg/encoder_randomaccess_main10.cfg:24-31 with its 2 active references per list
+
+
+class RecordingGopEngine:
+    """stands in for the device in hm-16.2_amd/gop_shard.py: a finished picture is (poc, who encoded it); its blob carries both"""
+
+    def __init__(self, rank):
+        self.rank, self.encoded, self.imported = rank, [], []
+
+    def encode(self, pic, refs, prev_rates):
+        assert sorted(refs) == sorted(pic["refs"]) and all(h[0] == r for r, h in refs.items()), "a picture ran before its references were finished here"
+        self.encoded.append((pic["poc"], tuple(prev_rates)))
+        return (pic["poc"], self.rank), {"poc": pic["poc"]}, (pic["poc"] + 0.25, pic["poc"] + 0.5, pic["poc"] + 0.75)
+
+    def export(self, handle, rates):
+        return np.frombuffer(np.array([handle[0], handle[1], *rates], np.float64).tobytes(), np.uint8).copy()
+
+    def blob_like(self):
+        return np.zeros(40, np.uint8)
+
+    def imp(self, blob):
+        v = np.frombuffer(np.asarray(blob, np.uint8).tobytes(), np.float64)
+        self.imported.append(int(v[0]))
+        return (int(v[0]), int(v[1])), tuple(float(x) for x in v[2:5])
 
 
 def payload(rank, slot, row, nbytes):
@@ -70,6 +98,12 @@ def main():
     rows = [None] * world
     dist.all_gather_object(rows, (bands.band_rows(h_ctu, world, rank), sorted(eng.searched), eng.launches, ms))
     out["bands"] = rows
+    # ---- pictures of one temporal layer on different ranks: hm-16.2_amd/gop_shard.py over gloo
+    geng = RecordingGopEngine(rank)
+    res, done = gop_shard.run_gop(geng, RA_GOP, rank, world, gop_shard.TorchAllGather(dist, torch))
+    gop = [None] * world
+    dist.all_gather_object(gop, (geng.encoded, sorted(geng.imported), sorted((poc, h[0][1]) for poc, h in done.items())))
+    out["gop"] = gop
     dist.barrier()
     if rank == 0:
         print(json.dumps(out))

@@ -770,6 +770,116 @@ def test_full_size_1080p_main10_batch_equals_single(hm):
     enc.close()
 
 
+def test_hip_gop_levels_on_two_contexts_match_reference(hm):
+    """SURVEY 8e "Inter (C5)": the pictures of one temporal layer on different devices.  Two contexts on one GPU play ranks 0 and 1 of
+    hm-16.2_amd/gop_shard.py over the reference's random-access clip (hierarchical GOP of 8): each encodes its share of every level with
+    device-resident references (search -> deblocking -> SAO -> hm355_ref_from_slot), exports its finished pictures as blobs into DEVICE buffers
+    (hm355_ref_export), the all-gather hands them round and the other context imports them (hm355_ref_import).  Every picture -- decisions,
+    motion, coefficients, the finished picture -- equals the reference's single-encoder run; each picture was searched exactly once."""
+    import ctypes
+    import threading
+    import gop_shard
+    name = "ra_192x128_10b_qp32"
+    saod = {}
+    cfg, slices, finals = common.load_ldp_case(name, sao=saod)
+    w, h, bd = cfg["width"], cfg["height"], cfg["bit_depth"]
+    by_poc = {int(r["poc"]): r for r in slices}
+    pics = [dict(poc=int(r["poc"]), depth=saod[int(r["poc"])]["depth"],
+                 refs=sorted(set(int(p) for l in range(2) for p in r["ref_poc"][l][:r["num_ref_idx"][l]])) if int(r["slice_type"]) != 2 else []) for r in slices]
+    world = 2
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    barrier = threading.Barrier(world)
+    wire, errors, out = [None] * world, [], [None] * world
+
+    class Engine:
+        def __init__(self, enc):
+            self.enc, self.nb, self.bufs = enc, enc.ref_bytes(), []
+
+        def dev_buffer(self):
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(self.nb)) == 0
+            self.bufs.append(p)
+            return p.value
+
+        def encode(self, pic, refs, prev_rates):
+            r = by_poc[pic["poc"]]
+            st, poc = int(r["slice_type"]), pic["poc"]
+            planes = synth.frame(w, h, bd, poc, cfg["seed"])
+            if st == 2:
+                self.enc.upload(0, planes)
+                sl = (hm.SliceDesc * 1)(hm.SliceDesc(2, int(r["qp"]), float(r["lambda"]), float(r["weight_cb"])))
+                self.enc._check(self.enc.lib.hm355_run(self.enc.h_, 1, sl), "hm355_run")
+                _, ctus, _ = self.enc.download(0)
+                ictus = None
+            else:
+                sp, _ = common.ldp_slice_inputs(r, finals)
+                _, ctus, ictus, _ = self.enc.compress_inter(planes, sp, {p: refs[p] for p in pic["refs"]})
+            self.enc.deblock_run([(st, int(r["qp"]), r["ref_poc"])])
+            rate = np.zeros((3, 8), np.float64)
+            if pic["depth"] > 0:
+                rate[:, pic["depth"] - 1] = prev_rates
+            self.enc.sao_run([dict(qp=int(r["qp"]), cabac_init_type=int(r["cabac_init_type"]), depth=pic["depth"], disabled_rate=rate,
+                                   chroma_weight=float(r["weight_cb"]), **{"lambda": float(r["lambda"])})])
+            fin, _, _ = self.enc.download(0, want_ctus=False)
+            handle = self.enc.ref_from_slot(0, poc, st != 2, r["num_ref_idx"], r["ref_poc"], r["ref_long_term"])
+            return handle, (ctus, ictus, fin), tuple(rate[:, pic["depth"]])
+
+        def export(self, handle, rates):
+            p = self.dev_buffer()
+            self.enc.ref_export(handle, p, (*rates, 0.0))
+            return p
+
+        def blob_like(self):
+            return self.dev_buffer()
+
+        def imp(self, blob):
+            handle, user = self.enc.ref_import(int(blob))
+            return handle, user[:3]
+
+    def all_gather_for(rank):
+        def all_gather(blobs):
+            wire[rank] = blobs
+            barrier.wait()
+            got = [list(b) for b in wire]
+            barrier.wait()
+            return got
+        return all_gather
+
+    def run(rank):
+        try:
+            enc = hm.Encoder(w, h, bd, cfg["wpp"], max_batch=1)
+            eng = Engine(enc)
+            res, done = gop_shard.run_gop(eng, pics, rank, world, all_gather_for(rank))
+            out[rank] = res
+            barrier.wait()                                # nobody frees a buffer the other rank may still be importing from
+            for handle, _ in done.values():
+                enc.ref_release(handle)
+            for p in eng.bufs:
+                hip.hipFree(p)
+            enc.close()
+        except Exception as e:                            # noqa: BLE001
+            errors.append((rank, repr(e)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sorted(list(out[0]) + list(out[1])) == sorted(by_poc), "every picture exactly once"
+    assert len(out[0]) >= 3 and len(out[1]) >= 2
+    for res in out:
+        for poc, (ctus, ictus, fin) in res.items():
+            r = by_poc[poc]
+            if ictus is None:
+                common.assert_ctus_equal(ctus, common.split_fixture_ctus(r["ctus"])[0], f"{name} POC {poc}")
+            else:
+                common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], f"{name} POC {poc}")
+            for c in range(3):
+                assert np.array_equal(fin[c], finals[poc]["rec"][c]), f"{name} POC {poc}: finished picture plane {c}"
+
+
 def test_row_bands_two_real_ranks_over_gloo():
     """the band pipeline with REAL ranks: two processes (torch.distributed.run, gloo transport) share the GPU, each searches its band of the
     same pictures through hm-16.2_amd/bands.py + TorchTransport, rank 0 gathers the bands and compares them with an unsplit run"""

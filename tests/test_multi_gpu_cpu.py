@@ -38,6 +38,26 @@ def test_ranks_with_gloo(world, port):
         covered += list(range(first, last + 1))
         assert searched == list(range(7)) and [tuple(l) for l in launches] == [(0, 3), (3, 3), (6, 1)] and ms == 3.0
     assert covered == list(range(5))
+    # gop_shard: every picture encoded exactly once, by the rank the level plan names, after its references; every rank ends up holding every
+    # finished picture (its own or imported from the owner); the SAO rates a picture reads are those of the picture gop_shard names
+    import gop_shard
+    import mp_worker
+    pics = mp_worker.RA_GOP
+    want_owner = {}
+    for level in gop_shard.levels(pics):
+        for k, i in enumerate(level):
+            want_owner[pics[i]["poc"]] = gop_shard.owner(k, world)
+    encoded_by = {}
+    for r, (encoded, imported, holds) in enumerate(res["gop"]):
+        for poc, prev in encoded:
+            assert poc not in encoded_by
+            encoded_by[poc] = r
+            src = gop_shard.sao_rate_source(pics, [p["poc"] for p in pics].index(poc))
+            want = (0.0, 0.0, 0.0) if src is None else (pics[src]["poc"] + 0.25, pics[src]["poc"] + 0.5, pics[src]["poc"] + 0.75)
+            assert tuple(prev) == want, f"POC {poc}: SAO rates of the wrong picture"
+        assert [tuple(h) for h in holds] == sorted((poc, o) for poc, o in want_owner.items())
+        assert sorted(imported) == sorted(poc for poc, o in want_owner.items() if o != r)
+    assert encoded_by == want_owner
 
 
 @pytest.mark.parametrize("h_ctu,world", [(34, 8), (34, 1), (4, 2), (5, 3), (3, 8), (17, 4)])
