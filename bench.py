@@ -219,7 +219,7 @@ def cpu_baseline_inter(kind, qp, width, height):
             "sample": f"{n_inter} inter pictures of the top 4 CTU rows ({w}x{h}, {bd}-bit) of the benched clip ({n_ctus} CTUs), same cfg, QP {qp}; HM 'Total Time' of 1+{n_inter} pictures minus 1 picture"}
 
 
-def run_inter(args, torch):
+def run_inter(args, torch, world=1, rank=0, local_rank=0):
     """Secondary workloads: inter slices through hm355_compress_slices_inter, `--frames` independent streams per step (one current
     picture each, WaveFrontSynchro=1); the reference pictures are HIP-path I-slice reconstructions of the same synthetic clip,
     shifted per stream so that every stream has its own data.
@@ -230,6 +230,11 @@ def run_inter(args, torch):
     import math
     import hm355
     import synth
+    dist = None
+    if world > 1:      # every rank its own streams (independent GOP chains shard with no data-path collective): weak scaling; RCCL carries the barrier and the max time
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     kind, qp, S = args.workload, args.qp, args.frames
     if kind == "ldp_p":
         w, h, bd, nref, qpp, qpf, ref_idx_pocs, cur_poc = 1920, 1080, 8, 4, qp + 3, 0.4624, [3, 2, 1, 0], 4
@@ -258,14 +263,17 @@ def run_inter(args, torch):
     # neither share reference data in the caches nor repeat each other's decisions
     cur0 = synth.frame(w, h, bd, cur_poc, 1234)
     def shifted(planes, k):
+        k += rank * S                               # other ranks, other streams
         dx, dy = (24 * k) % w, (8 * k) % h
         return [np.ascontiguousarray(np.roll(np.roll(p, dy >> (1 if i else 0), axis=0), dx >> (1 if i else 0), axis=1)) for i, p in enumerate(planes)]
     jobs = []
     for k in range(S):
-        rk = {f: dict(r, rec=shifted(r["rec"], k)) for f, r in refs.items()} if k else refs
-        jobs.append((shifted(cur0, k) if k else cur0, sp, rk))
+        rk = {f: dict(r, rec=shifted(r["rec"], k)) for f, r in refs.items()} if (k or rank) else refs
+        jobs.append((shifted(cur0, k) if (k or rank) else cur0, sp, rk))
     kernel_ms, wall = 0.0, 0.0
     for it in range(args.warmup + args.steps):
+        if dist is not None:
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = enc.compress_inter_batch(jobs)
         torch.cuda.synchronize()
@@ -276,15 +284,21 @@ def run_inter(args, torch):
             wall += time.perf_counter() - t0
     ctus = n * S * args.steps
     alg = 54278 + (nref if kind == "ldp_p" else 2 * nref) * 80000 + 4608        # intra bytes + search window per reference + MV fields
-    ach = alg * ctus / (kernel_ms * 1e-3) / 1e9
+    ach = alg * ctus / (kernel_ms * 1e-3) / 1e9                                 # this rank's kernel
+    if dist is not None:
+        kernel_ms = agree_over_ranks(dist, torch, kernel_ms, dist.ReduceOp.MAX, "cuda"); wall = agree_over_ranks(dist, torch, wall, dist.ReduceOp.MAX, "cuda")
+        ctus *= world
+        if rank != 0:
+            enc.close(); dist.barrier(); dist.destroy_process_group()
+            return
     what = ("encoder_lowdelay_P_main P slices, synthetic 1920x1080 8-bit, 4 references" if kind == "ldp_p"
             else "encoder_randomaccess_main10 B slices, synthetic 3840x2160 10-bit, 2 + 2 references, BipredSearchRange 4")
     line = {
         "metric": f"CTUs/sec (enc), {'P' if kind == 'ldp_p' else 'B'} slices; bit-exact CU partition / MV vs HM", "value": ctus / (kernel_ms * 1e-3),
-        "unit": "CTU/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": kernel_ms / args.steps, "higher_is_better": True,
+        "unit": "CTU/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": kernel_ms / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32+f64", "data": "synthetic", "call_s": wall / args.steps,
-        "config": {"workload": f"{what}, SearchRange 64, QP {qpp}, WaveFrontSynchro=1, {S} independent streams per step", "streams": S,
-                   "ctus_per_step": n * S,
+        "config": {"workload": f"{what}, SearchRange 64, QP {qpp}, WaveFrontSynchro=1, {S} independent streams per GPU per step", "streams": S,
+                   "ctus_per_step": n * S * world,
                    "mode_mix": {"skip": float(np.mean([(o[2]["skip"] != 0).mean() for o in out])),
                                 "bi": float(np.mean([(o[2]["inter_dir"] == 3).mean() for o in out])),
                                 "intra": float(np.mean([(o[1]["pred_mode"] == 1).mean() for o in out]))}},
@@ -297,6 +311,8 @@ def run_inter(args, torch):
             line["speedup_vs_cpu_1core"] = line["value"] / cb["value"]
     print(json.dumps(line))
     enc.close()
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def run_as_stated(args, torch):
@@ -654,15 +670,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X: hm355 has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if args.workload != "intra4k":
-        if world > 1:
-            raise SystemExit("--workload ldp_p / ra_b / dbk are single-GPU measurements")
+        if world > 1 and args.workload not in ("ldp_p", "ra_b"):
+            raise SystemExit("--workload c2 / c3 / dbk / sao / bits / ingest are single-GPU measurements")
         if args.workload in ("c2", "c3"):
             return run_as_stated(args, torch)
         if args.workload == "bits":
             return run_bits(args, torch)
         if args.workload == "ingest":
             return run_ingest(args, torch)
-        return run_dbk(args, torch) if args.workload in ("dbk", "sao") else run_inter(args, torch)
+        return run_dbk(args, torch) if args.workload in ("dbk", "sao") else run_inter(args, torch, world, rank, local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -675,6 +691,8 @@ def main():
     args.lanes = lanes
     enc = hm355.Encoder(args.width, args.height, bd, 1, args.frames * lanes)
     build_id = enc.lib.hm355_build_id().decode()
+    if lanes > 1:
+        enc.set_lane_share(lanes)
     # synthetic clip: 16 distinct frames per rank (rank r takes frames 16r .. 16r+15), cycled over the picture slots; resident in HBM before timing
     distinct = pre_frames
     for i in range(args.frames * lanes):

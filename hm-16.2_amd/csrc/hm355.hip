@@ -204,7 +204,7 @@ struct hm355_ctx {
   std::vector<Slot> slots;
   Lane lane[HM_MAX_LANES];   // lane 0 is the context's own stream / scratch (every blocking entry point); 1.. are created on first use
   hipStream_t stream; hipEvent_t ev0, ev1;
-  double lastKernelMs; int lastLaunches;
+  double lastKernelMs; int lastLaunches; int laneShare;
   std::string err;
   int numCtus;
   void *staging; size_t stagingBytes;
@@ -243,7 +243,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
-  c->cfg = *cfg; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
+  c->cfg = *cfg; c->laneShare = 1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
   c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
   for (int l = 0; l < HM_MAX_LANES; l++) { Lane &L = c->lane[l]; L.stream = NULL; L.ev0 = L.ev1 = NULL; L.dP = NULL; L.dWs = NULL; L.wsCount = 0; L.dItems = NULL; L.itemsCap = 0; L.dSched = NULL; L.keyValid = 0; L.fewWaves = -1; L.busy = 0; L.grid = 0; L.inFixup = 0; L.dTeamWin = NULL; L.teamCap = 0; }
   Params &P = c->hp; memset(&P, 0, sizeof(P));
@@ -468,6 +468,10 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
     hipLaunchKernelGGL(hm355_ctu_team_kernel, dim3(L.grid), dim3(64 * HM_TEAM), 0, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
   } else {
     L.grid = total < (int)L.wsCount ? total : (int)L.wsCount;
+    // A caller that keeps `share` launches in flight (hm355_set_lane_share): each launch only takes its share of the searches the device can hold --
+    // a persistent workgroup that waits for a neighbouring CTU keeps its place on the CU, so a launch sized for the whole device would lock the
+    // others out until its tickets run out, and the launches would run one after the other
+    if (c->laneShare > 1) { const int cap = (int)(2816 * 5 / (4 * c->laneShare)); if (L.grid > cap) L.grid = cap; }
     hipLaunchKernelGGL(hm355_ctu_kernel, dim3(L.grid), dim3(64), 0, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
   }
   HM_CHECK(c, hipGetLastError());
@@ -540,6 +544,12 @@ extern "C" int hm355_run_begin(hm355_ctx *c, int lane, int first_slot, int n, co
     if (l != lane && c->lane[l].busy && c->lane[l].keyValid && first_slot < (int)(c->lane[l].key[0] + c->lane[l].key[1]) && (int)c->lane[l].key[0] < first_slot + n)
       return fail(c, HM355_ERR_ARG, "hm355_run_begin: the slots overlap a launch in flight on another lane");
   return run_begin(c, lane, first_slot, n, slices, 0, c->hp.hCtu - 1);
+}
+extern "C" int hm355_set_lane_share(hm355_ctx *c, int launches_in_flight)
+{
+  if (!c || launches_in_flight < 1 || launches_in_flight > HM_MAX_LANES) return HM355_ERR_ARG;
+  c->laneShare = launches_in_flight;
+  return HM355_OK;
 }
 extern "C" int hm355_run_wait(hm355_ctx *c, int lane, double *kernel_ms)
 {

@@ -1163,6 +1163,17 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   int16_t *rqCur = e->u.rq.cur;                              // not used by 32x32 blocks
   uint8_t *rqCtxSig = e->u.rq.ctxSig, *rqCode = e->u.rq.code;   // not used by 32x32 blocks
   uint8_t *cgCtxSet = big ? (uint8_t *)e->u.bufB + 4096 : e->u.rq.cgCtxSet;
+  // ---- 0. nothing to decide when even the largest coefficient quantises to level 0 (the pre-pass below would find no position with a
+  // non-zero rounded level and leave): one pass over the block in raster order, no scan table, no per-position state.  The levels are
+  // not written then -- every caller clears them itself when the block comes back empty.
+  {
+    int mx = 0;
+    HM_PAR_FOR(i, numCoef) { const int a = hm_abs(src[(i >> log2n) * HM_TSTRIDE + (i & (n - 1))]); mx = a > mx ? a : mx; }
+    mx = hm_wave_max_i(mx);
+    const int64_t cap0 = 2147483647LL - (1LL << (qBits - 1)), t0 = (int64_t)mx * quantCoef;
+    const int32_t l0 = (int32_t)(t0 < cap0 ? t0 : cap0);
+    if (((l0 + (1 << (qBits - 1))) >> qBits) == 0) return 0;
+  }
   // ---- 1. pre-pass
   int lastLocal = -1;
   {

@@ -1189,8 +1189,9 @@ HM_DEV inline void set_residual_qt_data(Shared *e, const TU *root, int spatial)
         for (int comp = 0; comp < 3; comp++) {
           if (comp && !t->cW) continue;
           const int n = comp ? t->cW : (1 << t->log2), l2 = hm_log2(n), st = HM_PLANE_STRIDE(comp), po = HM_PLANE_OFF(comp), bx = comp ? t->cx : t->x, by = comp ? t->cy : t->y;
-          if (spatial) { HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); e->ws->resiBest[po + (by + y) * st + bx + x] = e->ws->qtRec[layer][po + (by + y) * st + bx + x]; } }
-          else { const int off = po + (comp ? t->cOff : z * 16); HM_PAR_FOR(i, n * n) e->cc[off + i] = e->ws->qtCoef[layer][off + i]; }
+          const int coded = (m->cbf[comp][t->cuZ + (comp ? t->cRelZ : t->relZ)] >> t->trDepth) & 1;      // an empty block: zeros (irq_check_full leaves its buffers as they were)
+          if (spatial) { HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); e->ws->resiBest[po + (by + y) * st + bx + x] = coded ? e->ws->qtRec[layer][po + (by + y) * st + bx + x] : (Pel)0; } }
+          else { const int off = po + (comp ? t->cOff : z * 16); HM_PAR_FOR(i, n * n) e->cc[off + i] = coded ? e->ws->qtCoef[layer][off + i] : 0; }
         }
         HM_SYNC();
         w.sp--; continue;
@@ -1233,16 +1234,16 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
       reset_bits(&e->cur);
       uint32_t currBits = 0, currDist = 0, nonCoeffBits = 0, nonCoeffDist = 0; double currCost = 0, nonCoeffCost = 0;
       if (!isOne && !isFirst) { HM_PAR_FOR(i, 16) { e->ws->tsCoef[comp][i] = coef[i]; e->ws->tsRec[comp][i] = rq[(i >> 2) * st + (i & 3)]; } HM_SYNC(); }
-      HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int r = resi[y * st + x]; e->bufA[y * HM_TSTRIDE + x] = tsMode ? (r << tshift) : r; }
+      uint32_t sqResi = 0;                                            // SSE of the residual against zero, for the "no coefficients" alternative below
+      { const int shiftSse = (bd - 8) << 1;
+        HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int r = resi[y * st + x]; e->bufA[y * HM_TSTRIDE + x] = tsMode ? (r << tshift) : r; sqResi += (uint32_t)((r * r) >> shiftSse); } }
       HM_SYNC();
       { HM_PROF_BEGIN(e, PR_IQ_FWD); if (!tsMode) fwd_transform(e, n, 0, bd); HM_PROF_END(e, PR_IQ_FWD); }
       int absSum;
       { HM_PROF_BEGIN(e, PR_IQ_RDOQ); absSum = (int)HM_UCALL(rdoq(e, coef, n, comp, SCAN_DIAG, cbfCtx)); HM_PROF_END(e, PR_IQ_RDOQ); }
       par_set8(m->cbf[comp] + zc, (absSum > 0 ? 1 : 0) << trMode, parts);
       if (isFirst || absSum == 0) {
-        const int shiftSse = (bd - 8) << 1; uint32_t sq = 0;
-        HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); const int d = resi[y * st + x]; sq += (uint32_t)((d * d) >> shiftSse); }
-        uint32_t d = hm_wave_sum(sq);
+        uint32_t d = hm_wave_sum(sqResi);
         if (comp) d = (uint32_t)(e->fb.chromaWeight * (double)d);
         nonCoeffDist = d;
         enc_bin(e, &e->cur, C_QT_CBF + (comp ? 5 : 0) + (comp ? t->trDepth : (t->trDepth == 0 ? 1 : 0)), 0);
@@ -1281,12 +1282,10 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
       } else if (tsMode == 1) currCost = HM_MAX_DOUBLE;
       else { currBits = nonCoeffBits; currDist = nonCoeffDist; currCost = nonCoeffCost; }
       if (currCost < minCost || (tsMode == 1 && currCost == minCost)) {
-        if (isFirst && (nonCoeffCost < currCost || absSum == 0)) {
-          HM_PAR_FOR(i, n * n) coef[i] = 0;
-          absSum = 0; currBits = nonCoeffBits; currDist = nonCoeffDist; currCost = nonCoeffCost;
-        }
+        if (isFirst && (nonCoeffCost < currCost || absSum == 0)) { absSum = 0; currBits = nonCoeffBits; currDist = nonCoeffDist; currCost = nonCoeffCost; }
+        // (an empty block's levels and reconstructed residual are not cleared here: nothing reads them while its cbf is 0, and
+        // set_residual_qt_data writes zeros for such a block instead of copying)
         f->absSum[comp] = (uint32_t)absSum; compDist = currDist; minCost = currCost; f->bestTS[comp] = (uint8_t)tsMode;
-        if (absSum == 0) { HM_PAR_FOR(i, n * n) { const int y = i >> l2, x = i & (n - 1); rq[y * st + x] = 0; } }
         HM_SYNC();
       } else {
         HM_PAR_FOR(i, 16) { coef[i] = e->ws->tsCoef[comp][i]; rq[(i >> 2) * st + (i & 3)] = e->ws->tsRec[comp][i]; }

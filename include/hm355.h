@@ -238,6 +238,9 @@ int hm355_download(hm355_ctx *ctx, int slot, hm355_planes *rec, hm355_ctu_out *c
  * lane's stream) and errors.  Launches of different lanes run concurrently, each with its own stream and scratch areas, so the
  * wavefront drain of one group overlaps the fill of the next; slot ranges of launches in flight must not overlap.  I slices. */
 int hm355_run_begin(hm355_ctx *ctx, int lane, int first_slot, int n, const hm355_slice_desc *slices);
+/* how many launches the caller keeps in flight (1..4, default 1): each then takes that share of the device's resident searches, so that they
+ * run side by side instead of one after the other (a waiting persistent workgroup keeps its place on the CU) */
+int hm355_set_lane_share(hm355_ctx *ctx, int launches_in_flight);
 int hm355_run_wait(hm355_ctx *ctx, int lane, double *kernel_ms);
 
 /* CTU-row bands (TEncSlice.cpp:740-755,855-858 are the WPP hand-off points a band boundary cuts through): a picture is
