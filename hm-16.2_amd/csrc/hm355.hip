@@ -32,7 +32,7 @@
 //                               previous CTU in raster order (CABAC chain)                               [no WPP]
 // Hand-off between workgroups follows the agent-scope release/acquire recipe: all stores of the wave, release
 // fence, s_waitcnt, relaxed flag store; consumer: relaxed poll by one lane, acquire fence, plain loads.
-#define HM_SPIN_TIMEOUT_TICKS (150ull * 100000000ull)   /* 150 s of the 100 MHz wall clock: bounds every spin */
+#define HM_SPIN_TIMEOUT_TICKS (40ull * 100000000ull)   /* 40 s of the 100 MHz wall clock: bounds every spin (a dependency is at most a few CTU searches away: tickets are taken in topological order) */
 typedef __attribute__((address_space(1))) unsigned int gu32;   // global address space: never a flat access
 
 // lane 0 polls the flag of one dependency (relaxed, agent scope); returns non-zero when the run must be abandoned
@@ -382,7 +382,7 @@ static int lane_prepare(hm355_ctx *c, int l)
   Lane &L = c->lane[l];
   if (L.stream) return HM355_OK;
   if (l == 0) { L.stream = c->stream; L.ev0 = c->ev0; L.ev1 = c->ev1; L.dP = c->dP; L.dWs = c->dWs; L.wsCount = c->wsCount; L.dSched = c->dSched; L.fewWaves = c->hp.fewWaves; return HM355_OK; }
-  HM_CHECK(c, hipStreamCreate(&L.stream));
+  HM_CHECK(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
   HM_CHECK(c, hipEventCreate(&L.ev0)); HM_CHECK(c, hipEventCreate(&L.ev1));
   L.wsCount = c->wsCount;
   HM_CHECK(c, hipMalloc((void **)&L.dWs, L.wsCount * sizeof(WorkSpace)));
@@ -516,7 +516,9 @@ static int run_wait(hm355_ctx *c, int l, double *kernelMs)
   HM_CHECK(c, hipStreamSynchronize(L.stream));
   float ms = 0; HM_CHECK(c, hipEventElapsedTime(&ms, L.ev0, L.ev1));
   unsigned int sched[2] = {0, 0};
-  HM_CHECK(c, hipMemcpy(sched, L.dSched, sizeof(sched), hipMemcpyDeviceToHost));
+  // on the lane's own stream: a copy on the null stream would wait for the launches of every other lane as well (legacy stream semantics)
+  HM_CHECK(c, hipMemcpyAsync(sched, L.dSched, sizeof(sched), hipMemcpyDeviceToHost, L.stream));
+  HM_CHECK(c, hipStreamSynchronize(L.stream));
   if (sched[1] != 0) return fail(c, HM355_ERR_DEVICE, "scheduler aborted: a dependency wait timed out");
   c->lastKernelMs = ms; c->lastLaunches = 1;
   if (kernelMs) *kernelMs = ms;

@@ -293,9 +293,10 @@ struct TZ {                            // state of one integer motion search (In
   const Pel *org; int orgStride, w, h;
   const Pel *ref; int refStride;
   uint32_t bestSad; int bestX, bestY, bestDist, bestRound, pointNr;
-  int l, r, t, b;
-  int subShift;
+  int16_t l, r, t, b;                  // search range in integer samples (within +-64 of a clipped vector: 16 bits are plenty)
+  int16_t subShift, pad_;
   int16_t lx[16], ly[16]; int8_t lp[16], ld[16];   // search points queued for one batched evaluation (x, y, point number, distance)
+  int16_t wx0, wy0, ww, wh;            // reference window staged in LDS (tz_stage_window): origin in search-point coordinates, size in samples; ww == 0: none
 };
 struct IrqFrame {                      // one level of the inter residual quadtree (xEstimateResidualQT)
   TU t; int8_t phase, child, checkFull, checkSplit, zero; uint8_t bestTS[3];
@@ -399,6 +400,8 @@ __shared__ Shared g_sh;                // the one CTU search of this workgroup (
 static_assert(sizeof(Shared) + 16 <= 14848 && sizeof(Shared) % 8 == 0, "Shared (+ the kernel's work item) must stay within 1/11 of a CU's 160 KB LDS in 512-byte granules (11 CTU searches per CU)");
 #endif
 static_assert(offsetof(Shared, bufA) % 8 == 0 && (16 * HM_TSTRIDE * 4) % 8 == 0, "the RDOQ cost array aliases the lower half of bufA as doubles");
+static_assert(offsetof(Shared, u) == offsetof(Shared, bufA) + sizeof(((Shared *)0)->bufA), "the motion search stages its reference window across bufA and the union behind it");
+#define HM_TZ_WIN_SAMPLES ((int)((sizeof(((Shared *)0)->bufA) + sizeof(((Shared *)0)->u)) / sizeof(Pel)))
 
 HM_DEV inline int hm_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 HM_DEV inline int hm_abs(int v) { return v < 0 ? -v : v; }
@@ -1135,6 +1138,22 @@ HM_DEV inline int ic_rate(HM_LVARG(int32_t, tOne), uint32_t absLevel, int ctxOne
 //      positions with a non-zero quantised magnitude run the level search;
 //   4. the last-position search and sign-bit hiding work the same way: lane-parallel per-group precompute,
 //      then a wave-uniform serial pass in the reference's order.
+// Nothing to decide when even the largest coefficient quantises to level 0: rdoq's pre-pass would find no position with a non-zero rounded level
+// and return 0.  Checked at the call site, in one pass over the block in LDS -- a call of the big stage (register saves and restores through
+// private memory) costs more than the check, and 98 % of the blocks of an inter residual quadtree are empty.  The levels are not written
+// then: every caller clears them itself when a block comes back empty.
+HM_DEV inline int rdoq_is_empty(const Shared *e, int n, int comp)
+{
+  const int chroma = comp != 0, log2n = hm_log2(n);
+  const int qBits = 14 + e->fb.qpPer[chroma] + (15 - e->bitDepth - log2n);
+  const int quantCoef = HM_QUANT_SCALES[e->fb.qpRem[chroma]];
+  int mx = 0;
+  HM_PAR_FOR(i, n * n) { const int a = hm_abs(e->bufA[(i >> log2n) * HM_TSTRIDE + (i & (n - 1))]); mx = a > mx ? a : mx; }
+  mx = hm_wave_max_i(mx);
+  const int64_t cap = 2147483647LL - (1LL << (qBits - 1)), t = (int64_t)mx * quantCoef;
+  const int32_t lvl = (int32_t)(t < cap ? t : cap);
+  return ((lvl + (1 << (qBits - 1))) >> qBits) == 0;
+}
 HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanType, int cbfCtx)
 {
   HM_ENTRY(e); n = HM_UNI(n); comp = HM_UNI(comp); scanType = HM_UNI(scanType); cbfCtx = HM_UNI(cbfCtx); dst = hm_uni_ptr(dst);
@@ -1163,17 +1182,6 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   int16_t *rqCur = e->u.rq.cur;                              // not used by 32x32 blocks
   uint8_t *rqCtxSig = e->u.rq.ctxSig, *rqCode = e->u.rq.code;   // not used by 32x32 blocks
   uint8_t *cgCtxSet = big ? (uint8_t *)e->u.bufB + 4096 : e->u.rq.cgCtxSet;
-  // ---- 0. nothing to decide when even the largest coefficient quantises to level 0 (the pre-pass below would find no position with a
-  // non-zero rounded level and leave): one pass over the block in raster order, no scan table, no per-position state.  The levels are
-  // not written then -- every caller clears them itself when the block comes back empty.
-  {
-    int mx = 0;
-    HM_PAR_FOR(i, numCoef) { const int a = hm_abs(src[(i >> log2n) * HM_TSTRIDE + (i & (n - 1))]); mx = a > mx ? a : mx; }
-    mx = hm_wave_max_i(mx);
-    const int64_t cap0 = 2147483647LL - (1LL << (qBits - 1)), t0 = (int64_t)mx * quantCoef;
-    const int32_t l0 = (int32_t)(t0 < cap0 ? t0 : cap0);
-    if (((l0 + (1 << (qBits - 1))) >> qBits) == 0) return 0;
-  }
   // ---- 1. pre-pass
   int lastLocal = -1;
   {
@@ -1886,7 +1894,7 @@ HM_DEV HM_NOINLINE uint32_t intra_coding_tu_block(Shared *e, TU tv, int comp, in
   { HM_PROF_BEGIN(e, PR_FWD); if (!tskip) fwd_transform(e, n, comp == 0 && n == 4, bitDepth); HM_PROF_END(e, PR_FWD); }      // TComTrQuant::xT, :1805
   const int cbfCtx = comp ? 5 + t->trDepth : (t->trDepth == 0 ? 1 : 0);
   HM_PROF_BEGIN(e, PR_RDOQ);
-  const int absSum = HM_UCALL(rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx));
+  const int absSum = rdoq_is_empty(e, n, comp) ? 0 : (int)HM_UCALL(rdoq(e, coef, n, comp, coef_scan_idx(m, z, n, comp), cbfCtx));
   HM_PROF_END(e, PR_RDOQ);
 #if defined(HM355_PROFILE) && !defined(HM355_HOSTSIM)
   { const int pid = l2 == 2 ? (absSum ? 13 : 7) : (l2 == 3 ? 14 : (l2 == 4 ? 15 : 43)); e->prof[pid] += __builtin_readcyclecounter() - prof_t0_PR_RDOQ; e->profCnt[pid] += 1; }

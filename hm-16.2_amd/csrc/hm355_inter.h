@@ -430,6 +430,32 @@ HM_DEV inline uint32_t mc_cost32(const Shared *e, uint32_t b) { return (uint32_t
 // row reads, a DPP prefix inside the group leaves the sum in its last lane, which also prices the motion vector; the pass's winner is the
 // cheapest point, the first one on a tie -- what the reference's one-by-one update with strict "<" arrives at -- and the running best is
 // updated once per pass on the scalar unit.
+// LDS-staged reference window (north_star: "LDS-staged pixel tiles" for block matching): the samples every search point within R of a centre can
+// touch -- (w + 2R) x (h + 2R), clipped to the search range -- are copied once into the transform buffers (idle during the motion search: 8.4 KB),
+// eight loads in flight per lane, and the passes whose points all lie inside read LDS instead of the reference plane.  Used where every point is
+// known to fall inside and the points are many: the +-4 full search of the bi-prediction refinement (xPatternSearch :3932, 81 points from one
+// (w + 8) x (h + 8) window).  Measured and NOT used for the TZ diamonds (xTZSearch :4027): their 4-8 points per round read L2-resident rows with the
+// loads of a pass in flight together, and staging a +-16 window cost more than the rounds it served saved (45 k instead of 29 k cycles per search);
+// the raster scan would need (w + 128) x (h + 128).
+HM_DEV inline void tz_stage_window(Shared *e, TZ *z, int cx, int cy, int R)
+{
+  const int w = z->w, h = z->h;
+  z->ww = 0;
+  if ((w + 2 * R) * (h + 2 * R) > HM_TZ_WIN_SAMPLES) return;
+  const int x0 = cx - R > z->l ? cx - R : z->l, x1 = cx + R < z->r ? cx + R : z->r, y0 = cy - R > z->t ? cy - R : z->t, y1 = cy + R < z->b ? cy + R : z->b;
+  if (x1 < x0 || y1 < y0) return;
+  const int ww = x1 - x0 + w, wh = y1 - y0 + h, sr = z->refStride, total = ww * wh;
+  const Pel *src = z->ref + (ptrdiff_t)y0 * sr + x0; Pel *win = (Pel *)e->bufA;
+  for (int base = 0; base < total; base += 8 * HM_NT) {
+    Pel v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int i = base + k * HM_NT + hm_lane(); const int y = i / ww, x = i - y * ww; v[k] = i < total ? src[(ptrdiff_t)y * sr + x] : (Pel)0; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int i = base + k * HM_NT + hm_lane(); if (i < total) win[i] = v[k]; }
+  }
+  z->wx0 = (int16_t)x0; z->wy0 = (int16_t)y0; z->ww = (int16_t)ww; z->wh = (int16_t)wh;
+  HM_SYNC();
+}
 #define TZ_PUSH(z, n, X, Y, PN, D) do { (z)->lx[n] = (int16_t)(X); (z)->ly[n] = (int16_t)(Y); (z)->lp[n] = (int8_t)(PN); (z)->ld[n] = (int8_t)(D); (n)++; } while (0)
 HM_DEV HM_NOINLINE void tz_eval_list(Shared *e, int n)
 {
@@ -439,20 +465,43 @@ HM_DEV HM_NOINLINE void tz_eval_list(Shared *e, int n)
   const int so = HM_UNI(z->orgStride), sr = HM_UNI(z->refStride), w = HM_UNI(z->w), h = HM_UNI(z->h), sub = HM_UNI(z->subShift), bd = e->bitDepth;
   const int rows = h >> sub, so2 = so << sub, sr2 = sr << sub, S = rows * w;
   const int groups = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : 16))), L = 64 / groups;      // lanes per point
+  // all points of the pass inside the staged window?
+  const int ww = HM_UNI(z->ww), wx0 = HM_UNI(z->wx0), wy0 = HM_UNI(z->wy0), wh = HM_UNI(z->wh);
+  int inWin = ww != 0;
+  for (int pnt = 0; pnt < n && inWin; pnt++) { const int px = z->lx[pnt], py = z->ly[pnt]; inWin = px >= wx0 && px <= wx0 + ww - w && py >= wy0 && py <= wy0 + wh - h; }
+  inWin = HM_UNI(inWin);
   HM_LV(int32_t, vCost);
-  HM_WAVE_FOR(k) {
-    const int pnt = k / L, j = k - pnt * L;
-    uint32_t sum = 0;
-    if (pnt < n) {
-      const Pel *r = ref + (ptrdiff_t)z->ly[pnt] * sr + z->lx[pnt];
-      const int sy = L / w, sx = L - sy * w;
-      int yy = j / w, x = j - yy * w;
-      for (int i = j; i < S; i += L) {
-        sum += (uint32_t)hm_abs(org[yy * so2 + x] - r[yy * sr2 + x]);
-        x += sx; yy += sy; if (x >= w) { x -= w; yy++; }
+  if (inWin) {
+    const Pel *win = (const Pel *)e->bufA; const int sw2 = ww << sub;
+    HM_WAVE_FOR(k) {
+      const int pnt = k / L, j = k - pnt * L;
+      uint32_t sum = 0;
+      if (pnt < n) {
+        const Pel *r = win + (z->ly[pnt] - wy0) * ww + (z->lx[pnt] - wx0);
+        const int sy = L / w, sx = L - sy * w;
+        int yy = j / w, x = j - yy * w;
+        for (int i = j; i < S; i += L) {
+          sum += (uint32_t)hm_abs(org[yy * so2 + x] - r[yy * sw2 + x]);
+          x += sx; yy += sy; if (x >= w) { x -= w; yy++; }
+        }
       }
+      HM_LVK(vCost, k) = (int32_t)sum;
     }
-    HM_LVK(vCost, k) = (int32_t)sum;
+  } else {
+    HM_WAVE_FOR(k) {
+      const int pnt = k / L, j = k - pnt * L;
+      uint32_t sum = 0;
+      if (pnt < n) {
+        const Pel *r = ref + (ptrdiff_t)z->ly[pnt] * sr + z->lx[pnt];
+        const int sy = L / w, sx = L - sy * w;
+        int yy = j / w, x = j - yy * w;
+        for (int i = j; i < S; i += L) {
+          sum += (uint32_t)hm_abs(org[yy * so2 + x] - r[yy * sr2 + x]);
+          x += sx; yy += sy; if (x >= w) { x -= w; yy++; }
+        }
+      }
+      HM_LVK(vCost, k) = (int32_t)sum;
+    }
   }
 #ifdef HM355_HOSTSIM
   for (int pnt = 0; pnt < groups; pnt++) { int32_t t = 0; for (int j = 0; j < L; j++) t += vCost[pnt * L + j]; vCost[pnt * L + L - 1] = t; }
@@ -566,7 +615,7 @@ HM_DEV inline uint32_t tz_search(Shared *e, TZ *z, MvD *mv, int cuX, int cuY, Mv
   int rl = lt.x, rr = rb.x, rt = lt.y, rbm = rb.y;
   z->l = lt.x; z->r = rb.x; z->t = lt.y; z->b = rb.y;
   MvD c = clip_mv(e, *mv, cuX, cuY); c.x >>= 2; c.y >>= 2;
-  z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0;
+  z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0; z->ww = 0;
   { // the start points (:4066-4090): predictor, zero vector, the 2Nx2N integer vector -- independent evaluations, one pass
     int n_ = 0;
     TZ_PUSH(z, n_, c.x, c.y, 0, 0); TZ_PUSH(z, n_, 0, 0, 0, 0);
@@ -650,7 +699,9 @@ HM_DEV inline uint32_t pattern_refinement(Shared *e, TZ *z, const Pel *refAtInt,
 // xPatternSearch :3932-3988: full search over the (small) bi-prediction range, one point per tz_help call
 HM_DEV inline uint32_t pattern_search(Shared *e, TZ *z, MvD *mv, MvD lt, MvD rb)
 {
-  z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0;
+  z->bestSad = 0xffffffffu; z->bestX = z->bestY = 0; z->bestDist = 0; z->bestRound = 0; z->pointNr = 0; z->ww = 0;
+  z->l = lt.x; z->r = rb.x; z->t = lt.y; z->b = rb.y;
+  tz_stage_window(e, z, (lt.x + rb.x) >> 1, (lt.y + rb.y) >> 1, 5);     // all 81 points from one window
   int n_ = 0;
   for (int y = lt.y; y <= rb.y; y++) for (int x = lt.x; x <= rb.x; x++) { TZ_PUSH(z, n_, x, y, 0, 0); if (n_ == 16) { tz_eval_list(e, n_); n_ = 0; } }
   if (n_) tz_eval_list(e, n_);
@@ -1240,7 +1291,7 @@ HM_DEV HM_NOINLINE void irq_check_full(Shared *e, int sp)
       HM_SYNC();
       { HM_PROF_BEGIN(e, PR_IQ_FWD); if (!tsMode) fwd_transform(e, n, 0, bd); HM_PROF_END(e, PR_IQ_FWD); }
       int absSum;
-      { HM_PROF_BEGIN(e, PR_IQ_RDOQ); absSum = (int)HM_UCALL(rdoq(e, coef, n, comp, SCAN_DIAG, cbfCtx)); HM_PROF_END(e, PR_IQ_RDOQ); }
+      { HM_PROF_BEGIN(e, PR_IQ_RDOQ); absSum = rdoq_is_empty(e, n, comp) ? 0 : (int)HM_UCALL(rdoq(e, coef, n, comp, SCAN_DIAG, cbfCtx)); HM_PROF_END(e, PR_IQ_RDOQ); }
       par_set8(m->cbf[comp] + zc, (absSum > 0 ? 1 : 0) << trMode, parts);
       if (isFirst || absSum == 0) {
         uint32_t d = hm_wave_sum(sqResi);
