@@ -7,11 +7,14 @@
 A "step" = one pass of the hot path (the TEncSlice::compressSlice replacement) over one batch of
 independent all-intra pictures that are already resident in HBM: synthetic 3840x2160 10-bit frames,
 encoder_intra_main10 parameters, QP 32, WaveFrontSynchro=1 (BASELINE.json configs[3], the configuration
-the metric is quoted on; it fits one GPU).  Consecutive steps are pipelined over `--lanes` HIP streams
-(hm355_run_begin / hm355_run_wait): each step has its own picture slots and its own launch, step k + lanes
-is issued once step k has finished, so the wavefront drain of one step overlaps the fill of the next ones
-and the device stays full with far fewer pictures per step.  The timed region holds exactly K steps between
-two barrier + synchronize pairs: the pipeline is empty when it starts and when it ends.
+the metric is quoted on; it fits one GPU).  By default every step is one launch over `--frames` pictures
+(768: the wavefront fill and drain are a small share of the launch); the timed region holds exactly K steps
+between two barrier + synchronize pairs.  `--lanes L` (optional, default 1) pipelines consecutive steps over L
+HIP streams (hm355_run_begin / hm355_run_wait): each step has its own picture slots and its own launch and
+step k + L is issued once step k has finished, so the drain of one step overlaps the fill of the next.
+Measured: two launches do overlap, but 2 x 192 or 4 x 160 pictures in flight run below
+one 768-picture launch, so the headline keeps the single launch.  `--workload c2|c3` run BASELINE.json's
+configs[1] / configs[2] exactly as stated (one picture; a 16-picture low-delay-P stream) for the latency figures.
 Every rank owns one GPU and its own batches (weak scaling: the path shards by picture with no data-path
 collective); RCCL is used only for the barrier / max-time.
 """
@@ -616,7 +619,7 @@ def intra_line(args, world, rows_mode, group, steps, warmup, dt, kernel_ms, laun
         "dtype": "int32+f64", "data": "synthetic",
         "config": {"workload": f"encoder_intra_main10, synthetic {args.width}x{args.height} 10-bit, QP {args.qp}, WaveFrontSynchro=1, " +
                                (f"{args.frames} independent I pictures per step shared by the ranks" if rows_mode else
-                                f"{args.frames} independent I pictures per GPU per step, steps pipelined {args.lanes} deep") +
+                                f"{args.frames} independent I pictures per GPU per step, " + ("one launch per step" if args.lanes == 1 else f"steps pipelined {args.lanes} deep")) +
                                f" ({min(DISTINCT_FRAMES, args.frames)} distinct frames), inputs resident in HBM",
                    "frames_per_gpu": args.frames, "ctus_per_step": total_ctus // steps, "lanes": 1 if rows_mode else args.lanes, "build_id": build_id,
                    "parallelism": (f"CTU rows of every picture sharded over {world} GPUs in bands, boundary rows handed down over RCCL send / recv, {group} pictures per pipeline stage"

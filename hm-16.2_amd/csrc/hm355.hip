@@ -32,7 +32,7 @@
 //                               previous CTU in raster order (CABAC chain)                               [no WPP]
 // Hand-off between workgroups follows the agent-scope release/acquire recipe: all stores of the wave, release
 // fence, s_waitcnt, relaxed flag store; consumer: relaxed poll by one lane, acquire fence, plain loads.
-#define HM_SPIN_TIMEOUT_TICKS (40ull * 100000000ull)   /* 40 s of the 100 MHz wall clock: bounds every spin (a dependency is at most a few CTU searches away: tickets are taken in topological order) */
+#define HM_SPIN_TIMEOUT_TICKS (40ull * 100000000ull)   /* 40 s of the 100 MHz wall clock without ANY CTU of the launch being published: bounds every spin (the oldest unfinished ticket always runs, and one CTU search takes at most a second or two) */
 typedef __attribute__((address_space(1))) unsigned int gu32;   // global address space: never a flat access
 
 // lane 0 polls the flag of one dependency (relaxed, agent scope); returns non-zero when the run must be abandoned
@@ -41,10 +41,18 @@ __device__ __attribute__((noinline)) int hm355_wait_flag(const unsigned int *fla
   int bad = 0;
   if (threadIdx.x == 0) {
     const gu32 *f = (const gu32 *)flag; gu32 *ab = (gu32 *)abortWord;
-    const unsigned long long t0 = wall_clock64();
+    unsigned long long t0 = wall_clock64();
+    unsigned int seen = __hip_atomic_load(ab + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // CTUs the launch has published so far
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
       __builtin_amdgcn_s_sleep(32);
-      if (__hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > HM_SPIN_TIMEOUT_TICKS) {
+      int stop = __hip_atomic_load(ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      if (!stop && wall_clock64() - t0 > HM_SPIN_TIMEOUT_TICKS) {
+        // a serial CABAC chain (no WPP) legitimately keeps the last ticket holders waiting for minutes: give up only when the
+        // whole launch has published nothing for the length of the timeout
+        const unsigned int now = __hip_atomic_load(ab + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (now != seen) { seen = now; t0 = wall_clock64(); } else stop = 1;
+      }
+      if (stop) {
         __hip_atomic_store(ab, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tell everybody to drain
         bad = 1; break;
       }
@@ -82,7 +90,7 @@ extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Param
     process_ctu(&g_sh, P, &curItem, (int)blockIdx.x);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) { __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add((gu32 *)(sched + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __syncthreads();
   }
 }
@@ -90,7 +98,7 @@ extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Param
 // The same scheduler with a TEAM of wavefronts per CTU (hm355_team.h): wave 0 takes the tickets, waits for the dependencies and runs the
 // reference's recursion; waves 1.. evaluate the unsplit candidates it hands them.  Used for launches that cannot fill the device with
 // one-wavefront searches (a few pictures, or pictures whose CABAC state chains through every CTU), where the time of ONE CTU search is
-// what the launch takes.  I slices.
+// what the launch takes.
 extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
 {
   Team *T = &g_team;
@@ -117,15 +125,17 @@ extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_ker
       if (cx > 0) dep0 = a - 1;
       if (cy > 0) dep1 = (cy - 1) * wCtu + (cx + 1 < wCtu ? cx + 1 : cx);
     } else if (a > 0) dep0 = a - 1;
+    const int dep2 = (P->wpp && cx == 0 && cy > 0 && P->frames[T->item.frame].imeta && (63 >= P->width || cy * 64 + 63 >= P->height)) ? a - 1 : -1;   // as in hm355_ctu_kernel
     int bad = 0;
     if (dep0 >= 0) bad = hm355_wait_flag(done + dep0, sched + 1, epoch);
     if (!bad && dep1 >= 0) bad = hm355_wait_flag(done + dep1, sched + 1, epoch);
+    if (!bad && dep2 >= 0) bad = hm355_wait_flag(done + dep2, sched + 1, epoch);
     if (bad) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     process_ctu(&T->sh[0], P, &T->item, (int)blockIdx.x * HM_TEAM, T);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) { __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add((gu32 *)(sched + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     HM_SYNC();
     if (team_ld(&T->dead)) break;
   }
@@ -186,7 +196,7 @@ struct Lane {           // one launch of the search in flight: its own stream, s
   Params *dP;           // device copy of the kernel parameters with this lane's scratch areas
   WorkSpace *dWs; size_t wsCount;
   WorkItem *dItems; size_t itemsCap;
-  unsigned int *dSched; // [0] ticket, [1] abort
+  unsigned int *dSched; // [0] ticket, [1] abort, [2] CTUs published by the launch (the spin timeout watches it)
   std::vector<WorkItem> items; std::vector<int> stepStart; std::vector<FrameBuf> fbs;
   long long key[5]; int keyValid, fewWaves;
   int busy, grid, inFixup;
@@ -200,7 +210,7 @@ struct hm355_ctx {
   FrameBuf *dFrames;
   WorkSpace *dWs; size_t wsCount;
   uint8_t *arena;       // the pictures' planes, decision arrays, coefficients, statistics, CABAC states, done words: one allocation
-  unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort of the search launch; [8] ticket, [9] abort of the bitstream launch
+  unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort, [2] published CTUs of the search launch; [8] ticket, [9] abort of the bitstream launch
   std::vector<Slot> slots;
   Lane lane[HM_MAX_LANES];   // lane 0 is the context's own stream / scratch (every blocking entry point); 1.. are created on first use
   hipStream_t stream; hipEvent_t ev0, ev1;
@@ -428,12 +438,11 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
   }
   // A WPP picture offers about 16 CTUs at a time (one when the CABAC state chains through all of them).  A launch that cannot keep ~5
   // one-wavefront searches per CU busy prefers the shortest dependency chain over the fewest instructions (fewWaves); one that cannot
-  // even give every CU two searches runs as teams of HM_TEAM wavefronts per CTU (I slices; HM355_TEAM=0 / 1 overrides for A/B runs).
+  // even give every CU two searches runs as teams of HM_TEAM wavefronts per CTU (HM355_TEAM=0 / 1 overrides for A/B runs).
   const long long parallel = (long long)n * (P.wpp ? 16 : 1);
   const int fewWaves = parallel < 1280 ? 1 : 0;
   int useTeam = parallel <= 512 && L.wsCount >= HM_TEAM;
-  for (int f = 0; f < n; f++) if (c->slots[slot0 + f].fb.imeta) useTeam = 0;
-  { const char *ev = getenv("HM355_TEAM"); if (ev && ev[0] == '0') useTeam = 0; if (ev && ev[0] == '1' && L.wsCount >= HM_TEAM && !carry) { useTeam = 1; for (int f = 0; f < n; f++) if (c->slots[slot0 + f].fb.imeta) useTeam = 0; } }
+  { const char *ev = getenv("HM355_TEAM"); if (ev && ev[0] == '0') useTeam = 0; if (ev && ev[0] == '1' && L.wsCount >= HM_TEAM) useTeam = 1; }
   const size_t winSamples = (size_t)65 * P.stride[0] + (size_t)33 * (P.stride[1] + P.stride[2]);
   int teams = 0;
   if (useTeam) {
@@ -458,7 +467,7 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
     L.fewWaves = fewWaves;
   }
   c->epoch++; if (c->epoch == 0) c->epoch = 1;
-  HM_CHECK(c, hipMemsetAsync(L.dSched, 0, 8, L.stream));        // ticket = 0, abort = 0
+  HM_CHECK(c, hipMemsetAsync(L.dSched, 0, 12, L.stream));       // ticket = 0, abort = 0, published CTUs = 0
   if (row0 > 0)    // the row above the band is complete: its CTUs count as published in this run
     for (int f = 0; f < n; f++) HM_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(c->slots[slot0 + f].fb.done + (size_t)(row0 - 1) * P.wCtu), (int)c->epoch, P.wCtu, L.stream));
   HM_CHECK(c, hipEventRecord(L.ev0, L.stream));

@@ -284,7 +284,7 @@ struct TuWalk { TU node[5]; int8_t next[5]; int sp; };
 struct RqtFrame {
   TU t; int8_t phase, child, checkFull, checkSplit, bestModeId; uint32_t singleDist, singleCbf, splitDist, splitCbf, singleBits; double singleCost, splitCost;
 };
-struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary, parentPart; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
+struct CuFrame { int16_t cuZ; int8_t phase, sub, boundary, parentPart, ampSens, pad_; double bestCost, splitCost; uint32_t bestBits, bestDist, splitBits, splitDist; };
 // inter (P / B slice) helpers kept in LDS
 struct MvFieldD { MvD mv; int ref; };
 struct MergeList { MvFieldD f[5][2]; uint8_t dir[5]; int num; };
@@ -2814,7 +2814,8 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
 #if !defined(HM355_HOSTSIM)
   // (a team hands the 64x64 candidate to a helper while it goes on: with m_bEncodeDQP set the later candidates would need to know whether that
   // one consumed it, so such a CTU -- rare -- is searched by the main wavefront alone)
-  if (team && !(e->fb.dqp && HM_UNI(e->ws->dq.flag))) compress_ctu_team(e); else
+  if (team && e->im && !e->fb.dqp) compress_ctu_team_inter(e);
+  else if (team && !e->im && !(e->fb.dqp && HM_UNI(e->ws->dq.flag))) compress_ctu_team(e); else
 #endif
   compress_ctu(e);
   e->fb.stat[a].cost = e->outCost; e->fb.stat[a].bits = e->outBits; e->fb.stat[a].dist = e->outDist;

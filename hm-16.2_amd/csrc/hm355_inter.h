@@ -206,7 +206,7 @@ HM_DEV inline int nb_at(const Shared *e, int x4, int y4, int dir, int curZ, int 
   return cy * e->wCtu + cx;
 }
 HM_DEV inline const CtuMeta *cmeta_of(const Shared *e, int ca) { return ca == e->ctuAddr ? &e->meta : e->fb.meta + ca; }
-HM_DEV inline const InterMeta *imeta_of(const Shared *e, int ca) { return e->fb.imeta + ca; }
+HM_DEV inline const InterMeta *imeta_of(const Shared *e, int ca) { return ca == e->ctuAddr ? e->im : e->fb.imeta + ca; }   // (a team helper searches on a private copy, hm355_team.h)
 HM_DEV inline int nb_is_inter(const Shared *e, int ca, int z) { return cmeta_of(e, ca)->pred[z] == MODE_INTER; }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,10 +711,10 @@ HM_DEV inline uint32_t pattern_search(Shared *e, TZ *z, MvD *mv, MvD lt, MvD rb)
 // xMotionEstimation :3816-3906; results in e->outMv / e->outBits / e->outDist(cost).
 // bi != 0: (inX, inY) is this list's uni-directional MV (search centre, quarter samples) and the pattern is
 // 2*org - prediction of the other list (ws->yuvPred[1-list]), TComYuv::removeHighFreq :393 without clipping
-HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int predX, int predY, int listRef, uint32_t bitsIn, int bi, int inX, int inY)
+HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int predX, int predY, int listRef, uint32_t bitsIn, int bi, int inX, int inY, int intOnly = 0)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); partSize = HM_UNI(partSize); puIdx = HM_UNI(puIdx); predX = HM_UNI(predX); predY = HM_UNI(predY); listRef = HM_UNI(listRef); bitsIn = HM_UCALL(bitsIn);
-  bi = HM_UNI(bi); inX = HM_UNI(inX); inY = HM_UNI(inY);
+  bi = HM_UNI(bi); inX = HM_UNI(inX); inY = HM_UNI(inY); intOnly = HM_UNI(intOnly);
   const int list = listRef >> 4, refIdx = listRef & 15;
   InterPic *s = e->fb.ip;
   const Rect r = pu_rect(cuZ, cuDepth, partSize, puIdx);
@@ -747,6 +747,7 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
     if (partSize == SIZE_2Nx2N) e->ws->intMv[list][refIdx] = mv;
   }
   HM_PROF_END(e, PR_ME_INT);
+  if (intOnly) return;                       // me_token_prepass: only m_integerMv2Nx2N is wanted
   HM_PROF_BEGIN(e, PR_ME_FRAC);
   e->costScale = 1;
   const Pel *refAtInt = z.ref + (ptrdiff_t)mv.y * z.refStride + mv.x;

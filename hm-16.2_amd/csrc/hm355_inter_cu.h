@@ -55,11 +55,31 @@ HM_DEV HM_NOINLINE void check_rd_cost_inter(Shared *e, int cuZ, int cuDepth, int
   check_dqp(e, cuZ, cuDepth);                                     // TEncCu.cpp:1563
   check_best_mode(e, f, cuZ, cuDepth);
 }
+// TEncSearch::m_integerMv2Nx2N as the 2Nx2N motion search of this CU leaves it (xMotionEstimation :3880-3888, :3938): the AMVP predictor and the
+// integer search of every (list, reference index) the uni-directional loop of predInterSearch visits, nothing else.  The team search
+// (hm355_team.h) runs it on the main wavefront so that the sub-CUs can start while a helper evaluates the CU's candidates.
+HM_DEV HM_NOINLINE void me_token_prepass(Shared *e, int cuZ, int cuDepth)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth);
+  const InterPic *s = e->fb.ip; CtuMeta *m = &e->meta; const int parts = 256 >> (2 * cuDepth);
+  init_est_data(e, cuZ, cuDepth);
+  par_set8(m->part + cuZ, SIZE_2Nx2N, parts); par_set8(m->pred + cuZ, MODE_INTER, parts);
+  const int numPredDir = s->sliceType == HM_P_SLICE ? 1 : 2;
+  uint32_t distBiP = 0xffffffffu;
+  for (int list = 0; list < numPredDir; list++)
+    for (int ri = 0; ri < s->numRefIdx[list]; ri++) {
+      if (list == 1 && s->list1ToList0[ri] >= 0) continue;         // GPB_SIMPLE_UNI: no search, the entry keeps its value
+      int mvpIdx;
+      const MvD mvPred = estimate_mvp_amvp(e, cuZ, cuDepth, SIZE_2Nx2N, 0, list, ri, &e->amvp, &mvpIdx, &distBiP);
+      motion_estimation(e, cuZ, cuDepth, SIZE_2Nx2N, 0, mvPred.x, mvPred.y, (list << 4) | ri, 0, 0, 0, 0, 1);
+    }
+}
 // the mode tests of one CU in a P / B slice (TEncCu::xCompressCU :600-857 with ESD/CFM/ECU off)
 HM_DEV HM_NOINLINE void compress_cu_inter_modes(Shared *e, int cuZ, int cuDepth, int sp)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp);
   CuFrame *f = &e->cuf[sp];
+  f->ampSens = 0;
   { HM_PROF_BEGIN(e, PR_MRG2N); check_rd_cost_merge_2Nx2N(e, cuZ, cuDepth, sp); HM_PROF_END(e, PR_MRG2N); }
   check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2Nx2N, 0, sp);
   check_rd_cost_inter(e, cuZ, cuDepth, SIZE_Nx2N, 0, sp);
@@ -75,6 +95,7 @@ HM_DEV HM_NOINLINE void compress_cu_inter_modes(Shared *e, int cuZ, int cuDepth,
     if (parent == SIZE_NONE) { if (ps == SIZE_2NxN) mh = 1; else if (ps == SIZE_Nx2N) mv = 1; }
     if (ps == SIZE_2Nx2N && !bskip) { mh = 1; mv = 1; }
     if ((64 >> cuDepth) == 64) { hor = 0; ver = 0; }
+    f->ampSens = (int8_t)((!hor && !mh) || (!ver && !mv));    // a parent with an AMP part size would add merge-only AMP candidates here (team search, hm355_team.h)
     if (hor) { check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnU, 0, sp); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnD, 0, sp); }
     else if (mh) { check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnU, 1, sp); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnD, 1, sp); }
     if (ver) { check_rd_cost_inter(e, cuZ, cuDepth, SIZE_nLx2N, 0, sp); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_nRx2N, 0, sp); }

@@ -17,8 +17,19 @@
 // The exact work skipping of the one-wavefront search (hm355_core.h, compress_ctu) needs the unsplit cost before the sub-CUs
 // start; here it is applied whenever the helper happens to have answered already -- it never changes a result, so the answer's
 // timing does not matter.
-// I slices.  The wavefronts of a team share one CU, so the request / done words live in LDS and workgroup-scope fences order the
+// The wavefronts of a team share one CU, so the request / done words live in LDS and workgroup-scope fences order the
 // HBM traffic between them.
+// P / B slices (compress_ctu_team_inter): helper d evaluates the whole candidate chain of the unsplit CU of depth d = 0, 1, 2
+// (compress_cu_inter_modes: merge, 2Nx2N, Nx2N, 2NxN, AMP, intra), the main wavefront the 8x8 CUs.  Two things the reference chains
+// through the quadtree cross the wavefronts:
+//   * TEncSearch::m_integerMv2Nx2N (TEncSearch.cpp:3880-3888): every 2Nx2N integer search starts from the result of the previous one
+//     in evaluation order.  The unsplit CU's own 2Nx2N search depends on nothing else of its candidate chain, so the main wavefront
+//     repeats just that search (me_token_prepass) after handing the helper the state before it, and goes on with the state after it;
+//   * deriveTestModeAMP (TEncCu.cpp:386-447) gives a sub-CU the part size of its parent's best unsplit mode, which the helper has not
+//     found yet when the sub-CUs start.  It only matters when that part size is an AMP one (then merge-only AMP candidates are added
+//     where the sub-CU's own best mode does not ask for them): the sub-CUs are searched as if it were not, every candidate chain
+//     reports whether an AMP parent would have changed its candidate list (CuFrame::ampSens), and when the parent's answer is AMP and
+//     a sub-CU was sensitive, the four sub-CUs are searched again with the part size known -- nothing outside the CU has seen them yet.
 #pragma once
 
 #define HM_TEAM 5
@@ -27,7 +38,7 @@
 
 struct TeamBox {                       // mailbox of one helper
   uint32_t reqSeq, doneSeq;            // main: arguments, release, reqSeq + 1;  helper: results, release, doneSeq = reqSeq
-  int32_t cuZ, depth, part, pad;
+  int32_t cuZ, depth, part, sens;      // part: I slice: the part size to evaluate; P / B slice: the parent's part size (deriveTestModeAMP); sens: CuFrame::ampSens of the answer
   uint32_t bits, dist; double cost;    // the candidate as xCheckBestMode sees it (split flag of the unsplit CU included)
 };
 struct Team {
@@ -195,6 +206,114 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
   e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
 }
 
+// TEncCu::compressCtu -> xCompressCU for a P / B slice: the unsplit CUs of depth 0..2 with the helpers, the 8x8 CUs here (see the head of this file)
+HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
+{
+  HM_ENTRY(e);
+  CtuMeta *m = (&e->meta);
+  CuFrame *fr = e->cuf; int sp = 0;
+  fr[0].cuZ = 0; fr[0].phase = 0; fr[0].parentPart = SIZE_NONE;
+  double retCost = 0; uint32_t retBits = 0, retDist = 0;
+  int pending[3] = {0, 0, 0};          // the unsplit CU of this depth is with its helper
+  int guessed[3] = {0, 0, 0};          // a sub-CU of this depth's CU started before the helper had answered: its parent part size was taken as "not AMP"
+  int sensitive[3] = {0, 0, 0};        // ... and its candidate list would have been another one under an AMP parent
+  while (sp >= 0) {
+    CuFrame *f = &fr[sp]; const int cuDepth = sp, cuZ = f->cuZ;
+    const int size = 64 >> cuDepth, parts = 256 >> (2 * cuDepth), q = parts >> 2;
+    if (f->phase == 0) {
+      const int r = hm_z2r(cuZ);
+      const int lx = e->ctuX * 64 + (r & 15) * 4, ty = e->ctuY * 64 + (r >> 4) * 4;
+      f->boundary = !((lx + size - 1 < e->width) && (ty + size - 1 < e->height));
+      f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
+      if (cuDepth == 3) {               // TEncCu.cpp:628-863 at the smallest CU size, as compress_ctu does it
+        if (!f->boundary) {
+          compress_cu_inter_modes(e, cuZ, cuDepth, sp);
+          reset_bits(&e->cur);
+          f->bestBits += num_bits(&e->cur);
+          f->bestCost = calc_rd_cost(e, f->bestBits, f->bestDist);
+        }
+        restore_best(e, cuZ, cuDepth); retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
+      }
+      pending[cuDepth] = 0; guessed[cuDepth] = 0; sensitive[cuDepth] = 0;
+      if (!f->boundary) {
+        WorkSpace *hw = team_helper_ws(e, cuDepth);
+        HM_PAR_FOR(i, 32) hw->intMv[i >> 4][i & 15] = e->ws->intMv[i >> 4][i & 15];   // m_integerMv2Nx2N as the unsplit CU finds it
+        HM_SYNC();
+        team_post(e, cuDepth, cuZ, cuDepth, f->parentPart);
+        pending[cuDepth] = 1;
+        me_token_prepass(e, cuZ, cuDepth);                                             // ... and as it leaves it
+        HM_PAR_FOR(i, 32) e->ws->teamTok[cuDepth][i >> 4][i & 15] = e->ws->intMv[i >> 4][i & 15];
+        HM_SYNC();
+      }
+      init_est_data(e, cuZ, cuDepth);
+      f->splitBits = 0; f->splitDist = 0; f->sub = 0; f->phase = 1;
+    }
+    if (f->phase == 1) {
+      if (f->sub < 4) {
+        const int s = f->sub++;
+        const int subZ = cuZ + s * q, r = hm_z2r(subZ);
+        const int sx = e->ctuX * 64 + (r & 15) * 4, sy = e->ctuY * 64 + (r >> 4) * 4;
+        HM_PAR_FOR(i, q) { m->depth[subZ + i] = (uint8_t)(cuDepth + 1); m->part[subZ + i] = SIZE_NONE; m->pred[subZ + i] = MODE_NONE; }
+        HM_SYNC();
+        if (sx < e->width && sy < e->height) {
+          if (s == 0) cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+          else cabac_copy(&e->ws->slot[HM_SLOT(cuDepth + 1, CI_CURR_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
+          fr[sp + 1].cuZ = (int16_t)subZ; fr[sp + 1].phase = 0;
+          // AMP speed-up: the part size of this depth's best mode when it is inter (TEncCu.cpp:1026) -- known once the helper has answered
+          int parentPart = SIZE_NONE;
+          if (!f->boundary) {
+            if (pending[cuDepth] && team_ready(e, cuDepth)) {
+              pending[cuDepth] = 0;
+              const TeamBox *b = &HM_TEAM_PTR()->box[cuDepth];
+              f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
+            }
+            if (!pending[cuDepth]) {
+              const Best *hb = &team_helper_ws(e, cuDepth)->best[cuDepth];
+              if (HM_UNI(hb->m.pred[cuZ]) == MODE_INTER) parentPart = HM_UNI(hb->m.part[cuZ]);
+            } else guessed[cuDepth] = 1;
+          }
+          fr[sp + 1].parentPart = (int8_t)parentPart;
+          f->phase = 2; sp++; continue;
+        }
+        continue;
+      }
+      if (pending[cuDepth]) {
+        team_wait(e, cuDepth); pending[cuDepth] = 0;
+        const TeamBox *b = &HM_TEAM_PTR()->box[cuDepth];
+        f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
+      }
+      if (!f->boundary && guessed[cuDepth] && sensitive[cuDepth]) {
+        const Best *hb = &team_helper_ws(e, cuDepth)->best[cuDepth];
+        const int pp = HM_UNI(hb->m.pred[cuZ]) == MODE_INTER ? HM_UNI(hb->m.part[cuZ]) : SIZE_NONE;
+        if (pp >= SIZE_2NxnU && pp <= SIZE_nRx2N) {
+          // the guess was wrong where it mattered: the sub-CUs again, from the state the unsplit CU's 2Nx2N search left (nothing outside this CU has read them)
+          HM_PAR_FOR(i, 32) e->ws->intMv[i >> 4][i & 15] = e->ws->teamTok[cuDepth][i >> 4][i & 15];
+          HM_SYNC();
+          guessed[cuDepth] = 0; sensitive[cuDepth] = 0;
+          init_est_data(e, cuZ, cuDepth);
+          f->splitBits = 0; f->splitDist = 0; f->sub = 0;
+          continue;
+        }
+      }
+      if (!f->boundary) {
+        reset_bits(&e->cur);
+        enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), m->depth[cuZ] > cuDepth);
+        f->splitBits += num_bits(&e->cur);
+      }
+      f->splitCost = calc_rd_cost(e, f->splitBits, f->splitDist);
+      cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)], &e->ws->slot[HM_SLOT(cuDepth + 1, CI_NEXT_BEST)]);
+      if (f->splitCost < f->bestCost) {
+        f->bestCost = f->splitCost; f->bestBits = f->splitBits; f->bestDist = f->splitDist;
+        cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &e->ws->slot[HM_SLOT(cuDepth, CI_TEMP_BEST)]);
+      } else team_take_unsplit(e, cuDepth, cuZ, cuDepth);
+      if (sp > 0 && !f->boundary) sensitive[sp - 1] |= HM_UNI(HM_TEAM_PTR()->box[cuDepth].sens);
+      retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
+    }
+    if (f->phase == 2) { f->splitBits += retBits; f->splitDist += retDist; f->phase = 1; continue; }   // a sub-CU returned
+  }
+  e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
+}
+
 // ---- helper wavefront h (1-based wave index h + 1) ----
 // the uniform per-CTU context of the main wavefront, with private places for everything a candidate writes
 HM_DEV inline void team_adopt(Shared *e, const Shared *mainSh, int h, Pel *win)
@@ -252,6 +371,26 @@ HM_DEV inline void team_helper(Team *T, int h, Pel *win)
     }
     team_fill_window(e, mainSh);
     cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)], &mainSh->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+    if (mainSh->im) {
+      // P / B slice: the whole candidate chain of the unsplit CU (TEncCu.cpp:628-863) on a private copy of the CTU's motion arrays; everything
+      // outside the CU is final, m_integerMv2Nx2N was put into this wavefront's workspace by the main one
+      e->im = &e->ws->teamIm;
+      { const uint32_t *src = (const uint32_t *)mainSh->im; uint32_t *dst = (uint32_t *)e->im;
+        HM_PAR_FOR(i, (int)(sizeof(InterMeta) / 4)) dst[i] = src[i];
+        HM_SYNC(); }
+      CuFrame *f = &e->cuf[cuDepth];
+      f->cuZ = (int16_t)cuZ; f->boundary = 0; f->parentPart = (int8_t)part; f->ampSens = 0;
+      f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
+      compress_cu_inter_modes(e, cuZ, cuDepth, cuDepth);
+      reset_bits(&e->cur);
+      if (cuDepth != 3) enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
+      const uint32_t bits = f->bestBits + num_bits(&e->cur), dist = f->bestDist;
+      const double c = calc_rd_cost(e, bits, dist);
+      if (hm_lane() == 0) { b->cost = c; b->bits = bits; b->dist = dist; b->sens = f->ampSens; }
+      HM_TEAM_RELEASE();
+      team_st(&b->doneSeq, s);
+      continue;
+    }
     // xCheckRDCostIntra + xCheckBestMode against an empty best (TEncCu.cpp:706-735, :1574, :1702)
     check_rd_cost_intra(e, cuZ, cuDepth, part);
     double c = e->outCost; uint32_t bits = e->outBits; const uint32_t dist = e->outDist;

@@ -92,6 +92,8 @@ struct WorkSpace {
   uint8_t tmpTr[256], tmpCbf[3][256], tmpTs[3][256], saveCbf[3][256], saveTs[3][256];
   struct { int32_t ctuQp, refQp, flag, pad; } dq;   // cu_qp_delta: QP of the CTU under search, its predictor, TEncCu::m_bEncodeDQP
   TCoeff teamCoef[HM_COEF_CTU];      // a team helper's private coefficient area (the team's main wavefront works in the picture's own, hm355_team.h)
+  InterMeta teamIm;                  // ... and its private copy of the CTU's motion arrays (P / B slices)
+  MvD teamTok[3][2][16];             // main wavefront of a team: m_integerMv2Nx2N after the unsplit CU of depth 0..2, where its sub-CUs start from
 };
 
 // ---- cu_qp_delta (adaptive QP / rate control; MaxCuDQPDepth 0, i.e. one quantisation group per CTU) ----

@@ -49,10 +49,13 @@ def test_hip_matches_oracle_on_fresh_inputs(built, hm, w, h, bd, qp, wpp, seed):
     enc.close()
 
 
+@pytest.mark.parametrize("team", ["0", "1"])
 @pytest.mark.parametrize("name", common.LDP_CASES + common.B_CASES)
-def test_hip_p_and_b_slices_match_reference_fixture(hm, name):
+def test_hip_p_and_b_slices_match_reference_fixture(hm, monkeypatch, name, team):
     """low-delay P, random access and low-delay B clips: every P / B slice through hm355_compress_slice_inter with the reference
-    pictures and slice parameters the reference's compressSlice saw; decisions, motion, coefficients, costs, reconstruction bit-exact."""
+    pictures and slice parameters the reference's compressSlice saw; decisions, motion, coefficients, costs, reconstruction bit-exact --
+    searched by one wavefront per CTU (team 0) and by a team of wavefronts per CTU (team 1, hm355_team.h: what a one-picture launch gets)."""
+    monkeypatch.setenv("HM355_TEAM", team)
     cfg, slices, finals = common.load_ldp_case(name)
     enc = hm.Encoder(cfg["width"], cfg["height"], cfg["bit_depth"], cfg["wpp"], max_batch=1)
     n_p = 0
