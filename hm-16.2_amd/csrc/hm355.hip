@@ -467,7 +467,7 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
     L.fewWaves = fewWaves;
   }
   c->epoch++; if (c->epoch == 0) c->epoch = 1;
-  HM_CHECK(c, hipMemsetAsync(L.dSched, 0, 12, L.stream));       // ticket = 0, abort = 0, published CTUs = 0
+  HM_CHECK(c, hipMemsetAsync(L.dSched, 0, 32, L.stream));       // ticket = 0, abort = 0, published CTUs = 0 (+ the counters of diagnostic builds)
   if (row0 > 0)    // the row above the band is complete: its CTUs count as published in this run
     for (int f = 0; f < n; f++) HM_CHECK(c, hipMemsetD32Async((hipDeviceptr_t)(c->slots[slot0 + f].fb.done + (size_t)(row0 - 1) * P.wCtu), (int)c->epoch, P.wCtu, L.stream));
   HM_CHECK(c, hipEventRecord(L.ev0, L.stream));
@@ -528,6 +528,11 @@ static int run_wait(hm355_ctx *c, int l, double *kernelMs)
   // on the lane's own stream: a copy on the null stream would wait for the launches of every other lane as well (legacy stream semantics)
   HM_CHECK(c, hipMemcpyAsync(sched, L.dSched, sizeof(sched), hipMemcpyDeviceToHost, L.stream));
   HM_CHECK(c, hipStreamSynchronize(L.stream));
+#if defined(HM355_TEAMSTAT)
+  { unsigned int ts[8] = {0}; (void)hipMemcpy(ts, L.dSched, sizeof(ts), hipMemcpyDeviceToHost);
+    if (ts[3]) fprintf(stderr, "[team] CTUs %u: main wavefront %.1f ms/CTU = 8x8 CUs %.1f + waiting for helpers %.1f + rest; re-searched CUs %u\n",
+                       ts[3], ts[4] * 1.28e-3 / ts[3], ts[6] * 1.28e-3 / ts[3], ts[5] * 1.28e-3 / ts[3], ts[7]); }
+#endif
   if (sched[1] != 0) return fail(c, HM355_ERR_DEVICE, "scheduler aborted: a dependency wait timed out");
   c->lastKernelMs = ms; c->lastLaunches = 1;
   if (kernelMs) *kernelMs = ms;

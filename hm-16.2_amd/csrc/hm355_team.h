@@ -56,6 +56,15 @@ __device__ __forceinline__ void team_st(uint32_t *p, uint32_t v) { if (hm_lane()
 #define HM_TEAM_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define HM_TEAM_ACQUIRE() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
+#if defined(HM355_TEAMSTAT)            /* diagnostic build (tools/): where the main wavefront's time goes, summed over the CTUs of a launch into the scheduler words */
+#define HM_TSTAT_ADD(k, v) do { if (hm_lane() == 0) atomicAdd((unsigned int *)HM_TEAM_PTR()->abortWord + 2 + (k), (unsigned int)(v)); } while (0)
+#define HM_TSTAT_T0(t) const unsigned long long t = wall_clock64()
+#define HM_TSTAT_T1(k, t) HM_TSTAT_ADD(k, (wall_clock64() - (t)) >> 7)
+#else
+#define HM_TSTAT_ADD(k, v) ((void)0)
+#define HM_TSTAT_T0(t) ((void)0)
+#define HM_TSTAT_T1(k, t) ((void)0)
+#endif
 // ---- main wavefront ----
 HM_DEV inline void team_post(Shared *e, int h, int cuZ, int depth, int part)
 {
@@ -210,6 +219,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
 HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
 {
   HM_ENTRY(e);
+  HM_TSTAT_T0(tAll);
   CtuMeta *m = (&e->meta);
   CuFrame *fr = e->cuf; int sp = 0;
   fr[0].cuZ = 0; fr[0].phase = 0; fr[0].parentPart = SIZE_NONE;
@@ -227,7 +237,9 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
       f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
       if (cuDepth == 3) {               // TEncCu.cpp:628-863 at the smallest CU size, as compress_ctu does it
         if (!f->boundary) {
+          HM_TSTAT_T0(t8);
           compress_cu_inter_modes(e, cuZ, cuDepth, sp);
+          HM_TSTAT_T1(3, t8);
           reset_bits(&e->cur);
           f->bestBits += num_bits(&e->cur);
           f->bestCost = calc_rd_cost(e, f->bestBits, f->bestDist);
@@ -278,7 +290,9 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
         continue;
       }
       if (pending[cuDepth]) {
+        HM_TSTAT_T0(tw);
         team_wait(e, cuDepth); pending[cuDepth] = 0;
+        HM_TSTAT_T1(2, tw);
         const TeamBox *b = &HM_TEAM_PTR()->box[cuDepth];
         f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
       }
@@ -290,6 +304,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
           HM_PAR_FOR(i, 32) e->ws->intMv[i >> 4][i & 15] = e->ws->teamTok[cuDepth][i >> 4][i & 15];
           HM_SYNC();
           guessed[cuDepth] = 0; sensitive[cuDepth] = 0;
+          HM_TSTAT_ADD(4, 1);
           init_est_data(e, cuZ, cuDepth);
           f->splitBits = 0; f->splitDist = 0; f->sub = 0;
           continue;
@@ -311,6 +326,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
     }
     if (f->phase == 2) { f->splitBits += retBits; f->splitDist += retDist; f->phase = 1; continue; }   // a sub-CU returned
   }
+  HM_TSTAT_T1(1, tAll); HM_TSTAT_ADD(0, 1);
   e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
 }
 
