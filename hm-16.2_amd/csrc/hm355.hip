@@ -100,14 +100,14 @@ extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Param
 // one-wavefront searches (a few pictures, or pictures whose CABAC state chains through every CTU), where the time of ONE CTU search is
 // what the launch takes.
 extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
-{
-  Team *T = &g_team;
+{ // blockDim.x = 64 * HM_TEAM_I (I slices only) or 64 * HM_TEAM; dynamic LDS = HM_TEAM_LDS_BYTES(waves)
+  Team *T = HM_TEAM_PTR();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (threadIdx.x < HM_TEAM_HELPERS) { T->box[threadIdx.x].reqSeq = 0; T->box[threadIdx.x].doneSeq = 0; }
+  if (threadIdx.x < HM_TEAM - 1) { T->box[threadIdx.x].reqSeq = 0; T->box[threadIdx.x].doneSeq = 0; }
   if (threadIdx.x == 0) { T->quit = 0; T->dead = 0; T->abortWord = sched + 1; }
   __syncthreads();
   if (wave != 0) {
-    team_helper(T, wave - 1, P->teamWin + ((size_t)blockIdx.x * HM_TEAM_HELPERS + (size_t)(wave - 1)) * P->teamWinStride);
+    team_helper(T, wave, wave <= HM_TEAM_HELPERS ? P->teamWin + ((size_t)blockIdx.x * HM_TEAM_HELPERS + (size_t)(wave - 1)) * P->teamWinStride : (Pel *)0);
     return;
   }
   for (;;) {
@@ -210,6 +210,7 @@ struct hm355_ctx {
   FrameBuf *dFrames;
   WorkSpace *dWs; size_t wsCount;
   uint8_t *arena;       // the pictures' planes, decision arrays, coefficients, statistics, CABAC states, done words: one allocation
+  int teamLdsSet;
   unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort, [2] published CTUs of the search launch; [8] ticket, [9] abort of the bitstream launch
   std::vector<Slot> slots;
   Lane lane[HM_MAX_LANES];   // lane 0 is the context's own stream / scratch (every blocking entry point); 1.. are created on first use
@@ -254,7 +255,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
   c->cfg = *cfg; c->laneShare = 1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
-  c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->wsCount = 0; c->dSched = NULL; c->epoch = 0;
+  c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->wsCount = 0; c->dSched = NULL; c->epoch = 0; c->teamLdsSet = 0;
   for (int l = 0; l < HM_MAX_LANES; l++) { Lane &L = c->lane[l]; L.stream = NULL; L.ev0 = L.ev1 = NULL; L.dP = NULL; L.dWs = NULL; L.wsCount = 0; L.dItems = NULL; L.itemsCap = 0; L.dSched = NULL; L.keyValid = 0; L.fewWaves = -1; L.busy = 0; L.grid = 0; L.inFixup = 0; L.dTeamWin = NULL; L.teamCap = 0; }
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
@@ -474,7 +475,11 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
   const int total = (int)L.items.size();
   if (useTeam && teams > 0) {
     L.grid = teams;
-    hipLaunchKernelGGL(hm355_ctu_team_kernel, dim3(L.grid), dim3(64 * HM_TEAM), 0, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
+    int waves = HM_TEAM_I;               // P / B slices: every chain of candidates on two wavefronts (hm355_team.h)
+    for (int f = 0; f < n; f++) if (c->slots[slot0 + f].fb.imeta) waves = HM_TEAM;
+    const size_t lds = HM_TEAM_LDS_BYTES(waves);
+    if (!c->teamLdsSet) { HM_CHECK(c, hipFuncSetAttribute((const void *)hm355_ctu_team_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HM_TEAM_LDS_BYTES(HM_TEAM))); c->teamLdsSet = 1; }
+    hipLaunchKernelGGL(hm355_ctu_team_kernel, dim3(L.grid), dim3(64 * waves), lds, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
   } else {
     L.grid = total < (int)L.wsCount ? total : (int)L.wsCount;
     // A caller that keeps `share` launches in flight (hm355_set_lane_share): each launch only takes its share of the searches the device can hold --

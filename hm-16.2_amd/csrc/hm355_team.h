@@ -32,25 +32,33 @@
 //     a sub-CU was sensitive, the four sub-CUs are searched again with the part size known -- nothing outside the CU has seen them yet.
 #pragma once
 
-#define HM_TEAM 5
-#define HM_TEAM_HELPERS (HM_TEAM - 1)
+#define HM_TEAM 8                      /* wavefronts (and workspaces) of a team in a launch with P / B slices */
+#define HM_TEAM_I 5                    /* ... in a launch of I slices only: waves 0..4 */
+#define HM_TEAM_HELPERS 4              /* waves 1..4 own a reconstruction window (they evaluate intra candidates) */
 #define HM_TEAM_TIMEOUT_TICKS (20ull * 100000000ull)   /* 20 s of the 100 MHz wall clock: a team member that never answers abandons the launch */
+// wave 0: main;  1 + d: the unsplit CU of depth d = 0, 1, 2;  4: I slice: the 2Nx2N candidate of an 8x8 CU, P / B slice: the main wavefront's partner
+// for the 8x8 CUs;  5 + d: partner of wave 1 + d (P / B slices).  A partner takes the Nx2N / 2NxN and the vertical AMP candidates of a CU.
+enum { TK_INTRA = 0, TK_CHAIN = 1, TK_PAIR1 = 2, TK_PAIR2 = 3 };
 
-struct TeamBox {                       // mailbox of one helper
-  uint32_t reqSeq, doneSeq;            // main: arguments, release, reqSeq + 1;  helper: results, release, doneSeq = reqSeq
-  int32_t cuZ, depth, part, sens;      // part: I slice: the part size to evaluate; P / B slice: the parent's part size (deriveTestModeAMP); sens: CuFrame::ampSens of the answer
-  uint32_t bits, dist; double cost;    // the candidate as xCheckBestMode sees it (split flag of the unsplit CU included)
+struct TeamBox {                       // mailbox of one helper wavefront (box[w - 1] of wave w)
+  uint32_t reqSeq, doneSeq;            // requester: arguments, release, reqSeq + 1;  helper: results, release, doneSeq = reqSeq
+  int32_t cuZ, depth, part, kind;      // part: TK_INTRA: the part size to evaluate; TK_CHAIN: the parent's part size (deriveTestModeAMP); TK_PAIR2: bit 0 full, bit 1 merge-only vertical AMP
+  int32_t src, sens, owner, improved;  // src: the requesting wave; answers: CuFrame::ampSens, the wave whose workspace holds the best mode, TK_PAIR*: a candidate came in below the threshold
+  uint32_t bits, dist; double cost;    // the candidate as xCheckBestMode sees it (TK_INTRA / TK_CHAIN: split flag of the unsplit CU included)
+  double threshold;                    // TK_PAIR2: the best cost so far
 };
 struct Team {
-  Shared sh[HM_TEAM];                  // [0] the main wavefront, [1 + h] helper h
-  TeamBox box[HM_TEAM_HELPERS];
+  TeamBox box[HM_TEAM - 1];
   uint32_t quit, dead;                 // quit: the launch is over; dead: a wait timed out, results are void (the host sees the abort word)
   unsigned int *abortWord;
   WorkItem item;
+  Shared sh[1];                        // [waves of the launch]: the launch sizes the workgroup's LDS for them
 };
+static_assert(offsetof(Team, sh) % 16 == 0, "Shared holds doubles and 16-byte rows");
+#define HM_TEAM_LDS_BYTES(waves) (offsetof(Team, sh) + (size_t)(waves) * sizeof(Shared))
 
-__shared__ Team g_team;               // only the team kernel (hm355_ctu_team_kernel) reaches it
-#define HM_TEAM_PTR() (&g_team)
+extern __shared__ __align__(16) unsigned char g_team_lds[];   // only the team kernel (hm355_ctu_team_kernel) reaches it
+#define HM_TEAM_PTR() ((Team *)g_team_lds)
 __device__ __forceinline__ uint32_t team_ld(const uint32_t *p) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)); }
 __device__ __forceinline__ void team_st(uint32_t *p, uint32_t v) { if (hm_lane() == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define HM_TEAM_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -66,10 +74,11 @@ __device__ __forceinline__ void team_st(uint32_t *p, uint32_t v) { if (hm_lane()
 #define HM_TSTAT_T1(k, t) ((void)0)
 #endif
 // ---- main wavefront ----
-HM_DEV inline void team_post(Shared *e, int h, int cuZ, int depth, int part)
-{
+HM_DEV inline void team_post(Shared *e, int h, int cuZ, int depth, int part, int kind = -1, int src = 0, double threshold = 0.0)
+{ // h: box index (wave - 1); kind -1: TK_INTRA on an I slice, TK_CHAIN on a P / B slice
   TeamBox *b = &HM_TEAM_PTR()->box[h];
-  if (hm_lane() == 0) { b->cuZ = cuZ; b->depth = depth; b->part = part; }
+  if (kind < 0) kind = e->im ? TK_CHAIN : TK_INTRA;
+  if (hm_lane() == 0) { b->cuZ = cuZ; b->depth = depth; b->part = part; b->kind = kind; b->src = src; b->threshold = threshold; }
   const uint32_t seq = team_ld(&b->reqSeq) + 1u;
   HM_TEAM_RELEASE();
   team_st(&b->reqSeq, seq);
@@ -98,12 +107,15 @@ HM_DEV HM_NOINLINE void team_wait(Shared *e, int h)
   }
   HM_TEAM_ACQUIRE();
 }
-HM_DEV inline WorkSpace *team_helper_ws(Shared *e, int h) { return e->ws + 1 + h; }      // the workspaces of a team lie side by side, the main wavefront's first
+HM_DEV inline WorkSpace *team_helper_ws(Shared *e, int h) { return e->ws + 1 + h; }      // the workspaces of a team lie side by side, the main wavefront's first (called by the main wavefront)
+HM_DEV inline WorkSpace *team_wave_ws(int wave) { return HM_TEAM_PTR()->sh[0].ws + wave; }
+// the workspace that holds the answer of helper h (box index): its own or its partner's
+HM_DEV inline WorkSpace *team_answer_ws(Shared *e, int h) { return team_wave_ws(HM_UNI(HM_TEAM_PTR()->box[h].owner)); }
 
 // what the reference's xCheckBestMode does when the unsplit candidate is the best mode: results of the helper become the CU's
 HM_DEV inline void team_take_unsplit(Shared *e, int h, int cuZ, int cuDepth)
 {
-  WorkSpace *hw = team_helper_ws(e, h);
+  WorkSpace *hw = e->im ? team_answer_ws(e, h) : team_helper_ws(e, h);
   restore_best_from(e, &hw->best[cuDepth], cuZ, cuDepth);
   cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &hw->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)]);
 }
@@ -215,6 +227,69 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
   e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
 }
 
+// The mode tests of one CU in a P / B slice (compress_cu_inter_modes, hm355_inter_cu.h) by two wavefronts: this one takes the merge and 2Nx2N
+// candidates, the horizontal AMP pair and the intra candidates, its partner (wave `mate`) Nx2N / 2NxN and the vertical AMP pair.  Every candidate
+// starts from the same CABAC snapshot and the same neighbourhood; what they share is xCheckBestMode's running best, and that is put together
+// here in the reference's order: this wavefront's candidates of a stage come first in it, so the partner's best replaces the running best only
+// when it is strictly cheaper.  The partner's 2Nx2N-dependent input -- m_integerMv2Nx2N after this CU's 2Nx2N search -- comes from me_token_prepass.
+// Returns the wave whose workspace holds the best mode (best[cuDepth], CI_NEXT_BEST of that depth).
+HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDepth, int sp, int self, int mate)
+{
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp); self = HM_UNI(self); mate = HM_UNI(mate);
+  CuFrame *f = &e->cuf[sp];
+  WorkSpace *mw = team_wave_ws(mate);
+  TeamBox *mb = &HM_TEAM_PTR()->box[mate - 1];
+  int owner = self;
+  f->ampSens = 0;
+  { // the partner's Nx2N / 2NxN searches start from the integer vectors this CU's 2Nx2N search will leave; this wavefront's own 2Nx2N search from those it found
+    const int i = hm_lane() & 31;
+    const MvD keep = e->ws->intMv[i >> 4][i & 15];
+    me_token_prepass(e, cuZ, cuDepth);
+    HM_PAR_FOR(k, 32) mw->intMv[k >> 4][k & 15] = e->ws->intMv[k >> 4][k & 15];
+    HM_SYNC();
+    if (hm_lane() < 32) e->ws->intMv[i >> 4][i & 15] = keep;
+    HM_SYNC();
+  }
+  team_post(e, mate - 1, cuZ, cuDepth, 0, TK_PAIR1, self);
+  check_rd_cost_merge_2Nx2N(e, cuZ, cuDepth, sp);
+  check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2Nx2N, 0, sp);
+  team_wait(e, mate - 1);
+  if (HM_UNI(mb->improved) && mb->cost < f->bestCost) { f->bestCost = mb->cost; f->bestBits = mb->bits; f->bestDist = mb->dist; owner = mate; }
+  if (cuDepth < 3) { // deriveTestModeAMP :386-447 on the best mode so far
+    const Best *b = &team_wave_ws(owner)->best[cuDepth];
+    const int ps = HM_UNI(b->m.part[cuZ]), bmrg = HM_UNI(b->im.mrg[cuZ]), bskip = HM_UNI(b->im.skip[cuZ]), parent = f->parentPart;
+    int hor = 0, ver = 0, mh = 0, mv = 0;
+    if (ps == SIZE_2NxN) hor = 1;
+    else if (ps == SIZE_Nx2N) ver = 1;
+    else if (ps == SIZE_2Nx2N && !bmrg && !bskip) { hor = 1; ver = 1; }
+    if (parent >= SIZE_2NxnU && parent <= SIZE_nRx2N) { mh = 1; mv = 1; }
+    if (parent == SIZE_NONE) { if (ps == SIZE_2NxN) mh = 1; else if (ps == SIZE_Nx2N) mv = 1; }
+    if (ps == SIZE_2Nx2N && !bskip) { mh = 1; mv = 1; }
+    if ((64 >> cuDepth) == 64) { hor = 0; ver = 0; }
+    f->ampSens = (int8_t)((!hor && !mh) || (!ver && !mv));
+    const int mateBusy = ver || mv;
+    if (mateBusy) team_post(e, mate - 1, cuZ, cuDepth, ver ? 1 : 2, TK_PAIR2, self, f->bestCost);
+    const double before = f->bestCost;
+    if (hor) { check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnU, 0, sp); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnD, 0, sp); }
+    else if (mh) { check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnU, 1, sp); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnD, 1, sp); }
+    if (f->bestCost < before) owner = self;
+    if (mateBusy) {
+      team_wait(e, mate - 1);
+      if (HM_UNI(mb->improved) && mb->cost < f->bestCost) { f->bestCost = mb->cost; f->bestBits = mb->bits; f->bestDist = mb->dist; owner = mate; }
+    }
+  }
+  { // intra only when the best inter mode left a residual (:820)
+    const Best *b = &team_wave_ws(owner)->best[cuDepth];
+    if (HM_UNI(b->m.cbf[0][cuZ]) != 0 || HM_UNI(b->m.cbf[1][cuZ]) != 0 || HM_UNI(b->m.cbf[2][cuZ]) != 0) {
+      const double before = f->bestCost;
+      check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N); check_best_mode(e, f, cuZ, cuDepth);
+      if (cuDepth == 3) { check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN); check_best_mode(e, f, cuZ, cuDepth); }
+      if (f->bestCost < before) owner = self;
+    }
+  }
+  return owner;
+}
+
 // TEncCu::compressCtu -> xCompressCU for a P / B slice: the unsplit CUs of depth 0..2 with the helpers, the 8x8 CUs here (see the head of this file)
 HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
 {
@@ -238,13 +313,18 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
       if (cuDepth == 3) {               // TEncCu.cpp:628-863 at the smallest CU size, as compress_ctu does it
         if (!f->boundary) {
           HM_TSTAT_T0(t8);
-          compress_cu_inter_modes(e, cuZ, cuDepth, sp);
+          const int owner = compress_cu_inter_modes_duo(e, cuZ, cuDepth, sp, 0, 4);
           HM_TSTAT_T1(3, t8);
           reset_bits(&e->cur);
           f->bestBits += num_bits(&e->cur);
           f->bestCost = calc_rd_cost(e, f->bestBits, f->bestDist);
-        }
-        restore_best(e, cuZ, cuDepth); retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
+          if (owner != 0) {              // the partner's candidate won: its workspace holds the CU (as team_take_unsplit)
+            WorkSpace *ow = team_wave_ws(owner);
+            restore_best_from(e, &ow->best[cuDepth], cuZ, cuDepth);
+            cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)], &ow->slot[HM_SLOT(cuDepth, CI_NEXT_BEST)]);
+          } else restore_best(e, cuZ, cuDepth);
+        } else restore_best(e, cuZ, cuDepth);
+        retCost = f->bestCost; retBits = f->bestBits; retDist = f->bestDist; sp--; continue;
       }
       pending[cuDepth] = 0; guessed[cuDepth] = 0; sensitive[cuDepth] = 0;
       if (!f->boundary) {
@@ -280,7 +360,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
               f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
             }
             if (!pending[cuDepth]) {
-              const Best *hb = &team_helper_ws(e, cuDepth)->best[cuDepth];
+              const Best *hb = &team_answer_ws(e, cuDepth)->best[cuDepth];
               if (HM_UNI(hb->m.pred[cuZ]) == MODE_INTER) parentPart = HM_UNI(hb->m.part[cuZ]);
             } else guessed[cuDepth] = 1;
           }
@@ -297,7 +377,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
         f->bestCost = b->cost; f->bestBits = b->bits; f->bestDist = b->dist;
       }
       if (!f->boundary && guessed[cuDepth] && sensitive[cuDepth]) {
-        const Best *hb = &team_helper_ws(e, cuDepth)->best[cuDepth];
+        const Best *hb = &team_answer_ws(e, cuDepth)->best[cuDepth];
         const int pp = HM_UNI(hb->m.pred[cuZ]) == MODE_INTER ? HM_UNI(hb->m.part[cuZ]) : SIZE_NONE;
         if (pp >= SIZE_2NxnU && pp <= SIZE_nRx2N) {
           // the guess was wrong where it mattered: the sub-CUs again, from the state the unsplit CU's 2Nx2N search left (nothing outside this CU has read them)
@@ -330,22 +410,24 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
   e->outCost = retCost; e->outBits = retBits; e->outDist = retDist;
 }
 
-// ---- helper wavefront h (1-based wave index h + 1) ----
-// the uniform per-CTU context of the main wavefront, with private places for everything a candidate writes
-HM_DEV inline void team_adopt(Shared *e, const Shared *mainSh, int h, Pel *win)
+// ---- helper wavefront `wave` (1 .. HM_TEAM - 1) ----
+// the uniform per-CTU context of the requesting wavefront, with private places for everything a candidate writes
+HM_DEV inline void team_adopt(Shared *e, const Shared *src, int wave, Pel *win)
 {
-  e->P = mainSh->P; e->fb = mainSh->fb; e->tab = mainSh->tab;
-  e->width = mainSh->width; e->height = mainSh->height; e->bitDepth = mainSh->bitDepth; e->wCtu = mainSh->wCtu;
-  for (int c = 0; c < 3; c++) e->stride[c] = mainSh->stride[c];
-  e->ctuX = mainSh->ctuX; e->ctuY = mainSh->ctuY; e->ctuAddr = mainSh->ctuAddr;
-  e->ws = mainSh->ws + 1 + h; e->cc = e->ws->teamCoef; e->im = (InterMeta *)0; e->mpmZ = -1; e->s8Reuse = 0;
-  if (e->fb.dqp && hm_lane() == 0) e->ws->dq = mainSh->ws->dq;    // QP of the CTU, its predictor (m_bEncodeDQP is clear whenever a team searches)
-  // the window: rows [ctuY * S - 1, ctuY * S + S) of a plane with the picture's stride, addressed like the picture
-  Pel *w = win;
-  for (int c = 0; c < 3; c++) {
-    const int S = c ? 32 : 64;
-    e->fb.rec[c] = w - ((long long)e->ctuY * S - 1) * e->stride[c];
-    w += (size_t)(S + 1) * e->stride[c];
+  e->P = src->P; e->fb = src->fb; e->tab = src->tab;
+  e->width = src->width; e->height = src->height; e->bitDepth = src->bitDepth; e->wCtu = src->wCtu;
+  for (int c = 0; c < 3; c++) e->stride[c] = src->stride[c];
+  e->ctuX = src->ctuX; e->ctuY = src->ctuY; e->ctuAddr = src->ctuAddr;
+  e->ws = team_wave_ws(wave); e->cc = e->ws->teamCoef; e->im = (InterMeta *)0; e->mpmZ = -1; e->s8Reuse = 0;
+  if (e->fb.dqp && hm_lane() == 0) e->ws->dq = src->ws->dq;    // QP of the CTU, its predictor (m_bEncodeDQP is clear whenever a team searches)
+  if (win) {
+    // the window: rows [ctuY * S - 1, ctuY * S + S) of a plane with the picture's stride, addressed like the picture
+    Pel *w = win;
+    for (int c = 0; c < 3; c++) {
+      const int S = c ? 32 : 64;
+      e->fb.rec[c] = w - ((long long)e->ctuY * S - 1) * e->stride[c];
+      w += (size_t)(S + 1) * e->stride[c];
+    }
   }
   HM_SYNC();
 }
@@ -360,10 +442,28 @@ HM_DEV inline void team_fill_window(Shared *e, const Shared *mainSh)
   }
   HM_SYNC();
 }
-HM_DEV inline void team_helper(Team *T, int h, Pel *win)
+// the decision (and motion) arrays as the requesting wavefront holds them: everything outside the CU is final (inside, init_est_data starts afresh)
+HM_DEV inline void team_copy_arrays(Shared *e, const Shared *src)
 {
-  Shared *e = &T->sh[1 + h]; const Shared *mainSh = &T->sh[0];
-  TeamBox *b = &T->box[h];
+  { const uint32_t *s_ = (const uint32_t *)&src->meta; uint32_t *d_ = (uint32_t *)&e->meta;
+    HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) d_[i] = s_[i]; }
+  if (src->im) {
+    e->im = &e->ws->teamIm;
+    const uint32_t *s_ = (const uint32_t *)src->im; uint32_t *d_ = (uint32_t *)e->im;
+    HM_PAR_FOR(i, (int)(sizeof(InterMeta) / 4)) d_[i] = s_[i];
+  }
+  HM_SYNC();
+}
+HM_DEV inline void team_answer(TeamBox *b, uint32_t seq, double cost, uint32_t bits, uint32_t dist, int sens, int owner, int improved)
+{
+  if (hm_lane() == 0) { b->cost = cost; b->bits = bits; b->dist = dist; b->sens = sens; b->owner = owner; b->improved = improved; }
+  HM_TEAM_RELEASE();
+  team_st(&b->doneSeq, seq);
+}
+HM_DEV inline void team_helper(Team *T, int wave, Pel *win)
+{
+  Shared *e = &T->sh[wave]; const Shared *mainSh = &T->sh[0];
+  TeamBox *b = &T->box[wave - 1];
   load_tmat(e);
   HM_PAR_FOR(i, 128) e->ebits[i] = HM_ENTROPY_BITS[i];
   HM_SYNC();
@@ -378,36 +478,43 @@ HM_DEV inline void team_helper(Team *T, int h, Pel *win)
     }
     HM_TEAM_ACQUIRE();
     seen = s;
-    const int cuZ = HM_UNI(b->cuZ), cuDepth = HM_UNI(b->depth), part = HM_UNI(b->part);
-    team_adopt(e, mainSh, h, win);
-    { // the decision arrays as the main wavefront holds them: everything outside the CU is final (inside, init_est_data starts afresh)
-      const uint32_t *src = (const uint32_t *)&mainSh->meta; uint32_t *dst = (uint32_t *)&e->meta;
-      HM_PAR_FOR(i, (int)(sizeof(CtuMeta) / 4)) dst[i] = src[i];
-      HM_SYNC();
+    const int cuZ = HM_UNI(b->cuZ), cuDepth = HM_UNI(b->depth), part = HM_UNI(b->part), kind = HM_UNI(b->kind);
+    const Shared *src = &T->sh[HM_UNI(b->src)];
+    CuFrame *f = &e->cuf[cuDepth];
+    if (kind == TK_PAIR2) {
+      // the vertical AMP pair of the CU this wavefront just searched Nx2N / 2NxN for (its context is in place); a candidate only counts below the best cost so far
+      const double thr = b->threshold;
+      f->bestCost = thr; f->bestBits = 0; f->bestDist = 0;
+      const int mrgOnly = (part & 1) ? 0 : 1;
+      check_rd_cost_inter(e, cuZ, cuDepth, SIZE_nLx2N, mrgOnly, cuDepth); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_nRx2N, mrgOnly, cuDepth);
+      team_answer(b, s, f->bestCost, f->bestBits, f->bestDist, 0, wave, f->bestCost < thr);
+      continue;
+    }
+    team_adopt(e, src, wave, win);
+    team_copy_arrays(e, src);
+    cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)], &src->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
+    f->cuZ = (int16_t)cuZ; f->boundary = 0; f->parentPart = SIZE_NONE; f->ampSens = 0;
+    f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
+    if (kind == TK_PAIR1) {
+      // Nx2N and 2NxN of the requester's CU (m_integerMv2Nx2N as its 2Nx2N search leaves it is in this wavefront's workspace)
+      check_rd_cost_inter(e, cuZ, cuDepth, SIZE_Nx2N, 0, cuDepth);
+      check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxN, 0, cuDepth);
+      team_answer(b, s, f->bestCost, f->bestBits, f->bestDist, 0, wave, f->bestCost < HM_MAX_DOUBLE);
+      continue;
     }
     team_fill_window(e, mainSh);
-    cabac_copy(&e->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)], &mainSh->ws->slot[HM_SLOT(cuDepth, CI_CURR_BEST)]);
-    if (mainSh->im) {
+    if (kind == TK_CHAIN) {
       // P / B slice: the whole candidate chain of the unsplit CU (TEncCu.cpp:628-863) on a private copy of the CTU's motion arrays; everything
       // outside the CU is final, m_integerMv2Nx2N was put into this wavefront's workspace by the main one
-      e->im = &e->ws->teamIm;
-      { const uint32_t *src = (const uint32_t *)mainSh->im; uint32_t *dst = (uint32_t *)e->im;
-        HM_PAR_FOR(i, (int)(sizeof(InterMeta) / 4)) dst[i] = src[i];
-        HM_SYNC(); }
-      CuFrame *f = &e->cuf[cuDepth];
-      f->cuZ = (int16_t)cuZ; f->boundary = 0; f->parentPart = (int8_t)part; f->ampSens = 0;
-      f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
-      compress_cu_inter_modes(e, cuZ, cuDepth, cuDepth);
+      f->parentPart = (int8_t)part;
+      const int owner = compress_cu_inter_modes_duo(e, cuZ, cuDepth, cuDepth, wave, wave + 4);
       reset_bits(&e->cur);
       if (cuDepth != 3) enc_bin(e, &e->cur, C_SPLIT + ctx_split_flag(e, cuZ, cuDepth), 0);
       const uint32_t bits = f->bestBits + num_bits(&e->cur), dist = f->bestDist;
-      const double c = calc_rd_cost(e, bits, dist);
-      if (hm_lane() == 0) { b->cost = c; b->bits = bits; b->dist = dist; b->sens = f->ampSens; }
-      HM_TEAM_RELEASE();
-      team_st(&b->doneSeq, s);
+      team_answer(b, s, calc_rd_cost(e, bits, dist), bits, dist, f->ampSens, owner, 1);
       continue;
     }
-    // xCheckRDCostIntra + xCheckBestMode against an empty best (TEncCu.cpp:706-735, :1574, :1702)
+    // I slice: xCheckRDCostIntra + xCheckBestMode against an empty best (TEncCu.cpp:706-735, :1574, :1702)
     check_rd_cost_intra(e, cuZ, cuDepth, part);
     double c = e->outCost; uint32_t bits = e->outBits; const uint32_t dist = e->outDist;
     save_best(e, cuZ, cuDepth);
@@ -418,8 +525,6 @@ HM_DEV inline void team_helper(Team *T, int h, Pel *win)
       bits += num_bits(&e->cur);
       c = calc_rd_cost(e, bits, dist);
     }
-    if (hm_lane() == 0) { b->cost = c; b->bits = bits; b->dist = dist; }
-    HM_TEAM_RELEASE();
-    team_st(&b->doneSeq, s);
+    team_answer(b, s, c, bits, dist, 0, wave, 1);
   }
 }
