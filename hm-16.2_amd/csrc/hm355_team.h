@@ -43,7 +43,7 @@ enum { TK_INTRA = 0, TK_CHAIN = 1, TK_PAIR1 = 2, TK_PAIR2 = 3 };
 struct TeamBox {                       // mailbox of one helper wavefront (box[w - 1] of wave w)
   uint32_t reqSeq, doneSeq;            // requester: arguments, release, reqSeq + 1;  helper: results, release, doneSeq = reqSeq
   int32_t cuZ, depth, part, kind;      // part: TK_INTRA: the part size to evaluate; TK_CHAIN: the parent's part size (deriveTestModeAMP); TK_PAIR2: bit 0 full, bit 1 merge-only vertical AMP
-  int32_t src, sens, owner, improved;  // src: the requesting wave; answers: CuFrame::ampSens, the wave whose workspace holds the best mode, TK_PAIR*: a candidate came in below the threshold
+  int32_t src, sens, owner, improved;  // src: the requesting wave; answers: CuFrame::ampSens (TK_PAIR*: the fractional bits the go-on coder was left with), the wave whose workspace holds the best mode, TK_PAIR*: a candidate came in below the threshold
   uint32_t bits, dist; double cost;    // the candidate as xCheckBestMode sees it (TK_INTRA / TK_CHAIN: split flag of the unsplit CU included)
   double threshold;                    // TK_PAIR2: the best cost so far
 };
@@ -236,6 +236,9 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
 HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDepth, int sp, int self, int mate)
 {
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp); self = HM_UNI(self); mate = HM_UNI(mate);
+#if defined(HM355_NO_DUO)                /* diagnostic build: the whole chain on this wavefront */
+  compress_cu_inter_modes(e, cuZ, cuDepth, sp); return self;
+#endif
   CuFrame *f = &e->cuf[sp];
   WorkSpace *mw = team_wave_ws(mate);
   TeamBox *mb = &HM_TEAM_PTR()->box[mate - 1];
@@ -255,6 +258,9 @@ HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDep
   check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2Nx2N, 0, sp);
   team_wait(e, mate - 1);
   if (HM_UNI(mb->improved) && mb->cost < f->bestCost) { f->bestCost = mb->cost; f->bestBits = mb->bits; f->bestDist = mb->dist; owner = mate; }
+  // TEncBinCABACCounter::resetBits keeps the fractional bits (TEncBinCoderCABAC.cpp:161), so what follows the candidates on the go-on coder "as it
+  // stands" (the split flags, TEncCu.cpp:859-863, :1042-1047) sees the remainder the LAST candidate in the reference's order left -- the partner's, here
+  int mateLast = 1; uint32_t mateFrac = (uint32_t)HM_UNI(mb->sens);
   if (cuDepth < 3) { // deriveTestModeAMP :386-447 on the best mode so far
     const Best *b = &team_wave_ws(owner)->best[cuDepth];
     const int ps = HM_UNI(b->m.part[cuZ]), bmrg = HM_UNI(b->im.mrg[cuZ]), bskip = HM_UNI(b->im.skip[cuZ]), parent = f->parentPart;
@@ -273,9 +279,11 @@ HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDep
     if (hor) { check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnU, 0, sp); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnD, 0, sp); }
     else if (mh) { check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnU, 1, sp); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxnD, 1, sp); }
     if (f->bestCost < before) owner = self;
+    if (hor || mh) mateLast = 0;
     if (mateBusy) {
       team_wait(e, mate - 1);
       if (HM_UNI(mb->improved) && mb->cost < f->bestCost) { f->bestCost = mb->cost; f->bestBits = mb->bits; f->bestDist = mb->dist; owner = mate; }
+      mateLast = 1; mateFrac = (uint32_t)HM_UNI(mb->sens);
     }
   }
   { // intra only when the best inter mode left a residual (:820)
@@ -285,8 +293,10 @@ HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDep
       check_rd_cost_intra(e, cuZ, cuDepth, SIZE_2Nx2N); check_best_mode(e, f, cuZ, cuDepth);
       if (cuDepth == 3) { check_rd_cost_intra(e, cuZ, cuDepth, SIZE_NxN); check_best_mode(e, f, cuZ, cuDepth); }
       if (f->bestCost < before) owner = self;
+      mateLast = 0;
     }
   }
+  if (mateLast) { if (hm_lane() == 0) e->cur.frac = (e->cur.frac & ~32767ull) | mateFrac; HM_SYNC(); }
   return owner;
 }
 
@@ -487,7 +497,7 @@ HM_DEV inline void team_helper(Team *T, int wave, Pel *win)
       f->bestCost = thr; f->bestBits = 0; f->bestDist = 0;
       const int mrgOnly = (part & 1) ? 0 : 1;
       check_rd_cost_inter(e, cuZ, cuDepth, SIZE_nLx2N, mrgOnly, cuDepth); check_rd_cost_inter(e, cuZ, cuDepth, SIZE_nRx2N, mrgOnly, cuDepth);
-      team_answer(b, s, f->bestCost, f->bestBits, f->bestDist, 0, wave, f->bestCost < thr);
+      team_answer(b, s, f->bestCost, f->bestBits, f->bestDist, (int)(e->cur.frac & 32767), wave, f->bestCost < thr);
       continue;
     }
     team_adopt(e, src, wave, win);
@@ -499,7 +509,7 @@ HM_DEV inline void team_helper(Team *T, int wave, Pel *win)
       // Nx2N and 2NxN of the requester's CU (m_integerMv2Nx2N as its 2Nx2N search leaves it is in this wavefront's workspace)
       check_rd_cost_inter(e, cuZ, cuDepth, SIZE_Nx2N, 0, cuDepth);
       check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxN, 0, cuDepth);
-      team_answer(b, s, f->bestCost, f->bestBits, f->bestDist, 0, wave, f->bestCost < HM_MAX_DOUBLE);
+      team_answer(b, s, f->bestCost, f->bestBits, f->bestDist, (int)(e->cur.frac & 32767), wave, f->bestCost < HM_MAX_DOUBLE);
       continue;
     }
     team_fill_window(e, mainSh);
