@@ -32,17 +32,18 @@
 //     a sub-CU was sensitive, the four sub-CUs are searched again with the part size known -- nothing outside the CU has seen them yet.
 #pragma once
 
-#define HM_TEAM 8                      /* wavefronts (and workspaces) of a team in a launch with P / B slices */
+#define HM_TEAM 9                      /* wavefronts (and workspaces) of a team in a launch with P / B slices */
 #define HM_TEAM_I 5                    /* ... in a launch of I slices only: waves 0..4 */
 #define HM_TEAM_HELPERS 4              /* waves 1..4 own a reconstruction window (they evaluate intra candidates) */
 #define HM_TEAM_TIMEOUT_TICKS (20ull * 100000000ull)   /* 20 s of the 100 MHz wall clock: a team member that never answers abandons the launch */
 // wave 0: main;  1 + d: the unsplit CU of depth d = 0, 1, 2;  4: I slice: the 2Nx2N candidate of an 8x8 CU, P / B slice: the main wavefront's partner
-// for the 8x8 CUs;  5 + d: partner of wave 1 + d (P / B slices).  A partner takes the Nx2N / 2NxN and the vertical AMP candidates of a CU.
+// for the 8x8 CUs;  5 + d: partner of wave 1 + d (P / B slices);  8: second partner of the main wavefront.  A partner takes the Nx2N / 2NxN and the
+// vertical AMP candidates of a CU; with two partners the first takes Nx2N, the second 2NxN.
 enum { TK_INTRA = 0, TK_CHAIN = 1, TK_PAIR1 = 2, TK_PAIR2 = 3 };
 
 struct TeamBox {                       // mailbox of one helper wavefront (box[w - 1] of wave w)
   uint32_t reqSeq, doneSeq;            // requester: arguments, release, reqSeq + 1;  helper: results, release, doneSeq = reqSeq
-  int32_t cuZ, depth, part, kind;      // part: TK_INTRA: the part size to evaluate; TK_CHAIN: the parent's part size (deriveTestModeAMP); TK_PAIR2: bit 0 full, bit 1 merge-only vertical AMP
+  int32_t cuZ, depth, part, kind;      // part: TK_INTRA: the part size to evaluate; TK_CHAIN: the parent's part size (deriveTestModeAMP); TK_PAIR1: bit 0 Nx2N, bit 1 2NxN; TK_PAIR2: bit 0 full, bit 1 merge-only vertical AMP
   int32_t src, sens, owner, improved;  // src: the requesting wave; answers: CuFrame::ampSens (TK_PAIR*: the fractional bits the go-on coder was left with), the wave whose workspace holds the best mode, TK_PAIR*: a candidate came in below the threshold
   uint32_t bits, dist; double cost;    // the candidate as xCheckBestMode sees it (TK_INTRA / TK_CHAIN: split flag of the unsplit CU included)
   double threshold;                    // TK_PAIR2: the best cost so far
@@ -233,9 +234,9 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
 // here in the reference's order: this wavefront's candidates of a stage come first in it, so the partner's best replaces the running best only
 // when it is strictly cheaper.  The partner's 2Nx2N-dependent input -- m_integerMv2Nx2N after this CU's 2Nx2N search -- comes from me_token_prepass.
 // Returns the wave whose workspace holds the best mode (best[cuDepth], CI_NEXT_BEST of that depth).
-HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDepth, int sp, int self, int mate)
-{
-  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp); self = HM_UNI(self); mate = HM_UNI(mate);
+HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDepth, int sp, int self, int mate, int mate2 = 0)
+{ // mate2 != 0: a second partner for 2NxN (the first one then only takes Nx2N); CUs without AMP candidates only (the smallest CU size)
+  HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp); self = HM_UNI(self); mate = HM_UNI(mate); mate2 = HM_UNI(mate2);
 #if defined(HM355_NO_DUO)                /* diagnostic build: the whole chain on this wavefront */
   compress_cu_inter_modes(e, cuZ, cuDepth, sp); return self;
 #endif
@@ -249,18 +250,26 @@ HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDep
     const MvD keep = e->ws->intMv[i >> 4][i & 15];
     me_token_prepass(e, cuZ, cuDepth);
     HM_PAR_FOR(k, 32) mw->intMv[k >> 4][k & 15] = e->ws->intMv[k >> 4][k & 15];
+    if (mate2) { WorkSpace *mw2 = team_wave_ws(mate2); HM_PAR_FOR(k, 32) mw2->intMv[k >> 4][k & 15] = e->ws->intMv[k >> 4][k & 15]; }
     HM_SYNC();
     if (hm_lane() < 32) e->ws->intMv[i >> 4][i & 15] = keep;
     HM_SYNC();
   }
-  team_post(e, mate - 1, cuZ, cuDepth, 0, TK_PAIR1, self);
+  team_post(e, mate - 1, cuZ, cuDepth, mate2 ? 1 : 3, TK_PAIR1, self);
+  if (mate2) team_post(e, mate2 - 1, cuZ, cuDepth, 2, TK_PAIR1, self);
   check_rd_cost_merge_2Nx2N(e, cuZ, cuDepth, sp);
   check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2Nx2N, 0, sp);
   team_wait(e, mate - 1);
   if (HM_UNI(mb->improved) && mb->cost < f->bestCost) { f->bestCost = mb->cost; f->bestBits = mb->bits; f->bestDist = mb->dist; owner = mate; }
+  if (mate2) {                          // 2NxN follows Nx2N in the reference's order
+    team_wait(e, mate2 - 1);
+    mb = &HM_TEAM_PTR()->box[mate2 - 1];
+    if (HM_UNI(mb->improved) && mb->cost < f->bestCost) { f->bestCost = mb->cost; f->bestBits = mb->bits; f->bestDist = mb->dist; owner = mate2; }
+  }
   // TEncBinCABACCounter::resetBits keeps the fractional bits (TEncBinCoderCABAC.cpp:161), so what follows the candidates on the go-on coder "as it
   // stands" (the split flags, TEncCu.cpp:859-863, :1042-1047) sees the remainder the LAST candidate in the reference's order left -- the partner's, here
   int mateLast = 1; uint32_t mateFrac = (uint32_t)HM_UNI(mb->sens);
+  mb = &HM_TEAM_PTR()->box[mate - 1];
   if (cuDepth < 3) { // deriveTestModeAMP :386-447 on the best mode so far
     const Best *b = &team_wave_ws(owner)->best[cuDepth];
     const int ps = HM_UNI(b->m.part[cuZ]), bmrg = HM_UNI(b->im.mrg[cuZ]), bskip = HM_UNI(b->im.skip[cuZ]), parent = f->parentPart;
@@ -323,7 +332,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team_inter(Shared *e)
       if (cuDepth == 3) {               // TEncCu.cpp:628-863 at the smallest CU size, as compress_ctu does it
         if (!f->boundary) {
           HM_TSTAT_T0(t8);
-          const int owner = compress_cu_inter_modes_duo(e, cuZ, cuDepth, sp, 0, 4);
+          const int owner = compress_cu_inter_modes_duo(e, cuZ, cuDepth, sp, 0, 4, 8);
           HM_TSTAT_T1(3, t8);
           reset_bits(&e->cur);
           f->bestBits += num_bits(&e->cur);
@@ -507,8 +516,8 @@ HM_DEV inline void team_helper(Team *T, int wave, Pel *win)
     f->bestCost = HM_MAX_DOUBLE; f->bestBits = 0; f->bestDist = 0;
     if (kind == TK_PAIR1) {
       // Nx2N and 2NxN of the requester's CU (m_integerMv2Nx2N as its 2Nx2N search leaves it is in this wavefront's workspace)
-      check_rd_cost_inter(e, cuZ, cuDepth, SIZE_Nx2N, 0, cuDepth);
-      check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxN, 0, cuDepth);
+      if (part & 1) check_rd_cost_inter(e, cuZ, cuDepth, SIZE_Nx2N, 0, cuDepth);
+      if (part & 2) check_rd_cost_inter(e, cuZ, cuDepth, SIZE_2NxN, 0, cuDepth);
       team_answer(b, s, f->bestCost, f->bestBits, f->bestDist, (int)(e->cur.frac & 32767), wave, f->bestCost < HM_MAX_DOUBLE);
       continue;
     }
