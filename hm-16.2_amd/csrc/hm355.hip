@@ -104,7 +104,7 @@ extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_ker
   Team *T = HM_TEAM_PTR();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (threadIdx.x < HM_TEAM - 1) { T->box[threadIdx.x].reqSeq = 0; T->box[threadIdx.x].doneSeq = 0; }
-  if (threadIdx.x == 0) { T->quit = 0; T->dead = 0; T->abortWord = sched + 1; }
+  if (threadIdx.x == 0) { T->quit = 0; T->dead = 0; T->abortWord = sched + 1; T->waves = (int)(blockDim.x >> 6); }
   __syncthreads();
   if (wave != 0) {
     team_helper(T, wave, wave <= HM_TEAM_HELPERS ? P->teamWin + ((size_t)blockIdx.x * HM_TEAM_HELPERS + (size_t)(wave - 1)) * P->teamWinStride : (Pel *)0);
@@ -132,7 +132,7 @@ extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_ker
     if (!bad && dep2 >= 0) bad = hm355_wait_flag(done + dep2, sched + 1, epoch);
     if (bad) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    process_ctu(&T->sh[0], P, &T->item, (int)blockIdx.x * HM_TEAM, T);
+    process_ctu(&T->sh[0], P, &T->item, (int)blockIdx.x * T->waves, T);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) { __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add((gu32 *)(sched + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -440,17 +440,24 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
   // A WPP picture offers about 16 CTUs at a time (one when the CABAC state chains through all of them).  A launch that cannot keep ~5
   // one-wavefront searches per CU busy prefers the shortest dependency chain over the fewest instructions (fewWaves); one that cannot
   // even give every CU two searches runs as teams of HM_TEAM wavefronts per CTU (HM355_TEAM=0 / 1 overrides for A/B runs).
+  // P / B slices: a team (nine wavefronts, one team per CU) searches a CTU 5x faster than one wavefront, and 256 teams together do about half of
+  // what 2,816 one-wavefront searches do: measured on 1080p low-delay P streams with WaveFrontSynchro (CTU/s, one wavefront / teams): 32 streams
+  // 798 / 1,556, 64: 1,538 / 2,356, 128: 2,862 / 2,944 -- teams up to 96 streams (1,024 when every stream is one serial chain of CTUs).
   const long long parallel = (long long)n * (P.wpp ? 16 : 1);
   const int fewWaves = parallel < 1280 ? 1 : 0;
-  int useTeam = parallel <= 512 && L.wsCount >= HM_TEAM;
+  int anyInter = 0;
+  for (int f = 0; f < n; f++) if (c->slots[slot0 + f].fb.imeta) anyInter = 1;
+  int useTeam = (anyInter ? (P.wpp ? n <= 96 : n <= 1024) : parallel <= 512) && L.wsCount >= HM_TEAM;
   { const char *ev = getenv("HM355_TEAM"); if (ev && ev[0] == '0') useTeam = 0; if (ev && ev[0] == '1' && L.wsCount >= HM_TEAM) useTeam = 1; }
   const size_t winSamples = (size_t)65 * P.stride[0] + (size_t)33 * (P.stride[1] + P.stride[2]);
   int teams = 0;
+  int waves = anyInter ? HM_TEAM : HM_TEAM_I;   // P / B slices: every chain of candidates on two or three wavefronts (hm355_team.h)
+  { const char *ev = getenv("HM355_TEAM_WAVES"); if (ev && atoi(ev) == HM_TEAM_I) waves = HM_TEAM_I; }   // A/B runs (five-wavefront teams on P streams: 1,021 / 1,529 / 1,871 CTU/s in the table above)
   if (useTeam) {
     const size_t total = L.items.size();
     // as many teams as CTUs can ever be ready at once (the wavefront's widest step), a few more so that a finished team finds the next ticket taken
     size_t want = (size_t)maxItemsPerStep(P.wCtu, row1 - row0 + 1 < P.hCtu ? row1 - row0 + 1 : P.hCtu, P.wpp, n) + 2;
-    if (want > total) want = total; if (want > 512) want = 512; if (want > L.wsCount / HM_TEAM) want = L.wsCount / HM_TEAM;
+    if (want > total) want = total; if (want > 512) want = 512; if (want > L.wsCount / waves) want = L.wsCount / waves;
     if (want > L.teamCap) {
       HM_CHECK(c, hipStreamSynchronize(L.stream));
       if (L.dTeamWin) hipFree(L.dTeamWin);
@@ -475,8 +482,6 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
   const int total = (int)L.items.size();
   if (useTeam && teams > 0) {
     L.grid = teams;
-    int waves = HM_TEAM_I;               // P / B slices: every chain of candidates on two wavefronts (hm355_team.h)
-    for (int f = 0; f < n; f++) if (c->slots[slot0 + f].fb.imeta) waves = HM_TEAM;
     const size_t lds = HM_TEAM_LDS_BYTES(waves);
     if (!c->teamLdsSet) { HM_CHECK(c, hipFuncSetAttribute((const void *)hm355_ctu_team_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HM_TEAM_LDS_BYTES(HM_TEAM))); c->teamLdsSet = 1; }
     hipLaunchKernelGGL(hm355_ctu_team_kernel, dim3(L.grid), dim3(64 * waves), lds, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);

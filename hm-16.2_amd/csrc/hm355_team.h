@@ -53,6 +53,7 @@ struct Team {
   uint32_t quit, dead;                 // quit: the launch is over; dead: a wait timed out, results are void (the host sees the abort word)
   unsigned int *abortWord;
   WorkItem item;
+  int32_t waves, pad_[3];              // wavefronts of this launch's teams: HM_TEAM_I (no partners: a candidate chain stays on one wavefront) or HM_TEAM
   Shared sh[1];                        // [waves of the launch]: the launch sizes the workgroup's LDS for them
 };
 static_assert(offsetof(Team, sh) % 16 == 0, "Shared holds doubles and 16-byte rows");
@@ -237,9 +238,7 @@ HM_DEV HM_NOINLINE void compress_ctu_team(Shared *e)
 HM_DEV HM_NOINLINE int compress_cu_inter_modes_duo(Shared *e, int cuZ, int cuDepth, int sp, int self, int mate, int mate2 = 0)
 { // mate2 != 0: a second partner for 2NxN (the first one then only takes Nx2N); CUs without AMP candidates only (the smallest CU size)
   HM_ENTRY(e); cuZ = HM_UNI(cuZ); cuDepth = HM_UNI(cuDepth); sp = HM_UNI(sp); self = HM_UNI(self); mate = HM_UNI(mate); mate2 = HM_UNI(mate2);
-#if defined(HM355_NO_DUO)                /* diagnostic build: the whole chain on this wavefront */
-  compress_cu_inter_modes(e, cuZ, cuDepth, sp); return self;
-#endif
+  if (HM_UNI(HM_TEAM_PTR()->waves) < HM_TEAM) { compress_cu_inter_modes(e, cuZ, cuDepth, sp); return self; }   // a launch of five-wavefront teams: the whole chain here
   CuFrame *f = &e->cuf[sp];
   WorkSpace *mw = team_wave_ws(mate);
   TeamBox *mb = &HM_TEAM_PTR()->box[mate - 1];
