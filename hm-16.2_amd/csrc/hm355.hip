@@ -440,7 +440,7 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
   // A WPP picture offers about 16 CTUs at a time (one when the CABAC state chains through all of them).  A launch that cannot keep ~5
   // one-wavefront searches per CU busy prefers the shortest dependency chain over the fewest instructions (fewWaves); one that cannot
   // even give every CU two searches runs as teams of HM_TEAM wavefronts per CTU (HM355_TEAM=0 / 1 overrides for A/B runs).
-  // P / B slices: a team (nine wavefronts, one team per CU) searches a CTU 5x faster than one wavefront, and 256 teams together do about half of
+  // P / B slices: a team (nine wavefronts, one team per CU) takes a one-stream picture through 3x faster than one wavefront per CTU, and 256 teams together do about half of
   // what 2,816 one-wavefront searches do: measured on 1080p low-delay P streams with WaveFrontSynchro (CTU/s, one wavefront / teams): 32 streams
   // 798 / 1,556, 64: 1,538 / 2,356, 128: 2,862 / 2,944 -- teams up to 96 streams (1,024 when every stream is one serial chain of CTUs).
   const long long parallel = (long long)n * (P.wpp ? 16 : 1);
