@@ -39,7 +39,7 @@ typedef __attribute__((address_space(1))) unsigned int gu32;   // global address
 __device__ __attribute__((noinline)) int hm355_wait_flag(const unsigned int *flag, unsigned int *abortWord, unsigned int epoch)
 {
   int bad = 0;
-  if (threadIdx.x == 0) {
+  if (hm_lane() == 0) {
     const gu32 *f = (const gu32 *)flag; gu32 *ab = (gu32 *)abortWord;
     unsigned long long t0 = wall_clock64();
     unsigned int seen = __hip_atomic_load(ab + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // CTUs the launch has published so far
@@ -61,16 +61,22 @@ __device__ __attribute__((noinline)) int hm355_wait_flag(const unsigned int *fla
   return __shfl(bad, 0, 64);
 }
 
-extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
+// A workgroup holds HM_CTU_WAVES wavefronts, each an independent CTU search with its own ticket loop, LDS state and HBM workspace; they share
+// the read-only tables (LdsTables) and nothing else -- no workgroup barrier after the tables are loaded.  Two such workgroups fit a CU: 12 searches.
+extern "C" __global__ void __launch_bounds__(64 * HM_CTU_WAVES, 3) hm355_ctu_kernel(const Params *P, const WorkItem *items, int total, unsigned int *sched, unsigned int epoch)
 {
-  __shared__ WorkItem curItem;
+  __shared__ WorkItem curItems[HM_CTU_WAVES];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave == 0) load_tables();
+  __syncthreads();
+  WorkItem &curItem = curItems[wave];
   for (;;) {
     int idx = 0;
-    if (threadIdx.x == 0) idx = (int)atomicAdd(&sched[0], 1u);
+    if (hm_lane() == 0) idx = (int)atomicAdd(&sched[0], 1u);
     idx = __shfl(idx, 0, 64);
     if (idx >= total) break;
-    if (threadIdx.x == 0) curItem = items[idx];
-    __syncthreads();
+    if (hm_lane() == 0) curItem = items[idx];
+    HM_SYNC();
     const int cx = curItem.ctuX, cy = curItem.ctuY, wCtu = P->wCtu;
     const unsigned int *done = P->frames[curItem.frame].done;
     const int a = cy * wCtu + cx;
@@ -87,11 +93,11 @@ extern "C" __global__ void __launch_bounds__(64, 3) hm355_ctu_kernel(const Param
     if (!bad && dep2 >= 0) bad = hm355_wait_flag(done + dep2, sched + 1, epoch);
     if (bad) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    process_ctu(&g_sh, P, &curItem, (int)blockIdx.x);
+    process_ctu(&g_shs[wave], P, &curItem, (int)blockIdx.x * HM_CTU_WAVES + wave);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0) { __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add((gu32 *)(sched + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __syncthreads();
+    if (hm_lane() == 0) { __hip_atomic_store((gu32 *)(done + a), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_fetch_add((gu32 *)(sched + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    HM_SYNC();
   }
 }
 
@@ -105,6 +111,7 @@ extern "C" __global__ void __launch_bounds__(64 * HM_TEAM, 3) hm355_ctu_team_ker
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (threadIdx.x < HM_TEAM - 1) { T->box[threadIdx.x].reqSeq = 0; T->box[threadIdx.x].doneSeq = 0; }
   if (threadIdx.x == 0) { T->quit = 0; T->dead = 0; T->abortWord = sched + 1; T->waves = (int)(blockDim.x >> 6); }
+  if (wave == 0) load_tables();
   __syncthreads();
   if (wave != 0) {
     team_helper(T, wave, wave <= HM_TEAM_HELPERS ? P->teamWin + ((size_t)blockIdx.x * HM_TEAM_HELPERS + (size_t)(wave - 1)) * P->teamWinStride : (Pel *)0);
@@ -160,7 +167,7 @@ extern "C" __global__ void __launch_bounds__(64) hm355_dist_kernel(int kind, int
 extern "C" __global__ void __launch_bounds__(64) hm355_transform_kernel(int inverse, int n, int bitDepth, int useDst, int count, const int32_t *in, int32_t *out)
 {
   Shared &sh = g_sh;
-  load_tmat(&sh);
+  load_tables();
   const int l2 = hm_log2(n);
   for (int b = (int)blockIdx.x; b < count; b += (int)gridDim.x) {
     const int32_t *src = in + (size_t)b * n * n; int32_t *dst = out + (size_t)b * n * n;
@@ -490,8 +497,12 @@ static int run_begin(hm355_ctx *c, int l, int slot0, int n, const hm355_slice_de
     // A caller that keeps `share` launches in flight (hm355_set_lane_share): each launch only takes its share of the searches the device can hold --
     // a persistent workgroup that waits for a neighbouring CTU keeps its place on the CU, so a launch sized for the whole device would lock the
     // others out until its tickets run out, and the launches would run one after the other
-    if (c->laneShare > 1) { const int cap = (int)(2816 * 5 / (4 * c->laneShare)); if (L.grid > cap) L.grid = cap; }
-    hipLaunchKernelGGL(hm355_ctu_kernel, dim3(L.grid), dim3(64), 0, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
+    if (c->laneShare > 1) { const int cap = (int)(3072 * 5 / (4 * c->laneShare)); if (L.grid > cap) L.grid = cap; }
+    // workgroups of HM_CTU_WAVES independent searches (wavefronts); a search's workspace is blockIdx * HM_CTU_WAVES + wave < wsCount
+    int groups = (L.grid + HM_CTU_WAVES - 1) / HM_CTU_WAVES;
+    if (groups > (int)(L.wsCount / HM_CTU_WAVES)) groups = (int)(L.wsCount / HM_CTU_WAVES);
+    L.grid = groups * HM_CTU_WAVES;
+    hipLaunchKernelGGL(hm355_ctu_kernel, dim3(groups), dim3(64 * HM_CTU_WAVES), 0, L.stream, (const Params *)L.dP, (const WorkItem *)L.dItems, total, L.dSched, c->epoch);
   }
   HM_CHECK(c, hipGetLastError());
   HM_CHECK(c, hipEventRecord(L.ev1, L.stream));

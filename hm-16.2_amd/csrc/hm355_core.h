@@ -325,10 +325,21 @@ struct RefLds {
 #define HM_SLOT(d, ci) ((d) * CI_NUM + (ci) - ((d) == 4 ? 2 : 0))
 #define HM_NUM_SLOTS (4 * CI_NUM + 3)
 struct Team;                           // hm355_team.h: the wavefronts of one workgroup searching one CTU together (latency mode)
-struct Shared {
-  Cabac cur;                           // m_pcRDGoOnSbacCoder
+#define HM_CTU_WAVES 12                 /* independent CTU searches (wavefronts) per workgroup of hm355_ctu_kernel: they share one LdsTables */
+// read-only tables every CTU search of a workgroup shares (one copy per workgroup: the searches of a workgroup are independent wavefronts)
+struct LdsTables {
   int8_t tmat[32 * HM_TSTRIDE];        // 32-point transform matrix, padded rows
   int8_t dst4[16];                     // the 4-point DST of intra luma 4x4 blocks
+  int32_t ebits[128];                  // HM_ENTROPY_BITS for per-lane lookups (hm355_simt4.h)
+};
+#if defined(HM355_HOSTSIM)
+static LdsTables g_lt;
+#else
+__shared__ LdsTables g_lt;
+#endif
+#define HM_LT() (&g_lt)
+struct Shared {
+  Cabac cur;                           // m_pcRDGoOnSbacCoder
   int32_t bufA[32 * HM_TSTRIDE];
   union {                              // phase-exclusive LDS: transform temp | RDOQ state | intra reference samples
     int32_t bufB[32 * HM_TSTRIDE];
@@ -337,7 +348,6 @@ struct Shared {
   } u;
   TuWalk walkOuter, walkInner;         // tree-walk stacks
   CuFrame cuf[4];
-  int32_t ebits[128];                  // HM_ENTROPY_BITS for per-lane lookups (hm355_simt4.h)
   // results handed back by the big non-inlined stages (instead of pointers to private memory)
   double outCost; uint32_t outBits, outDist; double outRdCost;
   int32_t mpmZ;                        // the PU whose most-probable-mode list is tabulated below (-1: none)
@@ -394,10 +404,11 @@ __device__ inline void hm_trace(Shared *e, int tag, uint32_t a, uint32_t b, doub
 #endif
 
 #ifndef HM355_HOSTSIM
-__shared__ Shared g_sh;                // the one CTU search of this workgroup (HM_ENTRY)
+__shared__ Shared g_sh;                // the one wavefront of the secondary kernels' workgroups
+__shared__ Shared g_shs[HM_CTU_WAVES];  // the CTU searches of a workgroup of hm355_ctu_kernel
 #endif
 #if !defined(HM355_PROFILE)
-static_assert(sizeof(Shared) + 16 <= 14848 && sizeof(Shared) % 8 == 0, "Shared (+ the kernel's work item) must stay within 1/11 of a CU's 160 KB LDS in 512-byte granules (11 CTU searches per CU)");
+static_assert(HM_CTU_WAVES * (sizeof(Shared) + 16) + sizeof(LdsTables) <= 163840 / (12 / HM_CTU_WAVES) && sizeof(Shared) % 8 == 0, "two workgroups of HM_CTU_WAVES searches (+ work items, + the shared tables) per CU: 12 CTU searches in 160 KB of LDS");
 #endif
 static_assert(offsetof(Shared, bufA) % 8 == 0 && (16 * HM_TSTRIDE * 4) % 8 == 0, "the RDOQ cost array aliases the lower half of bufA as doubles");
 static_assert(offsetof(Shared, u) == offsetof(Shared, bufA) + sizeof(((Shared *)0)->bufA), "the motion search stages its reference window across bufA and the union behind it");
@@ -470,7 +481,7 @@ HM_DEV inline int hm_next_state(int st, int bin) { return bin == (st & 1) ? (st 
 HM_DEV inline void enc_bin(const Shared *e, Cabac *c, int ctx, int bin)
 {
   const int st = c->s[ctx];
-  c->frac += (uint64_t)e->ebits[st ^ bin];
+  c->frac += (uint64_t)HM_LT()->ebits[st ^ bin];
   c->s[ctx] = hm_next_state(st, bin);
 }
 HM_DEV inline void enc_ep(Cabac *c, int n) { c->frac += (uint64_t)32768 * (uint64_t)n; }
@@ -566,18 +577,19 @@ HM_DEV inline uint32_t dist_sad(const Pel *org, int so, const Pel *cur, int sc, 
 // ------------------------------------------------------------------------------------------------
 // transforms (TComTrQuant.cpp:387-935).  Blocks live in LDS with row stride HM_TSTRIDE.
 // ------------------------------------------------------------------------------------------------
-HM_DEV inline void load_tmat(Shared *e)
+HM_DEV inline void load_tables()
 {
   HM_PAR_FOR(i, 1024) {
     const int k = i >> 5, n = i & 31, m = (k * (2 * n + 1)) & 127;
     int v;
     if (m <= 32) v = HM_DCT_C[m]; else if (m <= 64) v = -HM_DCT_C[64 - m]; else if (m <= 96) v = -HM_DCT_C[m - 64]; else v = HM_DCT_C[128 - m];
-    e->tmat[k * HM_TSTRIDE + n] = (int8_t)v;
+    HM_LT()->tmat[k * HM_TSTRIDE + n] = (int8_t)v;
   }
-  HM_PAR_FOR(i, 16) e->dst4[i] = HM_DST4[i];
+  HM_PAR_FOR(i, 16) HM_LT()->dst4[i] = HM_DST4[i];
+  HM_PAR_FOR(i, 128) HM_LT()->ebits[i] = HM_ENTROPY_BITS[i];
   HM_SYNC();
 }
-HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst ? e->dst4[k * 4 + j] : e->tmat[(k * (32 / n)) * HM_TSTRIDE + j]; }
+HM_DEV inline int tm(const Shared *e, int n, int dst, int k, int j) { return dst ? HM_LT()->dst4[k * 4 + j] : HM_LT()->tmat[(k * (32 / n)) * HM_TSTRIDE + j]; }
 
 // The DCT rows are symmetric (even k) or antisymmetric (odd k) about their middle -- what partialButterfly4/8/16/32 (TComTrQuant.cpp:387-763) build
 // on -- so an output needs n/2 products of the folded input (x[i] +- x[n-1-i]) instead of n.  One fold level: the sums are the same integers in
@@ -622,7 +634,7 @@ HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth
   fold_rows(A, n, l2);
   HM_PAR_FOR(o, n * n) {
     const int j = o >> l2, k = o & (n - 1);
-    const int32_t *x = A + j * HM_TSTRIDE + ((k & 1) ? h : 0); const int8_t *t = e->tmat + (k * step) * HM_TSTRIDE;
+    const int32_t *x = A + j * HM_TSTRIDE + ((k & 1) ? h : 0); const int8_t *t = HM_LT()->tmat + (k * step) * HM_TSTRIDE;
     int32_t acc = 0;
     for (int i = 0; i < h; i++) acc += t[i] * x[i];
     B[k * HM_TSTRIDE + j] = (acc + a1) >> s1;
@@ -631,7 +643,7 @@ HM_DEV HM_NOINLINE void fwd_transform(Shared *e, int n, int useDst, int bitDepth
   fold_rows(B, n, l2);
   HM_PAR_FOR(o, n * n) {
     const int j = o >> l2, k = o & (n - 1);
-    const int32_t *x = B + j * HM_TSTRIDE + ((k & 1) ? h : 0); const int8_t *t = e->tmat + (k * step) * HM_TSTRIDE;
+    const int32_t *x = B + j * HM_TSTRIDE + ((k & 1) ? h : 0); const int8_t *t = HM_LT()->tmat + (k * step) * HM_TSTRIDE;
     int32_t acc = 0;
     for (int i = 0; i < h; i++) acc += t[i] * x[i];
     A[k * HM_TSTRIDE + j] = (acc + a2) >> s2;
@@ -666,7 +678,7 @@ HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth
   HM_PAR_FOR(o, n * h) {
     const int j = o >> (l2 - 1), i = o & (h - 1);
     int32_t ev = 0, od = 0;
-    for (int k = 0; k < n; k += 2) { ev += e->tmat[(k * step) * HM_TSTRIDE + i] * A[k * HM_TSTRIDE + j]; od += e->tmat[((k + 1) * step) * HM_TSTRIDE + i] * A[(k + 1) * HM_TSTRIDE + j]; }
+    for (int k = 0; k < n; k += 2) { ev += HM_LT()->tmat[(k * step) * HM_TSTRIDE + i] * A[k * HM_TSTRIDE + j]; od += HM_LT()->tmat[((k + 1) * step) * HM_TSTRIDE + i] * A[(k + 1) * HM_TSTRIDE + j]; }
     B[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (ev + od + (1 << (s1 - 1))) >> s1);
     B[j * HM_TSTRIDE + n - 1 - i] = hm_clip3(-32768, 32767, (ev - od + (1 << (s1 - 1))) >> s1);
   }
@@ -674,7 +686,7 @@ HM_DEV HM_NOINLINE void inv_transform(Shared *e, int n, int useDst, int bitDepth
   HM_PAR_FOR(o, n * h) {
     const int j = o >> (l2 - 1), i = o & (h - 1);
     int32_t ev = 0, od = 0;
-    for (int k = 0; k < n; k += 2) { ev += e->tmat[(k * step) * HM_TSTRIDE + i] * B[k * HM_TSTRIDE + j]; od += e->tmat[((k + 1) * step) * HM_TSTRIDE + i] * B[(k + 1) * HM_TSTRIDE + j]; }
+    for (int k = 0; k < n; k += 2) { ev += HM_LT()->tmat[(k * step) * HM_TSTRIDE + i] * B[k * HM_TSTRIDE + j]; od += HM_LT()->tmat[((k + 1) * step) * HM_TSTRIDE + i] * B[(k + 1) * HM_TSTRIDE + j]; }
     A[j * HM_TSTRIDE + i] = hm_clip3(-32768, 32767, (ev + od + (1 << (s2 - 1))) >> s2);
     A[j * HM_TSTRIDE + n - 1 - i] = hm_clip3(-32768, 32767, (ev - od + (1 << (s2 - 1))) >> s2);
   }
@@ -1215,10 +1227,10 @@ HM_DEV HM_NOINLINE int rdoq(Shared *e, TCoeff *dst, int n, int comp, int scanTyp
   HM_LV(double, vCGSig);                  // cost of the coded-sub-block flag per coefficient group (scan order)
   HM_WAVE_FOR(k) {
     const int bin = k & 1, c = k >> 1;
-    HM_LVK(tSig, k) = c < (chroma ? 16 : 28) ? e->ebits[cb->s[sigOff + c] ^ bin] : 0;
-    HM_LVK(tOne, k) = c < 30 ? e->ebits[cb->s[C_ONE + c] ^ bin] : 0;                   // C_ABS follows C_ONE
-    HM_LVK(tLast, k) = c < 30 ? e->ebits[cb->s[(c < 15 ? C_LASTX + c : C_LASTY + c - 15) + (chroma ? 15 : 0)] ^ bin] : 0;
-    HM_LVK(tMisc, k) = c < 15 ? e->ebits[cb->s[c < 4 ? C_SIG_CG + c : (c < 14 ? C_QT_CBF + c - 4 : C_ROOT_CBF)] ^ bin] : 0;   // cbfCtx 10 = root cbf
+    HM_LVK(tSig, k) = c < (chroma ? 16 : 28) ? HM_LT()->ebits[cb->s[sigOff + c] ^ bin] : 0;
+    HM_LVK(tOne, k) = c < 30 ? HM_LT()->ebits[cb->s[C_ONE + c] ^ bin] : 0;                   // C_ABS follows C_ONE
+    HM_LVK(tLast, k) = c < 30 ? HM_LT()->ebits[cb->s[(c < 15 ? C_LASTX + c : C_LASTY + c - 15) + (chroma ? 15 : 0)] ^ bin] : 0;
+    HM_LVK(tMisc, k) = c < 15 ? HM_LT()->ebits[cb->s[c < 4 ? C_SIG_CG + c : (c < 14 ? C_QT_CBF + c - 4 : C_ROOT_CBF)] ^ bin] : 0;   // cbfCtx 10 = root cbf
     HM_LVK(tLastCost, k) = 0;
     HM_LVK(vCGSig, k) = 0;
   }
@@ -1533,7 +1545,7 @@ HM_DEV inline void cabr_load(const Shared *e, CabacR &r, const Cabac *c)
 {
   HM_WAVE_FOR(k) {
     HM_LVK(r.st, k) = k < (int)(sizeof(c->s) / 4) ? ((const int32_t *)c->s)[k] : 0;
-    HM_LVK(r.eb0, k) = e->ebits[k]; HM_LVK(r.eb1, k) = e->ebits[64 + k];
+    HM_LVK(r.eb0, k) = HM_LT()->ebits[k]; HM_LVK(r.eb1, k) = HM_LT()->ebits[64 + k];
     HM_LVK(r.lps, k) = ((const int32_t *)HM_NEXT_LPS)[k & 31];
   }
   r.frac = c->frac;
@@ -2171,7 +2183,7 @@ HM_DEV HM_NOINLINE uint32_t est_intra_pred_qt(Shared *e, int cuZ, int cuDepth)
           if (k < 35) {
             int predIdx = -1;
             for (int i = 0; i < 3; i++) if (k == preds[i]) predIdx = i;
-            uint64_t fb = frac0 + (uint64_t)e->ebits[st0 ^ (predIdx != -1)];
+            uint64_t fb = frac0 + (uint64_t)HM_LT()->ebits[st0 ^ (predIdx != -1)];
             fb += (uint64_t)32768 * (uint64_t)(predIdx == -1 ? 5 : (predIdx ? 2 : 1));
             const uint32_t modeBits = (uint32_t)(fb >> 15);
             cost = (double)e->satd[k] + (double)modeBits * e->fb.sqrtLambda;
@@ -2770,8 +2782,9 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
   for (int i = 0; i < HM_PROF_N; i++) { e->prof[i] = 0; e->profCnt[i] = 0; }
 #endif
   HM_PROF_BEGIN(e, PR_TOTAL);
-  load_tmat(e);
-  HM_PAR_FOR(i, 128) e->ebits[i] = HM_ENTROPY_BITS[i];
+#if defined(HM355_HOSTSIM)
+  load_tables();                       // (the kernels load them once per workgroup)
+#endif
   const int a = e->ctuAddr, numCtus = P->wCtu * P->hCtu;
   { // TComDataCU::initCtu, TComDataCU.cpp:357-470
     CtuMeta *m = (&e->meta);

@@ -83,14 +83,14 @@ HM_DEV inline void s4_setup(Shared *e, const Cabac *cb, int chroma, int cbfCtx, 
   const int lxOff = C_LASTX + (chroma ? 15 : 0), lyOff = C_LASTY + (chroma ? 15 : 0);
   HM_PAR_FOR(i, T4_N) {
     int v = 0;
-    if (i < T4_ONE) v = e->ebits[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
-    else if (i < T4_ABS) v = e->ebits[cb->s[oneOff + ((i - T4_ONE) >> 1)] ^ (i & 1)];
-    else if (i < T4_LASTX) v = e->ebits[cb->s[absOff] ^ (i & 1)];
+    if (i < T4_ONE) v = HM_LT()->ebits[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
+    else if (i < T4_ABS) v = HM_LT()->ebits[cb->s[oneOff + ((i - T4_ONE) >> 1)] ^ (i & 1)];
+    else if (i < T4_LASTX) v = HM_LT()->ebits[cb->s[absOff] ^ (i & 1)];
     else if (i < T4_CBF) { // cost of the last-position group index g = 0..3: g ones, then a zero unless g is the maximum (xGetRateLast, TComTrQuant.cpp:2815)
       const int g = (i - T4_LASTX) & 3, off = i < T4_LASTY ? lxOff : lyOff;
-      for (int c = 0; c < g; c++) v += e->ebits[cb->s[off + c] ^ 1];
-      if (g < 3) v += e->ebits[cb->s[off + g] ^ 0];
-    } else if (i < T4_CBF + 2) v = e->ebits[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
+      for (int c = 0; c < g; c++) v += HM_LT()->ebits[cb->s[off + c] ^ 1];
+      if (g < 3) v += HM_LT()->ebits[cb->s[off + g] ^ 0];
+    } else if (i < T4_CBF + 2) v = HM_LT()->ebits[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
     A->tab[i] = v;
   }
   HM_PAR_FOR(i, 128) A->lps[i] = HM_NEXT_LPS[i];
@@ -116,7 +116,7 @@ HM_DEV inline void s4_setup(Shared *e, const Cabac *cb, int chroma, int cbfCtx, 
 HM_DEV inline void s4_bin(const Shared *e, Simt4A *A, int k, uint32_t *frac, int c, int bin)
 {
   const int st = A->ctx[c][k];
-  *frac += (uint32_t)e->ebits[st ^ bin];
+  *frac += (uint32_t)HM_LT()->ebits[st ^ bin];
   A->ctx[c][k] = (uint8_t)(bin == (st & 1) ? (st < 124 ? st + 2 : st) : A->lps[st]);
 }
 

@@ -58,16 +58,16 @@ HM_DEV inline void s8_setup(Shared *e, const Cabac *cb, int jobs, int chroma, in
   const int lxOff = chroma ? C_LASTX + 15 : C_LASTX + 3, lyOff = chroma ? C_LASTY + 15 : C_LASTY + 3, cgOff = C_SIG_CG + (chroma ? 2 : 0);
   HM_PAR_FOR(i, T8_N) {
     int v = 0;
-    if (i < T8_ONE) v = (chroma && (i >> 1) >= 16) ? 0 : e->ebits[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
-    else if (i < T8_ABS) v = (chroma && ((i - T8_ONE) >> 1) >= 8) ? 0 : e->ebits[cb->s[oneOff + ((i - T8_ONE) >> 1)] ^ (i & 1)];
-    else if (i < T8_LASTX) v = (chroma && ((i - T8_ABS) >> 1) >= 2) ? 0 : e->ebits[cb->s[absOff + ((i - T8_ABS) >> 1)] ^ (i & 1)];
+    if (i < T8_ONE) v = (chroma && (i >> 1) >= 16) ? 0 : HM_LT()->ebits[cb->s[sigOff + (i >> 1)] ^ (i & 1)];
+    else if (i < T8_ABS) v = (chroma && ((i - T8_ONE) >> 1) >= 8) ? 0 : HM_LT()->ebits[cb->s[oneOff + ((i - T8_ONE) >> 1)] ^ (i & 1)];
+    else if (i < T8_LASTX) v = (chroma && ((i - T8_ABS) >> 1) >= 2) ? 0 : HM_LT()->ebits[cb->s[absOff + ((i - T8_ABS) >> 1)] ^ (i & 1)];
     else if (i < T8_CG) { // last-position group index g = 0..5 of an 8x8 block: context (g >> 1) of the block's three; g > 3 adds one bypass bit (xGetRateLast :2815)
       const int g = (i - T8_LASTX) % 6, off = i < T8_LASTY ? lxOff : lyOff;
-      for (int c = 0; c < g; c++) v += e->ebits[cb->s[off + (c >> 1)] ^ 1];
-      if (g < 5) v += e->ebits[cb->s[off + (g >> 1)] ^ 0];
+      for (int c = 0; c < g; c++) v += HM_LT()->ebits[cb->s[off + (c >> 1)] ^ 1];
+      if (g < 5) v += HM_LT()->ebits[cb->s[off + (g >> 1)] ^ 0];
       if (g > 3) v += 32768 * ((g - 2) >> 1);
-    } else if (i < T8_CBF) v = e->ebits[cb->s[cgOff + ((i - T8_CG) >> 1)] ^ (i & 1)];
-    else v = e->ebits[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
+    } else if (i < T8_CBF) v = HM_LT()->ebits[cb->s[cgOff + ((i - T8_CG) >> 1)] ^ (i & 1)];
+    else v = HM_LT()->ebits[cb->s[C_QT_CBF + cbfCtx] ^ (i & 1)];
     A->tab[i] = v;
   }
   HM_PAR_FOR(i, 128) A->lps[i] = HM_NEXT_LPS[i];
@@ -86,7 +86,7 @@ HM_DEV inline void s8_setup(Shared *e, const Cabac *cb, int jobs, int chroma, in
 HM_DEV inline void s8_bin(const Shared *e, Simt8A *A, int k, uint32_t *frac, int c, int bin)
 {
   const int st = A->ctx[c][k];
-  *frac += (uint32_t)e->ebits[st ^ bin];
+  *frac += (uint32_t)HM_LT()->ebits[st ^ bin];
   A->ctx[c][k] = (uint8_t)(bin == (st & 1) ? (st < 124 ? st + 2 : st) : A->lps[st]);
 }
 // xGetICRate, TComTrQuant.cpp:2725-2800
@@ -430,13 +430,13 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
     HM_SYNC();
     HM_PAR_FOR(l, 64) { // xTrMxN :836, first stage
       const int j = l >> 3, kk = l & 7; int32_t acc = 0;
-      for (int i = 0; i < 8; i++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][j * 8 + i];
+      for (int i = 0; i < 8; i++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][j * 8 + i];
       A->tile[1][kk * 8 + j] = (acc + a1) >> s1;
     }
     HM_SYNC();
     HM_PAR_FOR(l, 64) { // second stage, one lane per scan position
       const int blkPos = B->scan[scanType][l], kk = blkPos >> 3, j = blkPos & 7; int32_t acc = 0;
-      for (int i = 0; i < 8; i++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][j * 8 + i];
+      for (int i = 0; i < 8; i++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][j * 8 + i];
       A->cs[l][c] = (int16_t)((acc + a2) >> s2);
     }
     HM_SYNC();
@@ -468,7 +468,7 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
       HM_SYNC();
       HM_PAR_FOR(l, 64) { // xITrMxN :894
         const int j = l >> 3, i = l & 7; int32_t acc = 0;
-        for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
+        for (int kk = 0; kk < 8; kk++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
         A->tile[1][j * 8 + i] = hm_clip3(-32768, 32767, (acc + 64) >> 7);
       }
       HM_SYNC();
@@ -478,7 +478,7 @@ HM_DEV HM_NOINLINE int simt8_luma_first_pass(Shared *e, TU tv, int numModes)
       const int j = l >> 3, i = l & 7; int resi = 0;
       if (cbf) {
         int32_t acc = 0;
-        for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
+        for (int kk = 0; kk < 8; kk++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
         resi = hm_clip3(-32768, 32767, (acc + (1 << (is2 - 1))) >> is2);
       }
       const int r = hm_clip3(0, maxv, pred_sample(e, mode, 8, 3, i, j, dcVal, bitDepth) + resi);
@@ -577,13 +577,13 @@ HM_DEV HM_NOINLINE uint32_t simt8_chroma_cu16(Shared *e, int cuZ)
     HM_SYNC();
     HM_PAR_FOR(l, 64) {
       const int j = l >> 3, kk = l & 7; int32_t acc = 0;
-      for (int i = 0; i < 8; i++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][j * 8 + i];
+      for (int i = 0; i < 8; i++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][j * 8 + i];
       A->tile[1][kk * 8 + j] = (acc + a1) >> s1;
     }
     HM_SYNC();
     HM_PAR_FOR(l, 64) {
       const int blkPos = B->scan[SCAN_DIAG][l], kk = blkPos >> 3, j = blkPos & 7; int32_t acc = 0;
-      for (int i = 0; i < 8; i++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][j * 8 + i];
+      for (int i = 0; i < 8; i++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][j * 8 + i];
       A->cs[l][job] = (int16_t)((acc + a2) >> s2);
     }
     HM_SYNC();
@@ -631,7 +631,7 @@ HM_DEV HM_NOINLINE uint32_t simt8_chroma_cu16(Shared *e, int cuZ)
       HM_SYNC();
       HM_PAR_FOR(l, 64) {
         const int j = l >> 3, i = l & 7; int32_t acc = 0;
-        for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
+        for (int kk = 0; kk < 8; kk++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
         A->tile[1][j * 8 + i] = hm_clip3(-32768, 32767, (acc + 64) >> 7);
       }
       HM_SYNC();
@@ -642,7 +642,7 @@ HM_DEV HM_NOINLINE uint32_t simt8_chroma_cu16(Shared *e, int cuZ)
       const int j = l >> 3, i = l & 7; int resi = 0;
       if (cbf) {
         int32_t acc = 0;
-        for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
+        for (int kk = 0; kk < 8; kk++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
         resi = hm_clip3(-32768, 32767, (acc + (1 << (is2 - 1))) >> is2);
       }
       const int rr = hm_clip3(0, maxv, s8_pred_sample_chroma(e, c, mode, i, j, dcVal[c]) + resi);
@@ -698,7 +698,7 @@ HM_DEV HM_NOINLINE void simt8_luma_winner_as_single_tu(Shared *e, TU tv)
     HM_SYNC();
     HM_PAR_FOR(l, 64) {
       const int j = l >> 3, i = l & 7; int32_t acc = 0;
-      for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
+      for (int kk = 0; kk < 8; kk++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[0][kk * 8 + j];
       A->tile[1][j * 8 + i] = hm_clip3(-32768, 32767, (acc + 64) >> 7);
     }
     HM_SYNC();
@@ -707,7 +707,7 @@ HM_DEV HM_NOINLINE void simt8_luma_winner_as_single_tu(Shared *e, TU tv)
     const int j = l >> 3, i = l & 7; int resi = 0;
     if (cbf) {
       int32_t acc = 0;
-      for (int kk = 0; kk < 8; kk++) acc += e->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
+      for (int kk = 0; kk < 8; kk++) acc += HM_LT()->tmat[(kk * 4) * HM_TSTRIDE + i] * A->tile[1][kk * 8 + j];
       resi = hm_clip3(-32768, 32767, (acc + (1 << (is2 - 1))) >> is2);
     }
     const Pel rr = (Pel)hm_clip3(0, maxv, pred_sample(e, mode, 8, 3, i, j, dcVal, bitDepth) + resi);

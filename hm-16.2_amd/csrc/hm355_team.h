@@ -482,9 +482,6 @@ HM_DEV inline void team_helper(Team *T, int wave, Pel *win)
 {
   Shared *e = &T->sh[wave]; const Shared *mainSh = &T->sh[0];
   TeamBox *b = &T->box[wave - 1];
-  load_tmat(e);
-  HM_PAR_FOR(i, 128) e->ebits[i] = HM_ENTROPY_BITS[i];
-  HM_SYNC();
   uint32_t seen = 0;
   for (;;) {
     uint32_t s;
