@@ -397,7 +397,7 @@ def run_as_stated(args, torch):
                                        "(search -> deblocking -> SAO -> slice data -> device-resident reference per picture), a step = one P picture",
                            "ctus_per_step": n_ctus, "picture_wall_ms_incl_loop_filters_and_slice_data": wall_ms / args.steps,
                            "pictures": [{k: x[k] for k in ("poc", "qp", "bits", "search_kernel_ms")} for x in pics]},
-                "roofline": {"bound": "hbm", "kernel": "hm355_ctu_team_kernel (a one-stream launch runs as teams of 8 wavefronts per CTU)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "roofline": {"bound": "hbm", "kernel": "hm355_ctu_team_kernel (a one-stream launch runs as teams of 9 wavefronts per CTU)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                              "avg_launch_ms": kernel_ms / args.steps, "launches": args.steps, "note": f"algorithmic bytes {alg} B/CTU (SURVEY 8d: 4 reference windows)"}}
         if not args.no_cpu_baseline and os.path.exists(enc_bin):
             cfg = os.path.join(td, "ldp.cfg")
