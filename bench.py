@@ -630,7 +630,7 @@ def intra_line(args, world, rows_mode, group, steps, warmup, dt, kernel_ms, laun
                      "avg_launch_ms": kernel_ms / max(1, launches), "launches": launches, "launches_in_flight": in_flight,
                      "note": "achieved = 54,278 B/CTU (SURVEY 8d) x CTUs per launch / average launch duration (HIP events on the launch's stream) x "
                              "launches in flight on average; the path is bound by the latency of its own dependent LDS / L2 round trips "
-                             "(profiles/r02_pmc_sq_summary.json), not by HBM"},
+                             "(profiles/r03_pmc_sq_summary.json), not by HBM"},
     }
 
 
