@@ -244,6 +244,8 @@ def run_inter(args, torch, world=1, rank=0, local_rank=0):
     else:
         w, h, bd, nref, qpp, qpf, ref_idx_pocs, cur_poc = 3840, 2160, 10, 2, qp + 2, 0.3536, [0, 8], 4
     enc = hm355.Encoder(w, h, bd, 1, max(S, nref))
+    if os.environ.get("HM355_SHARE"):       # diagnostic: fewer resident searches (hm355_set_lane_share caps the launch at 3840 / share)
+        enc.set_lane_share(int(os.environ["HM355_SHARE"]))
     n = enc.num_ctus
     ref_frames = sorted(set(ref_idx_pocs))
     res = enc.compress([synth.frame(w, h, bd, f, 1234) for f in ref_frames], qp)
