@@ -218,6 +218,7 @@ struct hm355_ctx {
   WorkSpace *dWs; size_t wsCount;
   uint8_t *arena;       // the pictures' planes, decision arrays, coefficients, statistics, CABAC states, done words: one allocation
   int teamLdsSet;
+  unsigned char *hStage; size_t hStageBytes;   // pinned host staging of hm355_download (one picture's results), allocated on first use
   unsigned int *dSched; unsigned int epoch;   // dSched: [0] ticket, [1] abort, [2] published CTUs of the search launch; [8] ticket, [9] abort of the bitstream launch
   std::vector<Slot> slots;
   Lane lane[HM_MAX_LANES];   // lane 0 is the context's own stream / scratch (every blocking entry point); 1.. are created on first use
@@ -262,7 +263,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HM355_ERR_NO_DEVICE;
   hm355_ctx *c = new hm355_ctx();
   c->cfg = *cfg; c->laneShare = 1; c->lastKernelMs = 0; c->lastLaunches = 0; c->staging = NULL; c->stagingBytes = 0; c->dDbk = NULL; c->dSao = NULL; c->dBits = NULL; c->dIngest = NULL;
-  c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->wsCount = 0; c->dSched = NULL; c->epoch = 0; c->teamLdsSet = 0;
+  c->arena = NULL; c->dP = NULL; c->dTab = NULL; c->dFrames = NULL; c->dWs = NULL; c->wsCount = 0; c->dSched = NULL; c->epoch = 0; c->teamLdsSet = 0; c->hStage = NULL; c->hStageBytes = 0;
   for (int l = 0; l < HM_MAX_LANES; l++) { Lane &L = c->lane[l]; L.stream = NULL; L.ev0 = L.ev1 = NULL; L.dP = NULL; L.dWs = NULL; L.wsCount = 0; L.dItems = NULL; L.itemsCap = 0; L.dSched = NULL; L.keyValid = 0; L.fewWaves = -1; L.busy = 0; L.grid = 0; L.inFixup = 0; L.dTeamWin = NULL; L.teamCap = 0; }
   Params &P = c->hp; memset(&P, 0, sizeof(P));
   P.width = cfg->width; P.height = cfg->height; P.bitDepth = cfg->bit_depth; P.wpp = cfg->wavefront_synchro;
@@ -340,6 +341,7 @@ extern "C" void hm355_destroy(hm355_ctx *c)
     if (L.ev0) hipEventDestroy(L.ev0); if (L.ev1) hipEventDestroy(L.ev1); if (L.stream) hipStreamDestroy(L.stream);
   }
   if (c->arena) hipFree(c->arena);
+  if (c->hStage) (void)hipHostFree(c->hStage);
   if (c->dTab) hipFree(c->dTab); if (c->dWs) hipFree(c->dWs); if (c->dFrames) hipFree(c->dFrames); if (c->dP) hipFree(c->dP); if (c->dSched) hipFree(c->dSched);
   if (c->staging) hipHostFree(c->staging);
   if (c->dDbk) hipFree(c->dDbk);
@@ -719,35 +721,45 @@ extern "C" int hm355_download(hm355_ctx *c, int slot, hm355_planes *rec, hm355_c
 {
   if (!c || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
   const Params &P = c->hp; FrameBuf &fb = c->slots[slot].fb;
+  if (rec) for (int k = 0; k < 3; k++) if (!rec->plane[k]) return fail(c, HM355_ERR_ARG, "null plane");
+  // one picture's results cross PCIe into a pinned staging buffer (asynchronous copies on the context's stream, one wait), then go to the caller's
+  // pageable buffers with plain memcpy: 81 MB per 4K picture
+  const size_t nC = (size_t)c->numCtus, bStat = sizeof(CtuStat) * nC, bMeta = sizeof(CtuMeta) * nC, bCoef = sizeof(TCoeff) * nC * HM_COEF_CTU;
+  size_t bPlane[3], oPlane[3], off = (bStat + bMeta + bCoef + 255) & ~(size_t)255;
+  for (int k = 0; k < 3; k++) { bPlane[k] = (size_t)(P.width >> (k ? 1 : 0)) * 2 * (size_t)(P.height >> (k ? 1 : 0)); oPlane[k] = off; off += (bPlane[k] + 255) & ~(size_t)255; }
+  if (c->hStageBytes < off) {
+    if (c->hStage) (void)hipHostFree(c->hStage);
+    c->hStage = NULL; c->hStageBytes = 0;
+    HM_CHECK(c, hipHostMalloc((void **)&c->hStage, off, hipHostMallocDefault));
+    c->hStageBytes = off;
+  }
+  CtuStat *st = (CtuStat *)c->hStage; CtuMeta *meta = (CtuMeta *)(c->hStage + bStat); TCoeff *coef = (TCoeff *)(c->hStage + bStat + bMeta);
   if (rec)
     for (int k = 0; k < 3; k++) {
-      if (!rec->plane[k]) return fail(c, HM355_ERR_ARG, "null plane");
       const int w = P.width >> (k ? 1 : 0), h = P.height >> (k ? 1 : 0);
-      HM_CHECK(c, hipMemcpy2D(rec->plane[k], (size_t)w * 2, fb.rec[k], (size_t)P.stride[k] * sizeof(Pel), (size_t)w * 2, h, hipMemcpyDeviceToHost));
+      HM_CHECK(c, hipMemcpy2DAsync(c->hStage + oPlane[k], (size_t)w * 2, fb.rec[k], (size_t)P.stride[k] * sizeof(Pel), (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
     }
-  if (ctus || stats) {
-    std::vector<CtuStat> st(c->numCtus);
-    HM_CHECK(c, hipMemcpy(st.data(), fb.stat, sizeof(CtuStat) * c->numCtus, hipMemcpyDeviceToHost));
-    if (stats) {
-      stats->pic_total_bits = 0; stats->pic_rd_cost = 0; stats->pic_dist = 0;
-      for (int a = 0; a < c->numCtus; a++) { stats->pic_total_bits += st[a].bits; stats->pic_rd_cost += st[a].cost; stats->pic_dist += st[a].dist; }
-    }
-    if (ctus) {
-      std::vector<CtuMeta> meta(c->numCtus);
-      std::vector<TCoeff> coef((size_t)c->numCtus * HM_COEF_CTU);
-      HM_CHECK(c, hipMemcpy(meta.data(), fb.meta, sizeof(CtuMeta) * c->numCtus, hipMemcpyDeviceToHost));
-      HM_CHECK(c, hipMemcpy(coef.data(), fb.coef, sizeof(TCoeff) * coef.size(), hipMemcpyDeviceToHost));
-      for (int a = 0; a < c->numCtus; a++) {
-        hm355_ctu_out *o = ctus + a; const CtuMeta *m = &meta[a];
-        o->total_cost = st[a].cost; o->total_bits = st[a].bits; o->total_dist = st[a].dist;
-        memcpy(o->depth, m->depth, 256); memcpy(o->part_size, m->part, 256); memcpy(o->pred_mode, m->pred, 256);
-        memcpy(o->intra_dir_luma, m->dirL, 256); memcpy(o->intra_dir_chroma, m->dirC, 256); memcpy(o->tr_idx, m->tr, 256);
-        memcpy(o->cbf, m->cbf, 768); memcpy(o->tskip, m->ts, 768);
-        const TCoeff *cf = coef.data() + (size_t)a * HM_COEF_CTU;
-        memcpy(o->coeff_y, cf, 4096 * 4); memcpy(o->coeff_cb, cf + 4096, 1024 * 4); memcpy(o->coeff_cr, cf + 5120, 1024 * 4);
-      }
-    }
+  if (ctus || stats) HM_CHECK(c, hipMemcpyAsync(st, fb.stat, bStat, hipMemcpyDeviceToHost, c->stream));
+  if (ctus) {
+    HM_CHECK(c, hipMemcpyAsync(meta, fb.meta, bMeta, hipMemcpyDeviceToHost, c->stream));
+    HM_CHECK(c, hipMemcpyAsync(coef, fb.coef, bCoef, hipMemcpyDeviceToHost, c->stream));
   }
+  HM_CHECK(c, hipStreamSynchronize(c->stream));
+  if (rec) for (int k = 0; k < 3; k++) memcpy(rec->plane[k], c->hStage + oPlane[k], bPlane[k]);
+  if (stats) {
+    stats->pic_total_bits = 0; stats->pic_rd_cost = 0; stats->pic_dist = 0;
+    for (int a = 0; a < c->numCtus; a++) { stats->pic_total_bits += st[a].bits; stats->pic_rd_cost += st[a].cost; stats->pic_dist += st[a].dist; }
+  }
+  if (ctus)
+    for (int a = 0; a < c->numCtus; a++) {
+      hm355_ctu_out *o = ctus + a; const CtuMeta *m = &meta[a];
+      o->total_cost = st[a].cost; o->total_bits = st[a].bits; o->total_dist = st[a].dist;
+      memcpy(o->depth, m->depth, 256); memcpy(o->part_size, m->part, 256); memcpy(o->pred_mode, m->pred, 256);
+      memcpy(o->intra_dir_luma, m->dirL, 256); memcpy(o->intra_dir_chroma, m->dirC, 256); memcpy(o->tr_idx, m->tr, 256);
+      memcpy(o->cbf, m->cbf, 768); memcpy(o->tskip, m->ts, 768);
+      const TCoeff *cf = coef + (size_t)a * HM_COEF_CTU;
+      memcpy(o->coeff_y, cf, 4096 * 4); memcpy(o->coeff_cb, cf + 4096, 1024 * 4); memcpy(o->coeff_cr, cf + 5120, 1024 * 4);
+    }
   return HM355_OK;
 }
 
