@@ -1857,6 +1857,11 @@ static int compress_impl(const hmo_cfg *cfg, const uint16_t *const org[3], uint1
       e->ctuQp = dq->ctu_qp ? dq->ctu_qp[a] : cfg->qp;
       e->refQp = (a == 0 || (e->ctuX == 0 && cfg->wpp)) ? cfg->qp : e->lastQp[a - 1];
       set_quant_qp(e, e->ctuQp);
+      if (dq->ctu_lambda) { /* TComRdCost::setLambda (TComRdCost.cpp:194-216) + TComTrQuant::setLambdas with the chroma weight of the slice, TEncSlice.cpp:793-803 */
+        const double L = dq->ctu_lambda[a];
+        e->lambda = L; e->sqrtLambda = sqrt(L); e->lambdaC = L / e->chromaWeight;
+        if (e->is) { islice.lambdaMotionSAD = (uint32_t)floor(65536.0 * e->sqrtLambda); islice.lambdaMotionSSE = (uint32_t)floor(65536.0 * L); }
+      }
     }
     if (a == 0) cabac_init(&e->slot[0][CI_CURR_BEST], cfg->qp);
     else if (e->ctuX == 0 && cfg->wpp) {

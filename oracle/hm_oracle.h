@@ -90,6 +90,8 @@ typedef struct {
   const int8_t *ctu_qp;              /* [numCtus] QP of each CTU (TEncCu::xComputeQP / TEncRateCtrl::getRCQP); NULL: the slice QP */
   int8_t *qp_out;                    /* [numCtus*256] m_phQP as compressSlice leaves it; may be NULL */
   int *dqp_flag_out;                 /* m_bEncodeDQP on exit; may be NULL */
+  const double *ctu_lambda;          /* [numCtus] lambda of each CTU's search: the LCU-level rate control sets one per CTU (TEncSlice.cpp:776-808: m_pcRdCost->setLambda,
+                                        m_pcTrQuant->setLambdas); NULL: the slice lambda.  n4 stage 2, oracle only so far */
 } hmo_dqp;
 /* slice NULL: I slice */
 int hmo_compress_slice_dqp(const hmo_cfg *cfg, const hmo_inter_slice *slice, const uint16_t *const org[3], uint16_t *const rec[3],

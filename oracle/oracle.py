@@ -152,7 +152,8 @@ def compress_inter(planes, bit_depth, srec, finals, trace=None, wpp=0):
 
 # ---- cu_qp_delta: adaptive QP / rate control ---------------------------------------------------------
 class Dqp(C.Structure):
-    _fields_ = [("use_dqp", C.c_int), ("dqp_flag_in", C.c_int), ("ctu_qp", C.c_void_p), ("qp_out", C.c_void_p), ("dqp_flag_out", C.POINTER(C.c_int))]
+    _fields_ = [("use_dqp", C.c_int), ("dqp_flag_in", C.c_int), ("ctu_qp", C.c_void_p), ("qp_out", C.c_void_p), ("dqp_flag_out", C.POINTER(C.c_int)),
+                ("ctu_lambda", C.c_void_p)]
 
 
 def preanalyze(luma):
@@ -174,7 +175,7 @@ def aq_qp(activity, avg_activity, aq_range, slice_qp, bit_depth):
     return np.array([L.hmo_aq_qp(float(a), float(avg_activity), int(aq_range), int(slice_qp), int(bit_depth)) for a in activity], np.int8)
 
 
-def compress_dqp(planes, bit_depth, srec, finals, wpp, ctu_qp, dqp_flag_in, trace=None):
+def compress_dqp(planes, bit_depth, srec, finals, wpp, ctu_qp, dqp_flag_in, trace=None, ctu_lambda=None):
     """One slice (I, P or B: srec["slice_type"]) with cu_qp_delta enabled: ctu_qp = int8 QP per CTU (None: the slice QP everywhere, as the
     picture-level rate control runs it).  Returns (rec planes, ctus, inter ctus or None, qp (numCtus, 256) int8, dqp_flag_out)."""
     L = lib()
@@ -191,7 +192,9 @@ def compress_dqp(planes, bit_depth, srec, finals, wpp, ctu_qp, dqp_flag_in, trac
     cq = np.ascontiguousarray(ctu_qp, np.int8) if ctu_qp is not None else None
     assert cq is None or len(cq) == n
     qp_out = np.zeros((n, 256), np.int8); flag_out = C.c_int(-1)
-    d = Dqp(1, int(dqp_flag_in), cq.ctypes.data if cq is not None else None, qp_out.ctypes.data, C.pointer(flag_out))
+    cl = np.ascontiguousarray(ctu_lambda, np.float64) if ctu_lambda is not None else None      # the LCU-level rate control's lambda per CTU
+    assert cl is None or len(cl) == n
+    d = Dqp(1, int(dqp_flag_in), cq.ctypes.data if cq is not None else None, qp_out.ctypes.data, C.pointer(flag_out), cl.ctypes.data if cl is not None else None)
     L.hmo_compress_slice_dqp.argtypes = [C.POINTER(Cfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Dqp)]
     L.hmo_set_trace.argtypes = [C.c_char_p]
     if trace:

@@ -178,14 +178,32 @@ static void putMotion(FILE *f, TComDataCU *ctu, int l, bool full)
   fwrite(ri, 1, 256, f);
   if (full) { fwrite(mi, 1, 256, f); fwrite(mn, 1, 256, f); }
 }
+// TEncCu::compressCtu: the lambda every CTU is searched with (the LCU-level rate control sets one per CTU, TEncSlice.cpp:776-808)
+static std::vector<double> g_ctuLambda;
+static std::vector<int32_t> g_ctuRcQp;
+extern "C" void __real__ZN6TEncCu11compressCtuEP10TComDataCU(TEncCu *self, TComDataCU *ctu);
+extern "C" void __wrap__ZN6TEncCu11compressCtuEP10TComDataCU(TEncCu *self, TComDataCU *ctu)
+{
+  g_ctuLambda.push_back(self->m_pcRdCost->m_dLambda);
+  g_ctuRcQp.push_back(self->m_pcEncCfg->getUseRateCtrl() ? (int32_t)self->m_pcRateCtrl->getRCQP() : 0);      // what xCompressCU takes as the CTU's QP (TEncCu.cpp:522-526)
+  __real__ZN6TEncCu11compressCtuEP10TComDataCU(self, ctu);
+}
 extern "C" void __real__ZN9TEncSlice13compressSliceEP7TComPic(TEncSlice *self, TComPic *pic);
 extern "C" void __wrap__ZN9TEncSlice13compressSliceEP7TComPic(TEncSlice *self, TComPic *pic)
 {
   const int32_t dqpFlagIn = self->m_pcCuEncoder->getdQPFlag() ? 1 : 0;      // TEncCu::m_bEncodeDQP as the previous picture's encodeSlice left it
+  g_ctuLambda.clear(); g_ctuRcQp.clear();
   __real__ZN9TEncSlice13compressSliceEP7TComPic(self, pic);
   if (!g_dump2) return;
   FILE *f = g_dump2;
   TComSlice *sl = pic->getSlice(self->getSliceIdx());
+  if (self->m_pcCfg->getUseRateCtrl() && self->m_pcCfg->getLCULevelRC())
+  { // 'L' (before the 'Q' / 'S' records of the same slice, only under the LCU-level rate control): u32 numCtus; f64 lambda of every CTU's search; i32 its QP
+    fputc('L', f);
+    put32(f, (uint32_t)g_ctuLambda.size());
+    fwrite(g_ctuLambda.data(), 8, g_ctuLambda.size(), f);
+    fwrite(g_ctuRcQp.data(), 4, g_ctuRcQp.size(), f);
+  }
   if (sl->getPPS()->getUseDQP())
   { // 'Q' (before the 'S' record of the same slice, only when cu_qp_delta is enabled): i32 maxCuDQPDepth, dqpFlagIn, dqpFlagOut, qpAdaptationRange;
     //   u32 numCtus; per CTU i8[256] m_phQP as compressSlice left it; then the layer-0 activities of TEncPreanalyzer when AdaptiveQP is on:

@@ -83,7 +83,13 @@ def load_ldp_case(name, records=None, sao=None, bits=None):
     cfg["wpp"] = int(g["wpp"]) if "wpp" in g else 0
     slices, finals = [], {}
     pending_q = None
+    pending_l = None
     for i in range(int(g["num_records"])):
+        if chr(int(g[f"r{i}_tag"])) == "L":                      # LCU-level rate control: the lambda of every CTU of the slice that follows (tests/hmd2.py 'L' record)
+            pending_l = {"tag": "L", "ctu_lambda": g[f"r{i}_ctu_lambda"], "ctu_qp": g[f"r{i}_ctu_qp"]}
+            if records is not None:
+                records.append(pending_l)
+            continue
         if chr(int(g[f"r{i}_tag"])) == "Q":                      # cu_qp_delta side data of the slice that follows (tests/hmd2.py 'Q' record)
             pending_q = {"tag": "Q", "qp": g[f"r{i}_qp"], "activity": g[f"r{i}_activity"]}
             for k in ("max_cu_dqp_depth", "dqp_flag_in", "dqp_flag_out", "aq_range", "avg_activity"):
@@ -115,6 +121,7 @@ def load_ldp_case(name, records=None, sao=None, bits=None):
                 r[k] = g[f"r{i}_{k}"][()]
             r["ctus"] = g[f"r{i}_ctus"]
             r["dqp"], pending_q = pending_q, None               # None unless cu_qp_delta was enabled
+            r["lcu_rc"], pending_l = pending_l, None            # None unless the LCU-level rate control ran: its lambda and QP per CTU
             slices.append(r)
         else:
             r["poc"] = int(g[f"r{i}_poc"]); r["slice_type"] = int(g[f"r{i}_slice_type"]); r["motion"] = g[f"r{i}_motion"]
@@ -125,6 +132,7 @@ def load_ldp_case(name, records=None, sao=None, bits=None):
 
 
 DQP_CASES = ["aq_i_256x192_8b_qp30", "aq_iwpp_320x200_10b_qp27", "aq_ldp_256x136_8b_qp32", "aq_ra_192x128_10b_qp30", "rc_ldp_256x128_8b"]
+LCU_RC_CASES = ["rc2_ldp_256x128_8b"]   # n4 stage 2, oracle only so far: the LCU-level rate control hands every CTU a QP and a lambda
 
 
 INTER_PAIRS = [("skip", "skip"), ("merge_flag", "merge_flag"), ("merge_idx", "merge_idx"), ("inter_dir", "inter_dir")]

@@ -125,6 +125,8 @@ LDP_CASES = [
     ("aq_ldp_256x136_8b_qp32", 256, 136, 8, 4, 32, 53, 1, "encoder_lowdelay_P_main.cfg", ("--AdaptiveQP=1",)),
     ("aq_ra_192x128_10b_qp30", 192, 128, 10, 5, 30, 54, 0, "encoder_randomaccess_main10.cfg", ("--AdaptiveQP=1",)),
     ("rc_ldp_256x128_8b", 256, 128, 8, 5, 32, 55, 1, "encoder_lowdelay_P_main.cfg", ("--RateControl=1", "--TargetBitrate=400000", "--LCULevelRateControl=0", "--InitialQP=30")),
+    # n4 stage 2: the LCU-level rate model gives every CTU of the P pictures its own QP AND lambda ('L' record)
+    ("rc2_ldp_256x128_8b", 256, 128, 8, 5, 32, 56, 1, "encoder_lowdelay_P_main.cfg", ("--RateControl=1", "--TargetBitrate=400000", "--LCULevelRateControl=1", "--InitialQP=30")),
 ]
 S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
           "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
@@ -144,6 +146,9 @@ def run_ldp_case(name, w, h, bd, nf, qp, seed, wpp=0, cfg="encoder_lowdelay_P_ma
     out = {"width": w, "height": h, "bit_depth": bd, "frames": nf, "seed": seed, "wpp": wpp, "num_records": len(recs)}
     for i, r in enumerate(recs):
         out[f"r{i}_tag"] = np.array(ord(r["tag"]))
+        if r["tag"] == "L":
+            out[f"r{i}_ctu_lambda"] = r["ctu_lambda"]; out[f"r{i}_ctu_qp"] = r["ctu_qp"]
+            continue
         if r["tag"] == "Q":
             for k in ("max_cu_dqp_depth", "dqp_flag_in", "dqp_flag_out", "aq_range", "avg_activity"):
                 out[f"r{i}_{k}"] = np.array(r[k])

@@ -67,6 +67,11 @@ def parse(path, width, height):
             if nu:
                 r["avg_activity"], = struct.unpack_from("<d", buf, off); off += 8
                 r["activity"] = np.frombuffer(buf, "<f8", nu, off).copy(); off += 8 * nu
+        elif tag == b"L":                                   # LCU-level rate control: the lambda of every CTU's search (slice whose 'S' record follows)
+            r = {"tag": "L"}
+            n, = struct.unpack_from("<I", buf, off); off += 4
+            r["ctu_lambda"] = np.frombuffer(buf, "<f8", n, off).copy(); off += 8 * n
+            r["ctu_qp"] = np.frombuffer(buf, "<i4", n, off).copy(); off += 4 * n
         elif tag == b"A":
             r = {"tag": "A"}
             r["poc"], r["depth"], en0, en1, n = struct.unpack_from("<4iI", buf, off); off += 20
@@ -96,7 +101,7 @@ def write(path, recs, bits=False):
     with open(path, "wb") as f:
         f.write(b"HMD2")
         for r in recs:
-            if r["tag"] in ("A", "Q") or (r["tag"] == "B" and not bits):
+            if r["tag"] in ("A", "Q", "L") or (r["tag"] == "B" and not bits):
                 continue                                  # SAO decisions, slice data bytes: not part of what the search replays
             if r["tag"] == "B":
                 for a in recs:

@@ -177,6 +177,36 @@ def test_oracle_matches_full_size_reference_digests(built, name):
             assert np.array_equal(common.md5_of(np.ascontiguousarray(rec[c], np.uint16)), p["rec_md5"][c]), f"{name} POC {int(p['poc'])}: reconstruction plane {c}"
 
 
+@pytest.mark.parametrize("name", common.LCU_RC_CASES)
+def test_oracle_lcu_level_rate_control_matches_reference(built, name):
+    """SURVEY 8f n4, stage 2 (oracle first): a clip the reference encoded with --RateControl=1 --LCULevelRateControl=1.  TEncSlice::compressSlice asks the
+    rate model for a lambda and a QP per CTU (TEncSlice.cpp:776-808: TComRdCost::setLambda, TComTrQuant::setLambdas, setRCQP); the harness records both
+    ('L' record).  Given them the restated search reproduces decisions, motion, coefficients, costs, reconstruction, m_phQP and m_bEncodeDQP of every
+    picture bit for bit -- the search side of the LCU-level rate control is pinned; the model itself (TEncRateCtrl.cpp) and a lambda per CTU on the
+    device are what stage 2 still needs."""
+    import oracle
+    cfg, slices, finals = common.load_ldp_case(name)
+    n_var = 0
+    for r in slices:
+        q, lcu = r["dqp"], r["lcu_rc"]
+        assert q is not None and lcu is not None and int(q["max_cu_dqp_depth"]) == 0
+        planes = synth.frame(cfg["width"], cfg["height"], cfg["bit_depth"], int(r["poc"]), cfg["seed"])
+        rec, ctus, ictus, qp, flag = oracle.compress_dqp(planes, cfg["bit_depth"], r, finals, cfg["wpp"], lcu["ctu_qp"].astype(np.int8), int(q["dqp_flag_in"]),
+                                                         ctu_lambda=lcu["ctu_lambda"])
+        what = f"{name} POC {int(r['poc'])}"
+        if ictus is None:
+            common.assert_ctus_equal(ctus, common.split_fixture_ctus(r["ctus"])[0], what)
+        else:
+            common.assert_inter_ctus_equal(ctus, ictus, r["ctus"], what)
+        for c in range(3):
+            assert np.array_equal(rec[c], r["rec"][c]), f"{what}: reconstruction plane {c}"
+        m = common.inside_mask(len(ctus), cfg["width"], cfg["height"])
+        assert np.array_equal(qp[m], q["qp"][m]), f"{what}: QP differs in CTUs {np.nonzero((qp != q['qp']).any(axis=1))[0][:8]}"
+        assert flag == int(q["dqp_flag_out"]), f"{what}: m_bEncodeDQP after the slice"
+        n_var += int(len(set(np.round(lcu["ctu_lambda"], 9))) > 1)
+    assert n_var >= 3, "the clip should have pictures whose CTUs were searched with different lambdas"
+
+
 @pytest.mark.parametrize("name", common.DQP_CASES)
 def test_oracle_cu_qp_delta_matches_reference(built, name):
     """clips the reference encoded with AdaptiveQP (I, P and B slices, WPP on / off, 8 / 10 bit) and with the picture-level rate
