@@ -132,7 +132,7 @@ def load_ldp_case(name, records=None, sao=None, bits=None):
 
 
 DQP_CASES = ["aq_i_256x192_8b_qp30", "aq_iwpp_320x200_10b_qp27", "aq_ldp_256x136_8b_qp32", "aq_ra_192x128_10b_qp30", "rc_ldp_256x128_8b"]
-LCU_RC_CASES = ["rc2_ldp_256x128_8b"]   # n4 stage 2, oracle only so far: the LCU-level rate control hands every CTU a QP and a lambda
+LCU_RC_CASES = ["rc2_ldp_256x128_8b", "rc2_i_256x192_10b", "rc2_ra_192x128_10b"]   # n4 stage 2, oracle only so far: the LCU-level rate control hands every CTU a QP and a lambda
 
 
 INTER_PAIRS = [("skip", "skip"), ("merge_flag", "merge_flag"), ("merge_idx", "merge_idx"), ("inter_dir", "inter_dir")]

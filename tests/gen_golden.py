@@ -127,6 +127,8 @@ LDP_CASES = [
     ("rc_ldp_256x128_8b", 256, 128, 8, 5, 32, 55, 1, "encoder_lowdelay_P_main.cfg", ("--RateControl=1", "--TargetBitrate=400000", "--LCULevelRateControl=0", "--InitialQP=30")),
     # n4 stage 2: the LCU-level rate model gives every CTU of the P pictures its own QP AND lambda ('L' record)
     ("rc2_ldp_256x128_8b", 256, 128, 8, 5, 32, 56, 1, "encoder_lowdelay_P_main.cfg", ("--RateControl=1", "--TargetBitrate=400000", "--LCULevelRateControl=1", "--InitialQP=30")),
+    ("rc2_i_256x192_10b", 256, 192, 10, 3, 32, 57, 0, "encoder_intra_main10.cfg", ("--RateControl=1", "--TargetBitrate=3000000", "--LCULevelRateControl=1", "--InitialQP=28")),
+    ("rc2_ra_192x128_10b", 192, 128, 10, 5, 32, 58, 0, "encoder_randomaccess_main10.cfg", ("--RateControl=1", "--TargetBitrate=300000", "--LCULevelRateControl=1", "--InitialQP=30")),
 ]
 S_KEYS = ("poc", "slice_type", "qp", "lambda", "sqrt_lambda", "weight_cb", "weight_cr", "lambda_motion_sad", "lambda_motion_sse",
           "col_from_l0", "col_ref_idx", "tmvp", "mvd_l1_zero", "max_merge_cand", "check_ldc", "cabac_init_type")
