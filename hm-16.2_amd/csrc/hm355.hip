@@ -194,7 +194,6 @@ struct Slot {           // one picture resident in HBM
   uint8_t *bitsRaw, *bitsPacked; uint32_t *bitsSizes; CabacW *bitsSync; uint32_t *bitsFlag; InterPic *bitsIp;   // bitstream pass (allocated on first use)
   // cu_qp_delta (hm355_set_dqp): device state of the picture, allocated on first use; dqpOn: the next searches of the slot run with it
   DqpPic *dDqp; int8_t *dCtuQp; CtuDqp *dDqpOut; uint8_t *dRowFlag; int dqpOn, dqpFlagIn;
-  CtuRc *dCtuRc; std::vector<double> ctuLambda;      // LCU-level rate control: a lambda per CTU (hm355_dqp_desc::ctu_lambda), device table on first use
   std::vector<int8_t> ctuQp; std::vector<uint8_t> rowFlag; hm355_slice_desc lastSlice;
 };
 #define HM_BITS_CAP_PER_CTU 16384u   /* bytes reserved per CTU in the raw substream buffers: above the raw size of a 10-bit 4:2:0 CTU (7.7 KB) */
@@ -303,7 +302,7 @@ extern "C" int hm355_create(const hm355_seq_cfg *cfg, hm355_ctx **out)
       c->slots[s].imeta = NULL; c->slots[s].saoSrc[0] = c->slots[s].saoSrc[1] = c->slots[s].saoSrc[2] = NULL; c->slots[s].saoStat = NULL; c->slots[s].saoCand = NULL; c->slots[s].saoCoded = c->slots[s].saoRecon = NULL;
       c->slots[s].rawIn = c->slots[s].rawOut = NULL;
       c->slots[s].bitsRaw = c->slots[s].bitsPacked = NULL; c->slots[s].bitsSizes = NULL; c->slots[s].bitsSync = NULL; c->slots[s].bitsFlag = NULL; c->slots[s].bitsIp = NULL;
-      c->slots[s].dDqp = NULL; c->slots[s].dCtuQp = NULL; c->slots[s].dDqpOut = NULL; c->slots[s].dRowFlag = NULL; c->slots[s].dqpOn = 0; c->slots[s].dqpFlagIn = 0; c->slots[s].dCtuRc = NULL;
+      c->slots[s].dDqp = NULL; c->slots[s].dCtuQp = NULL; c->slots[s].dDqpOut = NULL; c->slots[s].dRowFlag = NULL; c->slots[s].dqpOn = 0; c->slots[s].dqpFlagIn = 0;
       uint8_t *p = c->arena + off;
       for (int k = 0; k < 3; k++) { fb.org[k] = (Pel *)p; p += planeBytes[k]; fb.rec[k] = (Pel *)p; p += planeBytes[k]; }
       fb.meta = (CtuMeta *)p; p += metaBytes; fb.coef = (TCoeff *)p; p += coefBytes; fb.stat = (CtuStat *)p; p += statBytes;
@@ -329,7 +328,7 @@ extern "C" void hm355_destroy(hm355_ctx *c)
     for (int k = 0; k < 3; k++) if (c->slots[s].saoSrc[k]) hipFree(c->slots[s].saoSrc[k]);
     { Slot &sl = c->slots[s]; if (sl.rawIn) hipFree(sl.rawIn); if (sl.rawOut) hipFree(sl.rawOut); if (sl.bitsRaw) hipFree(sl.bitsRaw); if (sl.bitsPacked) hipFree(sl.bitsPacked); if (sl.bitsSizes) hipFree(sl.bitsSizes);
       if (sl.bitsSync) hipFree(sl.bitsSync); if (sl.bitsFlag) hipFree(sl.bitsFlag); if (sl.bitsIp) hipFree(sl.bitsIp); }
-    { Slot &sl = c->slots[s]; if (sl.dDqp) hipFree(sl.dDqp); if (sl.dCtuQp) hipFree(sl.dCtuQp); if (sl.dDqpOut) hipFree(sl.dDqpOut); if (sl.dRowFlag) hipFree(sl.dRowFlag); if (sl.dCtuRc) hipFree(sl.dCtuRc); }
+    { Slot &sl = c->slots[s]; if (sl.dDqp) hipFree(sl.dDqp); if (sl.dCtuQp) hipFree(sl.dCtuQp); if (sl.dDqpOut) hipFree(sl.dDqpOut); if (sl.dRowFlag) hipFree(sl.dRowFlag); }
     if (c->slots[s].saoStat) hipFree(c->slots[s].saoStat); if (c->slots[s].saoCand) hipFree(c->slots[s].saoCand); if (c->slots[s].saoCoded) hipFree(c->slots[s].saoCoded); if (c->slots[s].saoRecon) hipFree(c->slots[s].saoRecon);
   }
   for (int l = 0; l < HM_MAX_LANES; l++) {
@@ -387,21 +386,7 @@ static int dqp_prepare(hm355_ctx *c, int slot, const hm355_slice_desc *sd, hipSt
   }
   std::vector<int8_t> q(c->numCtus, (int8_t)sd->qp);
   if (!sl.ctuQp.empty()) q = sl.ctuQp;
-  std::vector<CtuRc> rc;
-  if (!sl.ctuLambda.empty()) {          // what TComRdCost::setLambda / TComTrQuant::setLambdas derive from the CTU's lambda, with the CTU's QP (TEncSlice.cpp:793-803)
-    if (!sl.dCtuRc) { if (hipMalloc((void **)&sl.dCtuRc, sizeof(CtuRc) * c->numCtus) != hipSuccess) { delete hp; return fail(c, HM355_ERR_DEVICE, "hm355_set_dqp: allocation failed"); } }
-    rc.resize(c->numCtus);
-    for (int a = 0; a < c->numCtus; a++) {
-      FrameBuf t; memset(&t, 0, sizeof(t));
-      hm355_fill_slice_params(&t, P.bitDepth, q[a], sl.ctuLambda[a], sd->chroma_weight);
-      CtuRc &r = rc[a]; memset(&r, 0, sizeof(r));
-      r.lambda = t.lambda; r.sqrtLambda = t.sqrtLambda; r.lambdaC = t.lambdaC; r.rdFactor[0] = t.rdFactor[0]; r.rdFactor[1] = t.rdFactor[1];
-      r.lambdaMotionSAD = (uint32_t)floor(65536.0 * t.sqrtLambda);
-    }
-    hp->rc = sl.dCtuRc;
-  }
   hipError_t e1 = hipMemcpyAsync(sl.dDqp, hp, sizeof(DqpPic), hipMemcpyHostToDevice, stream);
-  if (e1 == hipSuccess && !rc.empty()) e1 = hipMemcpyAsync(sl.dCtuRc, rc.data(), sizeof(CtuRc) * rc.size(), hipMemcpyHostToDevice, stream);
   if (e1 == hipSuccess) e1 = hipMemcpyAsync(sl.dCtuQp, q.data(), c->numCtus, hipMemcpyHostToDevice, stream);
   if (e1 == hipSuccess) e1 = hipMemcpyAsync(sl.dRowFlag, sl.rowFlag.data(), P.hCtu, hipMemcpyHostToDevice, stream);
   if (e1 == hipSuccess) e1 = hipStreamSynchronize(stream);
@@ -618,17 +603,12 @@ extern "C" int hm355_set_dqp(hm355_ctx *c, int slot, const hm355_dqp_desc *d)
 {
   if (!c || slot < 0 || slot >= (int)c->slots.size()) return HM355_ERR_ARG;
   Slot &sl = c->slots[slot];
-  if (!d || !d->use_dqp) { sl.dqpOn = 0; sl.fb.dqp = NULL; sl.ctuQp.clear(); sl.ctuLambda.clear(); return HM355_OK; }
+  if (!d || !d->use_dqp) { sl.dqpOn = 0; sl.fb.dqp = NULL; sl.ctuQp.clear(); return HM355_OK; }
   const int lo = -6 * (c->hp.bitDepth - 8);
   sl.ctuQp.clear();
   if (d->ctu_qp) {
     for (int a = 0; a < c->numCtus; a++) if (d->ctu_qp[a] < lo || d->ctu_qp[a] > 51) return fail(c, HM355_ERR_ARG, "hm355_set_dqp: CTU QP out of range");
     sl.ctuQp.assign(d->ctu_qp, d->ctu_qp + c->numCtus);
-  }
-  sl.ctuLambda.clear();
-  if (d->ctu_lambda) {
-    for (int a = 0; a < c->numCtus; a++) if (!(d->ctu_lambda[a] > 0)) return fail(c, HM355_ERR_ARG, "hm355_set_dqp: CTU lambda must be positive");
-    sl.ctuLambda.assign(d->ctu_lambda, d->ctu_lambda + c->numCtus);
   }
   sl.dqpOn = 1; sl.dqpFlagIn = d->dqp_flag_in != 0;
   sl.rowFlag.assign(c->hp.hCtu, 0);
@@ -902,7 +882,7 @@ extern "C" int hm355_compress_slices_inter(hm355_ctx *c, int n, const hm355_inte
     if (e == hipSuccess && !c->slots[f].imeta) e = hipMalloc((void **)&c->slots[f].imeta, sizeof(InterMeta) * c->numCtus);
     if (e == hipSuccess) { dIm[f] = c->slots[f].imeta; e = hipMemset(dIm[f], 0, sizeof(InterMeta) * c->numCtus); }
     if (e == hipSuccess) e = da.make(&dIntMv, (size_t)c->numCtus * 32, NULL);
-    fb.imeta = dIm[f]; fb.ip = dIp; fb.intMv = dIntMv; fb.lambdaMotionSAD = sd->lambda_motion_sad;
+    fb.imeta = dIm[f]; fb.ip = dIp; fb.intMv = dIntMv;
     base[f] = sd->base; base[f].slice_type = 2;            // hm355_run validates the common fields
   }
   if (e != hipSuccess) { c->err = std::string("reference picture upload: ") + hipGetErrorString(e); rc = HM355_ERR_DEVICE; }

@@ -2808,11 +2808,6 @@ HM_DEV inline void process_ctu(Shared *e, const Params *P, const WorkItem *it, i
     const QpTab *t = &dp->tab[q + 12];
     e->fb.qp = q;
     for (int k = 0; k < 2; k++) { e->fb.qpPer[k] = t->qpPer[k]; e->fb.qpRem[k] = t->qpRem[k]; e->fb.rdFactor[k] = t->rdFactor[k]; for (int l = 0; l < 4; l++) e->fb.errScale[k][l] = t->errScale[k][l]; }
-    if (dp->rc) {                        // the LCU-level rate control's lambda of this CTU (TEncSlice.cpp:793-803)
-      const CtuRc *r = dp->rc + a;
-      e->fb.lambda = r->lambda; e->fb.sqrtLambda = r->sqrtLambda; e->fb.lambdaC = r->lambdaC;
-      e->fb.rdFactor[0] = r->rdFactor[0]; e->fb.rdFactor[1] = r->rdFactor[1]; e->fb.lambdaMotionSAD = r->lambdaMotionSAD;
-    }
     if (hm_lane() == 0) { e->ws->dq.ctuQp = q; e->ws->dq.refQp = refQp; e->ws->dq.flag = flag; }
     HM_SYNC();
   }

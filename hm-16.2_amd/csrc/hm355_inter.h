@@ -735,7 +735,7 @@ HM_DEV HM_NOINLINE void motion_estimation(Shared *e, int cuZ, int cuDepth, int p
   MvD lt, rb, centre = mvPred;
   if (bi) { centre.x = (int16_t)inX; centre.y = (int16_t)inY; }
   set_search_range(e, centre, bi ? 4 : 64, cuX, cuY, &lt, &rb);   // BipredSearchRange 4 / SearchRange 64
-  e->mcost = e->fb.lambdaMotionSAD; e->mvPredictor = mvPred; e->costScale = 2;
+  e->mcost = s->lambdaMotionSAD; e->mvPredictor = mvPred; e->costScale = 2;
   MvD mv = mvPred;
   uint32_t c;
   HM_PROF_BEGIN(e, PR_ME_INT);
@@ -812,7 +812,7 @@ HM_DEV inline uint32_t template_cost(Shared *e, int cuZ, Rect r, MvD cand, int l
   pred_inter_blk(e, 0, &s->ref[list][refIdx], px, py, clip_mv(e, cand, cuX, cuY), r.w, r.h, blk, bs);
   const uint32_t sad = dist_sad_rect(e->fb.org[0] + (ptrdiff_t)py * e->stride[0] + px, e->stride[0], blk, bs, r.w, r.h, 0, e->bitDepth);
   HM_TRACE(e, 9, ((uint32_t)(uint16_t)cand.x << 16) | (uint16_t)cand.y, sad, 0.0);
-  const double t = floor(((double)1 * (double)e->fb.lambdaMotionSAD) + 0.5) / 65536.0;
+  const double t = floor(((double)1 * (double)s->lambdaMotionSAD) + 0.5) / 65536.0;
   return (uint32_t)floor((double)sad + t);
 }
 HM_DEV inline MvD estimate_mvp_amvp(Shared *e, int cuZ, int cuDepth, int partSize, int puIdx, int list, int refIdx, AmvpInfo *info, int *bestIdx, uint32_t *distBiP)
@@ -834,7 +834,7 @@ HM_DEV inline MvD estimate_mvp_amvp(Shared *e, int cuZ, int cuDepth, int partSiz
 HM_DEV inline void check_best_mvp(Shared *e, const AmvpInfo *info, MvD mv, MvD *mvPred, int *mvpIdx, uint32_t *bits, uint32_t *cost)
 {
   if (info->n < 2) return;
-  e->mcost = e->fb.lambdaMotionSAD; e->costScale = 0;
+  e->mcost = e->fb.ip->lambdaMotionSAD; e->costScale = 0;
   int bestIdx = *mvpIdx;
   e->mvPredictor = *mvPred;
   const int orgBits = (int)mc_bits(e, mv.x, mv.y) + 1;
@@ -1014,7 +1014,7 @@ HM_DEV HM_NOINLINE void pred_inter_search(Shared *e, int cuZ, int cuDepth, int p
       }
     }
     if (partSize != SIZE_2Nx2N) {
-      e->mcost = e->fb.lambdaMotionSAD;
+      e->mcost = s->lambdaMotionSAD;
       uint32_t meCost = 0xffffffffu;
       if (testNormalMC) {
         motion_compensation_pu(e, cuZ, r, e->ws->tmpPred);

@@ -103,13 +103,7 @@ struct CtuDqp {                      // what a searched CTU leaves for the next 
   uint8_t flagOut;                   // TEncCu::m_bEncodeDQP after its encodeCtu
   int16_t firstZ, pad;               // first CU (z order) with a coded block, 256 if none: partitions before it carry refQp, the rest qp (m_phQP)
 };
-struct CtuRc {                        // LCU-level rate control (stage 2): what TEncSlice.cpp:776-808 sets before a CTU's search, host-computed
-  double lambda, sqrtLambda, lambdaC;  // TComRdCost::setLambda; TComTrQuant::setLambdas (chroma: lambda / the slice's chroma weight)
-  int64_t rdFactor[2];                 // the sign-bit-hiding factor for the CTU's QP and lambda (TComTrQuant.cpp:2382-2386)
-  uint32_t lambdaMotionSAD, pad_;      // TComRdCost::m_uiLambdaMotionSAD[0] = floor(65536 sqrt(lambda))
-};
 struct DqpPic {
-  const CtuRc *rc;                     // [numCtus] or NULL: every CTU at the slice lambda
   int32_t flagIn, sliceQp;           // m_bEncodeDQP on entry to the slice
   const int8_t *ctuQp;               // [numCtus] QP of every CTU (TEncCu::xComputeQP / TEncRateCtrl::getRCQP)
   CtuDqp *out;                       // [numCtus]
@@ -141,8 +135,6 @@ struct FrameBuf {
   double errScale[2][4];             // [luma/chroma][log2-2]  TComTrQuant::setErrScaleCoeff :2933
   int64_t rdFactor[2];               // sign-bit-hiding factor  TComTrQuant.cpp:2382-2386
   int32_t qp, qpPer[2], qpRem[2];
-  uint32_t lambdaMotionSAD;          // TComRdCost::m_uiLambdaMotionSAD[0] of the slice (InterPic::lambdaMotionSAD) or, under the LCU-level rate control, of the CTU
-  uint32_t pad_[2];
 };
 
 struct Params {

@@ -71,7 +71,7 @@ class SaoDesc(C.Structure):
 
 
 class DqpDesc(C.Structure):
-    _fields_ = [("use_dqp", C.c_int32), ("dqp_flag_in", C.c_int32), ("ctu_qp", C.c_void_p), ("ctu_lambda", C.c_void_p)]
+    _fields_ = [("use_dqp", C.c_int32), ("dqp_flag_in", C.c_int32), ("ctu_qp", C.c_void_p)]
 
 
 class BitsDesc(C.Structure):
@@ -238,14 +238,11 @@ class Encoder:
         self.lib.hm355_last_run_info(self.h_, C.byref(ms), C.byref(launches))
         return ms.value, launches.value
 
-    def set_dqp(self, slot, ctu_qp=None, dqp_flag_in=0, use_dqp=1, ctu_lambda=None):
-        """hm355_set_dqp: the following searches / deblocking / bitstream pass of the slot run with cu_qp_delta; ctu_qp int8 [numCtus] or None;
-        ctu_lambda float64 [numCtus] or None (the LCU-level rate control's lambda of every CTU)"""
+    def set_dqp(self, slot, ctu_qp=None, dqp_flag_in=0, use_dqp=1):
+        """hm355_set_dqp: the following searches / deblocking / bitstream pass of the slot run with cu_qp_delta; ctu_qp int8 [numCtus] or None"""
         q = np.ascontiguousarray(ctu_qp, np.int8) if ctu_qp is not None else None
         assert q is None or len(q) == self.num_ctus
-        lam = np.ascontiguousarray(ctu_lambda, np.float64) if ctu_lambda is not None else None
-        assert lam is None or len(lam) == self.num_ctus
-        d = DqpDesc(int(use_dqp), int(dqp_flag_in), q.ctypes.data if q is not None else None, lam.ctypes.data if lam is not None else None)
+        d = DqpDesc(int(use_dqp), int(dqp_flag_in), q.ctypes.data if q is not None else None)
         self._check(self.lib.hm355_set_dqp(self.h_, slot, C.byref(d)), "hm355_set_dqp")
 
     def get_dqp(self, slot):

@@ -302,7 +302,7 @@ Void TEncSlice::compressSlice(TComPic *pcPic)
   if (m_pcEncTop->getUseAdaptiveQP()) { // cu_qp_delta is on (TEncTop::xInitPPS :608-622): every CTU at its xComputeQP, TEncCu::m_bEncodeDQP handed in
     std::vector<int8_t> qp(pcPic->getNumberOfCtusInFrame());
     for (UInt a = 0; a < pcPic->getNumberOfCtusInFrame(); a++) qp[a] = (int8_t)xComputeQP(pcPic, a, pcSlice->getSliceQp());
-    hm355_dqp_desc dq; dq.use_dqp = 1; dq.dqp_flag_in = m_bEncodeDQP ? 1 : 0; dq.ctu_qp = qp.data(); dq.ctu_lambda = NULL;
+    hm355_dqp_desc dq; dq.use_dqp = 1; dq.dqp_flag_in = m_bEncodeDQP ? 1 : 0; dq.ctu_qp = qp.data();
     if (hm355_set_dqp(m_pcEncTop->getDeviceContext(), 0, &dq) != HM355_OK) { fprintf(stderr, "TEncSlice::compressSlice: %s\n", hm355_last_error(m_pcEncTop->getDeviceContext())); exit(EXIT_FAILURE); }
   }
   if (!pcSlice->isIntra()) { // P / B slice: the reference pictures are device-resident (hm355_ref_from_slot)

@@ -222,8 +222,6 @@ typedef struct {
   int32_t use_dqp;                     /* PPS cu_qp_delta_enabled_flag */
   int32_t dqp_flag_in;                 /* TEncCu::m_bEncodeDQP on entry (what the previous picture's encodeSlice left) */
   const int8_t *ctu_qp;                /* [numCtus] QP of every CTU; NULL: the slice QP (picture-level rate control) */
-  const double *ctu_lambda;            /* [numCtus] lambda of every CTU's search: the LCU-level rate control sets one per CTU before compressCtu (TEncSlice.cpp:776-808:
-                                          TComRdCost::setLambda, TComTrQuant::setLambdas with the slice's chroma weight); NULL: the slice lambda */
 } hm355_dqp_desc;
 int hm355_set_dqp(hm355_ctx *ctx, int slot, const hm355_dqp_desc *desc);
 int hm355_get_dqp(hm355_ctx *ctx, int slot, int8_t *qp_out, int32_t *dqp_flag_out);

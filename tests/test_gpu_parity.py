@@ -245,14 +245,12 @@ def test_hip_closed_loop_on_device_matches_reference(hm, name):
     enc.close()
 
 
-@pytest.mark.parametrize("name", common.DQP_CASES + common.LCU_RC_CASES)
+@pytest.mark.parametrize("name", common.DQP_CASES)
 def test_hip_cu_qp_delta_matches_reference(hm, name):
     """the clips the reference encoded with AdaptiveQP (I / P / B, WPP on and off) and with the picture-level rate control, closed loop
     on the device: hm355_preanalyze + the reference's double arithmetic give the reference's activities and per-CTU QPs; the search with
     hm355_set_dqp reproduces decisions, motion, coefficients, costs, reconstruction, TComDataCU::m_phQP and TEncCu::m_bEncodeDQP; deblocking with
-    the CUs' QPs, SAO and the bitstream pass with the cu_qp_delta syntax reproduce the finished picture and the slice data bytes.
-    LCU_RC_CASES (n4 stage 2): clips encoded with the LCU-level rate control -- the model gave every CTU a QP AND a lambda (the fixture's 'L' record);
-    hm355_set_dqp takes both (hm355_dqp_desc::ctu_lambda) and the same closed loop reproduces the reference."""
+    the CUs' QPs, SAO and the bitstream pass with the cu_qp_delta syntax reproduce the finished picture and the slice data bytes."""
     saod, bitd = {}, {}
     cfg, slices, finals = common.load_ldp_case(name, sao=saod, bits=bitd)
     w, h, bd = cfg["width"], cfg["height"], cfg["bit_depth"]
@@ -269,10 +267,7 @@ def test_hip_cu_qp_delta_matches_reference(hm, name):
             act, avg = hm.aq_activities(enc.preanalyze(0))
             assert np.array_equal(act, q["activity"]) and avg == float(q["avg_activity"]), f"{what}: activities"
             ctu_qp = hm.aq_ctu_qp(act, avg, int(q["aq_range"]), int(r["qp"]), bd)
-        ctu_lambda = None
-        if r.get("lcu_rc") is not None:
-            ctu_qp, ctu_lambda = r["lcu_rc"]["ctu_qp"].astype(np.int8), r["lcu_rc"]["ctu_lambda"]
-        enc.set_dqp(0, ctu_qp, int(q["dqp_flag_in"]), ctu_lambda=ctu_lambda)
+        enc.set_dqp(0, ctu_qp, int(q["dqp_flag_in"]))
         if st == 2:
             sl = (hm.SliceDesc * 1)(hm.SliceDesc(2, int(r["qp"]), float(r["lambda"]), float(r["weight_cb"])))
             enc._check(enc.lib.hm355_run(enc.h_, 1, sl), "hm355_run")
