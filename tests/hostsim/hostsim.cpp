@@ -49,6 +49,18 @@ int main(int argc, char **argv)
   std::vector<WorkItem> items; std::vector<int> stepStart;
   hm355_build_schedule(P.wCtu, P.hCtu, wpp, frames, items, stepStart);
   static Shared sh;
+  if (getenv("HM355_DIRTY")) {
+    // debugging aid: everything the search writes before it reads may hold anything -- fill the workspace, the LDS state, the reconstruction, the decision /
+    // coefficient / statistics arrays and the CABAC hand-off states with noise; the result must not change (tests/test_host_logic.py)
+    unsigned long long x = 88172645463325252ull ^ (unsigned long long)atoll(getenv("HM355_DIRTY"));
+    auto fill = [&](void *p, size_t n) { unsigned char *b = (unsigned char *)p; for (size_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; b[i] = (unsigned char)(x >> 24); } };
+    fill(P.ws, sizeof(WorkSpace)); fill(&sh, sizeof(sh));
+    for (int f = 0; f < frames; f++) {
+      FrameBuf &fb = fbs[f];
+      for (int c = 0; c < 3; c++) fill(fb.rec[c], (size_t)P.stride[c] * P.hCtu * (c ? 32 : 64) * sizeof(Pel));
+      fill(fb.meta, nctu * sizeof(CtuMeta)); fill(fb.coef, (size_t)nctu * HM_COEF_CTU * sizeof(TCoeff)); fill(fb.stat, nctu * sizeof(CtuStat)); fill(fb.endState, nctu * sizeof(Cabac));
+    }
+  }
   for (size_t i = 0; i < items.size(); i++) process_ctu(&sh, &P, &items[i], 0);
   fwrite("HMD1", 1, 4, fo);
   uint32_t hdr[5] = { (uint32_t)w, (uint32_t)h, (uint32_t)bd, 64, (uint32_t)frames }; fwrite(hdr, 4, 5, fo);

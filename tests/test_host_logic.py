@@ -100,6 +100,27 @@ def test_hostsim_of_kernel_source_matches_reference_fixture(tmp_path):
             assert np.array_equal(got[i][1], rec)
 
 
+def test_hostsim_result_does_not_depend_on_what_the_buffers_held(tmp_path):
+    """Everything the search writes before it reads may hold anything: the host twin with its workspace, LDS state, reconstruction planes, decision /
+    coefficient / statistics arrays and CABAC hand-off states filled with noise (HM355_DIRTY, three seeds) gives the result of the zero-filled run."""
+    import filecmp
+    import synth
+    out = tmp_path / "hostsim"
+    subprocess.run(["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-w", "-o", str(out), os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")], check=True)
+    for (w, h, bd, qp, wpp, seed) in [(192, 128, 10, 30, 1, 31), (200, 136, 8, 22, 0, 9)]:
+        yuv = tmp_path / f"in_{w}.yuv"
+        synth.write_yuv(str(yuv), w, h, bd, 2, seed)
+        dumps = []
+        for d in (None, "1", "2", "3"):
+            dump = tmp_path / f"d_{w}_{d}.bin"
+            env = dict(os.environ)
+            if d:
+                env["HM355_DIRTY"] = d
+            subprocess.run([str(out), str(yuv), str(w), str(h), str(bd), "2", str(qp), str(wpp), str(dump)], check=True, env=env)
+            dumps.append(str(dump))
+        assert all(filecmp.cmp(dumps[0], x, shallow=False) for x in dumps[1:]), f"{w}x{h}: the result depends on uninitialised memory"
+
+
 def test_hostsim_of_kernel_source_matches_oracle_at_extreme_qps(tmp_path):
     """Dense 32x32 blocks (low QP: RDOQ with every coefficient group coded, sign-bit hiding everywhere), nearly empty ones (high QP),
     with and without WPP: the code paths behind the early terminations of the CU / residual quadtrees and the LDS-resident RDOQ state
