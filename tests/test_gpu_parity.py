@@ -520,36 +520,6 @@ def test_hip_batch_equals_single(hm):
     enc.close()
 
 
-def test_hip_pipelined_lanes_equal_blocking_run(hm):
-    """hm355_run_begin / hm355_run_wait: four groups of pictures searched by four launches in flight at once (each lane its own stream,
-    scratch areas, work list and scheduler words) equal the same pictures through the blocking hm355_run; a lane can be reused after
-    its wait, a busy lane and overlapping slots are refused."""
-    w, h, bd, qp, per = 192, 128, 10, 30, 3
-    planes = [synth.frame(w, h, bd, i % 5, 31) for i in range(4 * per)]
-    enc = hm.Encoder(w, h, bd, 1, max_batch=4 * per)
-    want = enc.compress(planes, qp)
-    for rep in range(2):                                    # the second round reuses every lane's cached work list
-        for i, p in enumerate(planes):
-            enc.upload(i, planes[(i + rep) % len(planes)])
-        for lane in range(4):
-            enc.run_begin(lane, lane * per, per, qp)
-        with pytest.raises(RuntimeError):
-            enc.run_begin(1, per, per, qp)                  # lane 1 is busy
-        assert all(enc.run_wait(lane) > 0 for lane in (2, 0, 3, 1))
-        with pytest.raises(RuntimeError):
-            enc.run_wait(0)                                 # nothing in flight
-        for i in range(4 * per):
-            rec, ctus, _ = enc.download(i)
-            common.assert_ctus_equal(ctus, want[(i + rep) % len(planes)][1], f"round {rep} slot {i}")
-            for k in range(3):
-                assert np.array_equal(rec[k], want[(i + rep) % len(planes)][0][k])
-    enc.run_begin(0, 0, 2 * per, qp)
-    with pytest.raises(RuntimeError):
-        enc.run_begin(1, per, per, qp)                      # slots overlap the launch in flight on lane 0
-    enc.run_wait(0)
-    enc.close()
-
-
 @pytest.mark.parametrize("w,h,bd,qp,wpp,seed", [(256, 192, 10, 32, 1, 41), (200, 136, 8, 26, 0, 42), (448, 256, 8, 38, 1, 43)])
 def test_hip_team_search_equals_single_wavefront_search(hm, monkeypatch, w, h, bd, qp, wpp, seed):
     """hm355_team.h: a CTU searched by a team of wavefronts (the unsplit candidate of every CU depth and the 2Nx2N candidate of the 8x8 CUs
@@ -1048,3 +1018,33 @@ def test_cpp_host_mirror_inter_configurations(tmp_path, name):
             assert np.array_equal(rec[c], finals[poc]["rec"][c]), f"{what}: finished picture plane {c}"
         assert bits[i] == bd[poc]["substreams"], f"{what}: slice data bytes"
     assert off == len(buf)
+
+
+def test_hip_pipelined_lanes_equal_blocking_run(hm):
+    """hm355_run_begin / hm355_run_wait: four groups of pictures searched by four launches in flight at once (each lane its own stream,
+    scratch areas, work list and scheduler words) equal the same pictures through the blocking hm355_run; a lane can be reused after
+    its wait, a busy lane and overlapping slots are refused."""
+    w, h, bd, qp, per = 192, 128, 10, 30, 3
+    planes = [synth.frame(w, h, bd, i % 5, 31) for i in range(4 * per)]
+    enc = hm.Encoder(w, h, bd, 1, max_batch=4 * per)
+    want = enc.compress(planes, qp)
+    for rep in range(2):                                    # the second round reuses every lane's cached work list
+        for i, p in enumerate(planes):
+            enc.upload(i, planes[(i + rep) % len(planes)])
+        for lane in range(4):
+            enc.run_begin(lane, lane * per, per, qp)
+        with pytest.raises(RuntimeError):
+            enc.run_begin(1, per, per, qp)                  # lane 1 is busy
+        assert all(enc.run_wait(lane) > 0 for lane in (2, 0, 3, 1))
+        with pytest.raises(RuntimeError):
+            enc.run_wait(0)                                 # nothing in flight
+        for i in range(4 * per):
+            rec, ctus, _ = enc.download(i)
+            common.assert_ctus_equal(ctus, want[(i + rep) % len(planes)][1], f"round {rep} slot {i}")
+            for k in range(3):
+                assert np.array_equal(rec[k], want[(i + rep) % len(planes)][0][k])
+    enc.run_begin(0, 0, 2 * per, qp)
+    with pytest.raises(RuntimeError):
+        enc.run_begin(1, per, per, qp)                      # slots overlap the launch in flight on lane 0
+    enc.run_wait(0)
+    enc.close()
